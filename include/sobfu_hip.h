@@ -1,0 +1,215 @@
+/*
+ * sobfu_hip.h -- C ABI of the MI355X-native SobolevFusion hot path (libsobfu_hip.so, gfx950).
+ *
+ * This is the drop-in boundary: one entry point per host-callable launcher of the reference's "L1 device
+ * API" (include/sobfu/{solver,vector_fields,reductor}.hpp `namespace device`, include/kfusion/internal.hpp
+ * :189-257), plus an opaque solver handle replacing sobfu::cuda::Solver's workspace + hot loop.  The C++
+ * shells under include/sobfu_amd/ rebuild the reference's class surface on top of it; INTEGRATION.md shows
+ * the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer marked `d_` is a DEVICE pointer the callee does not own;
+ *  - volumes are dense, x fastest: idx = x + X*(y + Y*z) (reference: src/sobfu/cuda/vector_fields.cu:20-22);
+ *    TSDF voxel = float2 {tsdf, weight} (8 B), vector-field voxel = float4 with w == 0 (16 B), Jacobian voxel
+ *    = 4 x float4 (64 B, row 3 unused) -- the reference's layouts, unchanged;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Launches are asynchronous; nothing
+ *    synchronises unless documented (the reference's per-call cudaDeviceSynchronize is NOT reproduced);
+ *  - return value: 0 on success, otherwise a hipError_t (positive) or a SOBFU_E_* code (negative).  The
+ *    reference prints and calls exit(0) on any CUDA error (src/kfusion/device_memory.cpp:7-10); the C++ shells
+ *    keep that behaviour, the C ABI itself never exits.
+ */
+#ifndef SOBFU_HIP_H
+#define SOBFU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOBFU_HIP_ABI_VERSION 1
+
+#define SOBFU_E_BADARG (-1)      /* null pointer, non-positive dims, ... */
+#define SOBFU_E_FILTER (-2)      /* (s, lambda) not in the reference's Sobolev filter table */
+#define SOBFU_E_UNSUPPORTED (-3) /* valid in the reference but outside this build's limits */
+
+int sobfu_hip_abi_version(void);
+/* Human-readable text for a return code of this library. */
+const char* sobfu_hip_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------------
+ * TSDF volume  (kfusion::device::*, include/kfusion/internal.hpp:189-198, src/kfusion/cuda/tsdf_volume.cu)
+ * ---------------------------------------------------------------------------------------------------- */
+/* clear_volume (tsdf_volume.cu:23-46) */
+int sobfu_hip_clear_volume(float* d_vol, int X, int Y, int Z, void* stream);
+/* integrate(dists, volume, aff, proj) (tsdf_volume.cu:56-101,141-162).  d_dists: pitched float image
+ * (step in bytes) of ray lengths in metres; R (row-major 3x3) and t: vol2cam = camera_pose^-1 * volume_pose
+ * (src/kfusion/tsdf_volume.cpp:95-106); voxel_size[3]; trunc/eta in metres.  Voxels that project outside
+ * the image, onto Dp <= 0 or behind the camera are left untouched. */
+int sobfu_hip_integrate_depth(const float* d_dists, int dists_step_bytes, int rows, int cols, float* d_vol, int X,
+                              int Y, int Z, const float voxel_size[3], float trunc_dist, float eta,
+                              const float R[9], const float t[3], float fx, float fy, float cx, float cy,
+                              void* stream);
+/* integrate(phi_global, phi_n_psi) (tsdf_volume.cu:103-130,164-173): running weighted average fusion. */
+int sobfu_hip_integrate_fuse(float* d_phi_global, const float* d_phi_n_psi, int X, int Y, int Z, float max_weight,
+                             void* stream);
+/* init_{sphere,box,ellipsoid,plane,torus} (tsdf_volume.cu:181-382): analytic truncated SDFs. */
+int sobfu_hip_init_sphere(float* d_vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist, float eta,
+                          const float centre[3], float radius, void* stream);
+int sobfu_hip_init_box(float* d_vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                       const float b[3], void* stream);
+int sobfu_hip_init_ellipsoid(float* d_vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                             const float r[3], void* stream);
+int sobfu_hip_init_plane(float* d_vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist, float z,
+                         void* stream);
+int sobfu_hip_init_torus(float* d_vol, int X, int Y, int Z, const float voxel_size[3], float trunc_dist,
+                         const float t[2], void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * depth pre-steps  (include/kfusion/internal.hpp:236-239, src/kfusion/cuda/imgproc.cu:8-77,233-254)
+ * ---------------------------------------------------------------------------------------------------- */
+/* bilateralFilter: uint16 mm depth, sigma_depth in metres (scaled x1000 inside, imgproc.cu:43). */
+int sobfu_hip_bilateral_filter(const uint16_t* d_src, int src_step_bytes, uint16_t* d_dst, int dst_step_bytes,
+                               int rows, int cols, int kernel_size, float sigma_spatial, float sigma_depth,
+                               void* stream);
+/* truncateDepth: depth > max_dist_m*1000 -> 0, in place. */
+int sobfu_hip_truncate_depth(uint16_t* d_depth, int step_bytes, int rows, int cols, float max_dist_m, void* stream);
+/* compute_dists: uint16 mm depth -> ray length in metres. */
+int sobfu_hip_compute_dists(const uint16_t* d_depth, int depth_step_bytes, float* d_dists, int dists_step_bytes,
+                            int rows, int cols, float fx, float fy, float cx, float cy, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * vector fields  (sobfu::device::*, include/sobfu/vector_fields.hpp:140-241, src/sobfu/cuda/vector_fields.cu)
+ * ---------------------------------------------------------------------------------------------------- */
+int sobfu_hip_clear_field(float* d_field, int X, int Y, int Z, void* stream);   /* clear (:28-50) */
+int sobfu_hip_init_identity(float* d_psi, int X, int Y, int Z, void* stream);   /* init_identity (:56-79) */
+/* apply (:81-109): phi_warped(x) = trilinear phi(psi(x)), weight = nearest-floor weight. */
+int sobfu_hip_apply(const float* d_phi, float* d_phi_warped, const float* d_psi, int X, int Y, int Z, void* stream);
+/* estimate_inverse (:111-138): n_sweeps (reference: 48) in-place fixed-point sweeps on d_psi_inv. */
+int sobfu_hip_estimate_inverse(const float* d_psi, float* d_psi_inv, int X, int Y, int Z, int n_sweeps,
+                               void* stream);
+/* TsdfDifferentiator::calculate (:144-208): central-difference gradient, exact 0 on boundary faces. */
+int sobfu_hip_tsdf_gradient(const float* d_vol, float* d_grad, int X, int Y, int Z, void* stream);
+/* SecondOrderDifferentiator::calculate (:278-337): NEGATIVE 7-point Laplacian of psi. */
+int sobfu_hip_laplacian(const float* d_psi, float* d_L, int X, int Y, int Z, void* stream);
+/* Differentiator::calculate (mode 0) / calculate_deformation_jacobian (mode 1) (:389-472). */
+int sobfu_hip_jacobian(const float* d_psi, float* d_J, int X, int Y, int Z, int mode, void* stream);
+int sobfu_hip_clear_jacobian(float* d_J, int X, int Y, int Z, void* stream);    /* clear(Jacobian&) (:353-383) */
+
+/* ------------------------------------------------------------------------------------------------------
+ * solver launchers  (include/sobfu/solver.hpp:109-136, src/sobfu/cuda/solver.cu)
+ * ---------------------------------------------------------------------------------------------------- */
+/* decompose_sobolev_filter (src/sobfu/solver.cpp:160-262): writes s normalised taps to host array out. */
+int sobfu_hip_sobolev_filter(int s, float lambda, float* out);
+/* calculate_potential_gradient (solver.cu:15-47) */
+int sobfu_hip_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_grad,
+                                 const float* d_L, float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream);
+/* convolution_{rows,columns,depth} (solver.cu:237-459): rows ASSIGNS dst = Sx*src, columns / depth ACCUMULATE
+ * dst += S*src.  taps: 7 HOST floats (the reference's __constant__ S, solver.cu:229-234, passed by value so the
+ * library holds no global state). */
+int sobfu_hip_convolution_rows(float* d_dst, const float* d_src, const float taps[7], int w, int h, int d,
+                               void* stream);
+int sobfu_hip_convolution_columns(float* d_dst, const float* d_src, const float taps[7], int w, int h, int d,
+                                  void* stream);
+int sobfu_hip_convolution_depth(float* d_dst, const float* d_src, const float taps[7], int w, int h, int d,
+                                void* stream);
+/* update_psi (solver.cu:53-79): updates = alpha*nabla_U_S; psi -= updates. */
+int sobfu_hip_update_psi(float* d_psi, const float* d_nabla_U_S, float* d_updates, float alpha, int X, int Y, int Z,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * reductions  (sobfu::device::Reductor, include/sobfu/reductor.hpp:24-50, src/sobfu/reductor.cpp,
+ * src/sobfu/cuda/reductor.cu, launch sizing src/sobfu/precomp.cpp:20-43)
+ * ---------------------------------------------------------------------------------------------------- */
+int sobfu_hip_reduce_config(int n, int* blocks, int* threads);
+/* Each call runs the block reduction with the reference's tree shape, copies the block partials to the host
+ * and finishes on the CPU exactly as final_reduce / final_reduce_max do; it SYNCHRONISES the stream.
+ * d_scratch: device scratch of >= blocks*8 bytes. */
+int sobfu_hip_data_energy(const float* d_phi_global, const float* d_phi_n, int n, void* d_scratch, float* out,
+                          void* stream);
+int sobfu_hip_reg_energy_sobolev(const float* d_J, int n, void* d_scratch, float* out, void* stream);
+/* out[0] = max ||update|| (sqrt rounded down), out[1] = float-encoded linear index (reductor.cu:357-368). */
+int sobfu_hip_max_update_norm(const float* d_updates, int n, void* d_scratch, float out[2], void* stream);
+/* Same value as reg_energy_sobolev(J(psi, mode 1)) without materialising the 64 B/voxel Jacobian. */
+int sobfu_hip_reg_energy_sobolev_from_psi(const float* d_psi, int X, int Y, int Z, void* d_scratch, float* out,
+                                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * fused iteration kernels (MI355X-native decomposition of one pass of solver.cu:114-193; no reference
+ * counterpart -- results are bit-identical to the launcher sequence above)
+ * ---------------------------------------------------------------------------------------------------- */
+/* pass A: nabla_U = (phi_n_psi - phi_global) * grad(phi_n_psi) + w_reg * (-Lap psi)   [a14 + a15 + a17] */
+int sobfu_hip_fused_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
+                                       float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream);
+/* pass B: u = alpha * (Sx + Sy + Sz)(nabla_U); psi -= u; phi_n_psi = phi_n o psi; max ||u||^2 folded into
+ * d_max_sq_slots[256] with atomic max (uint32 view of non-negative floats)   [a18 + a19 + a12 + a20].
+ * d_updates may be NULL (updates consumed in registers). */
+int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n,
+                                        float* d_phi_n_psi, float* d_updates, uint32_t* d_max_sq_slots,
+                                        const float taps[7], float alpha, int X, int Y, int Z, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * solver handle  (sobfu::cuda::Solver, include/sobfu/solver.hpp:52-101, src/sobfu/solver.cpp:7-101)
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct sobfu_hip_solver sobfu_hip_solver; /* opaque */
+
+typedef struct {
+    int verbosity;         /* 0 quiet; 1 energies on iterations {1, k*50, max_iter}; 2 every iteration */
+    int max_iter;
+    int s;                 /* Sobolev filter length (only 7 taps reach the kernels, solver.cu:211-234) */
+    float max_update_norm; /* convergence threshold: break when max ||update|| <= this (solver.cu:183) */
+    float lambda;
+    float alpha;
+    float w_reg;
+} sobfu_hip_solver_params; /* = SolverParams, include/sobfu/solver.hpp:16-19 */
+
+typedef struct {
+    int iterations;        /* iterations executed (iter at break, or max_iter) */
+    int converged;         /* 1 if the max-update-norm test fired */
+    float last_max_update_norm;
+    float last_max_update_index; /* float-encoded linear voxel index; NaN in the fast (quiet) path */
+    float last_e_data, last_e_reg; /* last energies evaluated (verbosity > 0), else NaN */
+} sobfu_hip_solver_report;
+
+/* Allocates the per-solver device workspace (the reference's SpatialGradients + Reductor, minus the fields
+ * it never touches: nabla_phi_n, J_inv, L_o_psi_inv -- src/sobfu/vector_fields.cpp:152-161). */
+int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const sobfu_hip_solver_params* params);
+int sobfu_hip_solver_destroy(sobfu_hip_solver* s);
+int sobfu_hip_solver_set_params(sobfu_hip_solver* s, const sobfu_hip_solver_params* params);
+/* Bytes of device memory held by the handle. */
+size_t sobfu_hip_solver_workspace_bytes(const sobfu_hip_solver* s);
+/* Solver::estimate_psi (src/sobfu/solver.cpp:69-101 -> src/sobfu/cuda/solver.cu:85-205).  Mutates psi,
+ * psi_inv, phi_n_psi, phi_global_psi_inv; reads phi_global, phi_n.  Synchronises `stream` before returning
+ * (the reference synchronises every iteration).  per_iter_max_norm (host, may be NULL): max_iter floats. */
+int sobfu_hip_solver_estimate_psi(sobfu_hip_solver* s, const float* d_phi_global, float* d_phi_global_psi_inv,
+                                  const float* d_phi_n, float* d_phi_n_psi, float* d_psi, float* d_psi_inv,
+                                  sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream);
+/* Only the gradient-descent loop (solver.cu:106-193), no inverse / canonical warp: the unit bench.py times.
+ * Always runs exactly n_iters iterations when max_update_norm < 0. */
+int sobfu_hip_solver_iterate(sobfu_hip_solver* s, const float* d_phi_global, const float* d_phi_n,
+                             float* d_phi_n_psi, float* d_psi, int n_iters, sobfu_hip_solver_report* report,
+                             float* per_iter_max_norm, void* stream);
+/* Pointer to the `updates` buffer (Reductor::updates, src/sobfu/reductor.cpp:26); valid until destroy.  Holds
+ * the last iteration's updates only when verbosity > 0 or keep_updates was set. */
+float* sobfu_hip_solver_updates(sobfu_hip_solver* s);
+int sobfu_hip_solver_keep_updates(sobfu_hip_solver* s, int keep);
+/* Per-kernel timing of the quiet path with HIP events recorded on the solver's stream around every pass A / pass B
+ * launch; totals accumulate over iterations until reset. */
+int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int enable);
+int sobfu_hip_solver_get_profile(sobfu_hip_solver* s, float* ms_pass_a, float* ms_pass_b, int* launches, int reset);
+/* Callback invoked by estimate_psi for every line the reference prints with std::cout (solver.cu:115-190);
+ * NULL (default) = print to stdout like the reference. */
+typedef void (*sobfu_hip_log_fn)(const char* line, void* user);
+int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#endif /* SOBFU_HIP_H */

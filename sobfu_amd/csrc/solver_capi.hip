@@ -1,0 +1,401 @@
+// Solver handle: workspace + the gradient-descent loop of sobfu::device::estimate_psi
+// (reference: src/sobfu/cuda/solver.cu:85-205, src/sobfu/solver.cpp:7-101,160-262).
+//
+// One iteration = pass A + pass B (solver_kernels.hip) on ONE stream.  The reference copies block partials to
+// the host and tests convergence on the CPU every iteration (src/sobfu/reductor.cpp:52-57); here the max update
+// norm of iteration k lives in 256 device slots, iteration k+1's kernels test it themselves and turn into no-ops
+// once it is <= max_update_norm, and the host only looks every kCheckEvery iterations -- the iteration at which
+// the solver stops, and every array it leaves behind, are exactly the reference's.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sobfu_device.hpp"
+#include "sobfu_hip.h"
+#include "sobfu_host.hpp"
+
+namespace sobfu_hip {
+int pick_zc(int X, int Y, int Z, int ty);
+int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream);
+int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
+                  const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
+                  float max_update_norm, int zc, hipStream_t stream);
+}  // namespace sobfu_hip
+
+namespace {
+
+constexpr int kSlots      = 256;
+constexpr int kCheckEvery = 32;
+
+float host_sqrt_rd(float s) {  // __fsqrt_rd
+    float r = std::sqrt(s);
+    if (r > 0.f && (double) r * (double) r > (double) s) r = std::nextafterf(r, -INFINITY);
+    return r;
+}
+
+float slots_to_norm(const uint32_t* s) {
+    uint32_t m = 0;
+    for (int i = 0; i < kSlots; ++i) m = s[i] > m ? s[i] : m;
+    float f;
+    std::memcpy(&f, &m, 4);
+    return host_sqrt_rd(f);
+}
+
+}  // namespace
+
+struct sobfu_hip_solver {
+    int X = 0, Y = 0, Z = 0;
+    size_t N = 0;
+    sobfu_hip_solver_params p{};
+    float taps[7]{};
+    // device workspace
+    float* nabla_U     = nullptr;  // 16 B/voxel
+    float* updates     = nullptr;  // 16 B/voxel, allocated on first need (verbosity > 0 or keep_updates)
+    uint32_t* slots    = nullptr;  // (slots_iters + 1) x 256
+    void* red_scratch  = nullptr;  // 65536 x 8 B block partials
+    int slots_iters    = 0;
+    bool keep_updates  = false;
+    sobfu_hip_log_fn log_fn = nullptr;
+    void* log_user          = nullptr;
+    bool log_set            = false;
+    size_t bytes            = 0;
+    // optional per-kernel timing (HIP events on the solver's stream)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    double ms_a = 0, ms_b = 0;
+    int prof_launches = 0;
+
+    void log(const std::string& line) const {
+        if (log_set) {
+            if (log_fn) log_fn(line.c_str(), log_user);
+        } else {
+            std::printf("%s\n", line.c_str());  // the reference writes to std::cout
+        }
+    }
+};
+
+namespace {
+
+std::string fmt_g(float v) {  // std::cout default float formatting (%g, precision 6)
+    char b[64];
+    std::snprintf(b, sizeof b, "%g", (double) v);
+    return b;
+}
+
+int ensure_slots(sobfu_hip_solver* s, int iters) {
+    if (iters <= s->slots_iters) return 0;
+    if (s->slots) {
+        SOBFU_HIP_TRY(hipFree(s->slots));
+        s->bytes -= (size_t) (s->slots_iters + 1) * kSlots * 4;
+    }
+    s->slots = nullptr;
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->slots, (size_t) (iters + 1) * kSlots * 4));
+    s->slots_iters = iters;
+    s->bytes += (size_t) (iters + 1) * kSlots * 4;
+    return 0;
+}
+
+int ensure_updates(sobfu_hip_solver* s) {
+    if (s->updates) return 0;
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->updates, s->N * 16));
+    s->bytes += s->N * 16;
+    return 0;
+}
+
+int set_params(sobfu_hip_solver* s, const sobfu_hip_solver_params* p) {
+    SOBFU_CHECK_ARGS(p && p->max_iter >= 0);
+    // The kernels use 7 taps whatever s is (KERNEL_RADIUS 3, solver.cu:211-234: cudaMemcpyToSymbol copies the first
+    // 7 floats of the s-tap table).  s < 7 would read past the reference's allocation -> refused.
+    if (p->s < 7 || p->s > 16) return p->s < 7 ? SOBFU_E_UNSUPPORTED : SOBFU_E_FILTER;
+    float h[16];
+    SOBFU_TRY(sobfu_hip_sobolev_filter(p->s, p->lambda, h));
+    for (int i = 0; i < 7; ++i) s->taps[i] = h[i];
+    s->p = *p;
+    return 0;
+}
+
+int ensure_events(sobfu_hip_solver* s, size_t n) {
+    while (s->events.size() < n) {
+        hipEvent_t e;
+        SOBFU_HIP_TRY(hipEventCreate(&e));
+        s->events.push_back(e);
+    }
+    return 0;
+}
+
+// The gradient-descent loop.  Returns the number of iterations executed in rep->iterations.
+int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int max_iter,
+             sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
+    const int X = s->X, Y = s->Y, Z = s->Z;
+    const sobfu_hip_solver_params& p = s->p;
+    sobfu_hip_solver_report r{};
+    r.last_max_update_norm = NAN;
+    r.last_max_update_index = NAN;
+    r.last_e_data = r.last_e_reg = NAN;
+
+    SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
+    if (max_iter <= 0) {
+        SOBFU_HIP_TRY(hipStreamSynchronize(st));
+        if (rep) *rep = r;
+        return 0;
+    }
+    SOBFU_TRY(ensure_slots(s, max_iter));
+    SOBFU_HIP_TRY(hipMemsetAsync(s->slots, 0, (size_t) (max_iter + 1) * kSlots * 4, st));
+    const bool verbose = p.verbosity > 0;
+    float* upd = nullptr;
+    if (verbose || s->keep_updates) {
+        SOBFU_TRY(ensure_updates(s));
+        upd = s->updates;
+    }
+    const bool can_converge = p.max_update_norm >= 0.f;  // ||u|| >= 0 > negative threshold: never fires
+    std::vector<uint32_t> hs;
+    int done = 0;  // iterations known to have executed
+    bool converged = false;
+
+    const bool prof = s->profiling && !verbose;
+    if (prof) SOBFU_TRY(ensure_events(s, (size_t) 3 * max_iter));
+    int launched = 0;
+    if (!verbose) {
+        int checked = 0;
+        for (int it = 1; it <= max_iter && !converged; ++it) {
+            const uint32_t* prev = (it > 1) ? s->slots + (size_t) (it - 1) * kSlots : nullptr;
+            uint32_t* cur        = s->slots + (size_t) it * kSlots;
+            if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1)], st));
+            SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st));
+            if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1) + 1], st));
+            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, prev,
+                                               p.max_update_norm, 0, st));
+            if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1) + 2], st));
+            launched = it;
+            if (can_converge && (it % kCheckEvery == 0 || it == max_iter)) {
+                const int n = it - checked;
+                hs.resize((size_t) n * kSlots);
+                SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + (size_t) (checked + 1) * kSlots, hs.size() * 4,
+                                             hipMemcpyDeviceToHost, st));
+                SOBFU_HIP_TRY(hipStreamSynchronize(st));
+                for (int k = 0; k < n; ++k) {
+                    float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
+                    if (per_iter) per_iter[checked + k] = v;
+                    r.last_max_update_norm = v;
+                    done = checked + k + 1;
+                    if (v <= p.max_update_norm) {  // solver.cu:183 -- later launches were device-side no-ops
+                        converged = true;
+                        break;
+                    }
+                }
+                checked = it;
+            }
+        }
+        if (!can_converge) {
+            hs.resize((size_t) max_iter * kSlots);
+            SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + kSlots, hs.size() * 4, hipMemcpyDeviceToHost, st));
+            SOBFU_HIP_TRY(hipStreamSynchronize(st));
+            for (int k = 0; k < max_iter; ++k) {
+                float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
+                if (per_iter) per_iter[k] = v;
+                r.last_max_update_norm = v;
+            }
+            done = max_iter;
+        }
+        if (prof) {
+            SOBFU_HIP_TRY(hipStreamSynchronize(st));
+            for (int it = 1; it <= (done < launched ? done : launched); ++it) {
+                float a = 0, b = 0;
+                SOBFU_HIP_TRY(hipEventElapsedTime(&a, s->events[3 * (it - 1)], s->events[3 * (it - 1) + 1]));
+                SOBFU_HIP_TRY(hipEventElapsedTime(&b, s->events[3 * (it - 1) + 1], s->events[3 * (it - 1) + 2]));
+                s->ms_a += a;
+                s->ms_b += b;
+                s->prof_launches += 1;
+            }
+        }
+        // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
+        for (int it = 1; it <= done; ++it)
+            if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
+    } else {
+        // verbose: same kernels, plus the reference's energy / arg-max reductions and a host sync per iteration
+        for (int it = 1; it <= max_iter; ++it) {
+            if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
+            const bool report = (p.verbosity == 1 && (it == 1 || it % 50 == 0 || it == max_iter)) || p.verbosity == 2;
+            if (report) {  // solver.cu:132-142 (J of the displacement is rebuilt in registers, not stored)
+                SOBFU_TRY(sobfu_hip_data_energy(pg, pnp, (int) s->N, s->red_scratch, &r.last_e_data, st));
+                SOBFU_TRY(sobfu_hip_reg_energy_sobolev_from_psi(psi, X, Y, Z, s->red_scratch, &r.last_e_reg, st));
+                float e = r.last_e_data + p.w_reg * r.last_e_reg;
+                s->log("data energy + w_reg * reg energy = " + fmt_g(r.last_e_data) + " + " + fmt_g(p.w_reg) + " * " +
+                       fmt_g(r.last_e_reg) + " = " + fmt_g(e));
+            }
+            uint32_t* cur = s->slots + (size_t) it * kSlots;
+            SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st));
+            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st));
+            float mx[2];
+            SOBFU_TRY(sobfu_hip_max_update_norm(upd, (int) s->N, s->red_scratch, mx, st));  // solver.cu:172
+            r.last_max_update_norm  = mx[0];
+            r.last_max_update_index = mx[1];
+            if (per_iter) per_iter[it - 1] = mx[0];
+            done = it;
+            if (report) {  // solver.cu:175-180 (index arithmetic reproduced as written)
+                int ix = (int) (mx[1] / (float) (X * Y));
+                int iy = (int) ((mx[1] - (float) (ix * X * Y)) / (float) X);
+                int iz = (int) (mx[1] - (float) (X * (iy + Y * ix)));
+                s->log("max. update norm " + fmt_g(mx[0]) + " at voxel (" + std::to_string(iz) + ", " + std::to_string(iy) +
+                       ", " + std::to_string(ix) + ")");
+            }
+            if (mx[0] <= p.max_update_norm) {
+                converged = true;
+                break;
+            }
+        }
+    }
+    if (converged) s->log("SOLVER CONVERGED AFTER " + std::to_string(done) + " ITERATIONS");
+    else if (done == max_iter) s->log("SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING");
+    r.iterations = done;
+    r.converged  = converged ? 1 : 0;
+    if (rep) *rep = r;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sobfu_hip_abi_version(void) { return SOBFU_HIP_ABI_VERSION; }
+
+const char* sobfu_hip_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case SOBFU_E_BADARG: return "sobfu_hip: bad argument";
+        case SOBFU_E_FILTER: return "sobfu_hip: (s, lambda) not in the Sobolev filter table";
+        case SOBFU_E_UNSUPPORTED: return "sobfu_hip: unsupported configuration";
+        default: return code > 0 ? hipGetErrorString((hipError_t) code) : "sobfu_hip: unknown error";
+    }
+}
+
+// decompose_sobolev_filter -- src/sobfu/solver.cpp:160-262
+int sobfu_hip_sobolev_filter(int s, float lambda, float* h) {
+    SOBFU_CHECK_ARGS(h);
+    bool ok = false;
+    if (s == 3 && lambda == 0.1f) { h[0] = 0.06537f; h[1] = 0.99572f; h[2] = h[0]; ok = true; }
+    if (s == 7) {
+        if (lambda == 0.05f) { h[0] = 0.00006f; h[1] = 0.00015f; h[2] = 0.03917f; h[3] = 0.99846f; ok = true; }
+        if (lambda == 0.1f) { h[0] = 0.00030f; h[1] = 0.00441f; h[2] = 0.06571f; h[3] = 0.99565f; ok = true; }
+        if (lambda == 0.2f) { h[0] = 0.00120f; h[1] = 0.01094f; h[2] = 0.10204f; h[3] = 0.98941f; ok = true; }
+        if (lambda == 0.4f) { h[0] = 0.00169f; h[1] = 0.01312f; h[2] = 0.10927f; h[3] = 0.98781f; ok = true; }
+        if (ok) { h[4] = h[2]; h[5] = h[1]; h[6] = h[0]; }
+    }
+    if (s == 9) {
+        if (lambda == 0.05f) { h[0] = 0.000003f; h[1] = 0.00006f; h[2] = 0.00155f; h[3] = 0.03917f; h[4] = 0.99846f; ok = true; }
+        if (lambda == 0.1f) { h[0] = 0.00002f; h[1] = 0.00030f; h[2] = 0.00441f; h[3] = 0.06571f; h[4] = 0.99565f; ok = true; }
+        if (ok) { h[5] = h[3]; h[6] = h[2]; h[7] = h[1]; h[8] = h[0]; }
+    }
+    if (s == 11 && lambda == 0.1f) {
+        h[0] = 0.0000015f; h[1] = 0.00002f; h[2] = 0.00030f; h[3] = 0.00441f; h[4] = 0.06571f; h[5] = 0.99565f;
+        h[6] = h[4]; h[7] = h[3]; h[8] = h[2]; h[9] = h[1]; h[10] = h[0];
+        ok = true;
+    }
+    if (!ok) return SOBFU_E_FILTER;  // the reference would run on an uninitialised filter
+    volatile float sum = 0.f;
+    for (int i = 0; i < s; ++i) sum = sum + h[i];
+    for (int i = 0; i < s; ++i) h[i] = h[i] / sum;
+    return 0;
+}
+
+int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const sobfu_hip_solver_params* params) {
+    SOBFU_CHECK_ARGS(out && params && X > 1 && Y > 1 && Z > 1);
+    if ((size_t) X * Y * Z > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;  // int32 linear indices, like the reference
+    auto* s = new sobfu_hip_solver();
+    s->X = X; s->Y = Y; s->Z = Z;
+    s->N = (size_t) X * Y * Z;
+    int rc = set_params(s, params);
+    if (rc == 0) rc = (int) hipMalloc((void**) &s->nabla_U, s->N * 16);
+    if (rc == 0) rc = (int) hipMalloc(&s->red_scratch, 65536 * 8);
+    if (rc == 0) {
+        s->bytes = s->N * 16 + 65536 * 8;
+        rc = ensure_slots(s, params->max_iter > 0 ? params->max_iter : 1);
+    }
+    if (rc != 0) {
+        sobfu_hip_solver_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return 0;
+}
+
+int sobfu_hip_solver_destroy(sobfu_hip_solver* s) {
+    if (!s) return 0;
+    if (s->nabla_U) (void) hipFree(s->nabla_U);
+    if (s->updates) (void) hipFree(s->updates);
+    if (s->slots) (void) hipFree(s->slots);
+    if (s->red_scratch) (void) hipFree(s->red_scratch);
+    for (hipEvent_t e : s->events) (void) hipEventDestroy(e);
+    delete s;
+    return 0;
+}
+
+int sobfu_hip_solver_set_params(sobfu_hip_solver* s, const sobfu_hip_solver_params* params) {
+    SOBFU_CHECK_ARGS(s);
+    return set_params(s, params);
+}
+
+size_t sobfu_hip_solver_workspace_bytes(const sobfu_hip_solver* s) { return s ? s->bytes : 0; }
+
+float* sobfu_hip_solver_updates(sobfu_hip_solver* s) {
+    if (!s) return nullptr;
+    if (ensure_updates(s) != 0) return nullptr;
+    return s->updates;
+}
+
+int sobfu_hip_solver_keep_updates(sobfu_hip_solver* s, int keep) {
+    SOBFU_CHECK_ARGS(s);
+    s->keep_updates = keep != 0;
+    return 0;
+}
+
+int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* user) {
+    SOBFU_CHECK_ARGS(s);
+    s->log_fn   = fn;
+    s->log_user = user;
+    s->log_set  = true;
+    return 0;
+}
+
+int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int enable) {
+    SOBFU_CHECK_ARGS(s);
+    s->profiling = enable != 0;
+    return 0;
+}
+
+int sobfu_hip_solver_get_profile(sobfu_hip_solver* s, float* ms_pass_a, float* ms_pass_b, int* launches, int reset) {
+    SOBFU_CHECK_ARGS(s);
+    if (ms_pass_a) *ms_pass_a = (float) s->ms_a;
+    if (ms_pass_b) *ms_pass_b = (float) s->ms_b;
+    if (launches) *launches = s->prof_launches;
+    if (reset) {
+        s->ms_a = s->ms_b = 0;
+        s->prof_launches = 0;
+    }
+    return 0;
+}
+
+int sobfu_hip_solver_iterate(sobfu_hip_solver* s, const float* d_phi_global, const float* d_phi_n, float* d_phi_n_psi,
+                             float* d_psi, int n_iters, sobfu_hip_solver_report* report, float* per_iter_max_norm,
+                             void* stream) {
+    SOBFU_CHECK_ARGS(s && d_phi_global && d_phi_n && d_phi_n_psi && d_psi && n_iters >= 0);
+    SOBFU_TRY(run_loop(s, d_phi_global, d_phi_n, d_phi_n_psi, d_psi, n_iters, report, per_iter_max_norm, (hipStream_t) stream));
+    return (int) hipStreamSynchronize((hipStream_t) stream);
+}
+
+int sobfu_hip_solver_estimate_psi(sobfu_hip_solver* s, const float* d_phi_global, float* d_phi_global_psi_inv,
+                                  const float* d_phi_n, float* d_phi_n_psi, float* d_psi, float* d_psi_inv,
+                                  sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream) {
+    SOBFU_CHECK_ARGS(s && d_phi_global && d_phi_global_psi_inv && d_phi_n && d_phi_n_psi && d_psi && d_psi_inv);
+    hipStream_t st = (hipStream_t) stream;
+    SOBFU_TRY(run_loop(s, d_phi_global, d_phi_n, d_phi_n_psi, d_psi, s->p.max_iter, report, per_iter_max_norm, st));
+    SOBFU_TRY(sobfu_hip_init_identity(d_psi_inv, s->X, s->Y, s->Z, st));                               // solver.cu:196
+    SOBFU_TRY(sobfu_hip_estimate_inverse(d_psi, d_psi_inv, s->X, s->Y, s->Z, 48, st));                 // solver.cu:197
+    SOBFU_TRY(sobfu_hip_apply(d_phi_global, d_phi_global_psi_inv, d_psi_inv, s->X, s->Y, s->Z, st));   // solver.cu:199
+    return (int) hipStreamSynchronize(st);
+}
+
+}  // extern "C"

@@ -1,0 +1,527 @@
+// Solver kernels for gfx950.
+//
+// Part 1 -- launcher-for-launcher counterparts of include/sobfu/solver.hpp:109-136 (potential gradient, the
+//           three 1-D Sobolev convolutions, psi update), one lane per voxel, 3-D grids.
+// Part 2 -- the MI355X-native two-pass decomposition of one solver iteration (solver.cu:114-193):
+//             pass A  fused_potential_gradient : grad(phi_n o psi) + (-Lap psi) + combine      -> nabla_U
+//             pass B  fused_smooth_update_apply: (Sx+Sy+Sz) nabla_U, psi -= alpha*.., phi_n o psi, max||u||^2
+//           Both march along z with a register pipeline for the z taps and stage each xy plane (plus a
+//           radius-1 / radius-3 halo) in a double-buffered LDS tile for the x/y taps: every plane is read from
+//           HBM once per tile (+ halo), 112 B/voxel/iteration algorithmic traffic instead of the reference's
+//           456 B/voxel.
+//
+// Arithmetic is op-for-op the reference's (see sobfu_device.hpp): results are bit-identical to Part 1.
+#include "sobfu_device.hpp"
+#include "sobfu_hip.h"
+#include "sobfu_host.hpp"
+
+using namespace sobfu_hip;
+
+namespace {
+
+struct Taps {
+    float s[7];
+};
+
+// ============================================================================================================
+// Part 1: reference-shaped launchers
+// ============================================================================================================
+
+// calculate_potential_gradient_kernel -- solver.cu:15-33
+__global__ void __launch_bounds__(256) potential_gradient_kernel(const float2* __restrict__ pnp, const float2* __restrict__ pg,
+                                                                 const float4* __restrict__ grad, const float4* __restrict__ L,
+                                                                 float4* __restrict__ nU, float w_reg, size_t N) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float d = pnp[i].x - pg[i].x;
+    nU[i]   = add4(mul4(grad[i], d), mul4(L[i], w_reg));
+}
+
+// convolution_{rows,columns,depth}_kernel -- solver.cu:237-446: sum = 0; for j=-3..3: sum += S[3-j]*src(clamp(i+j))
+template <int AXIS>
+__global__ void __launch_bounds__(256) conv1d_kernel(float4* __restrict__ dst, const float4* __restrict__ src, Taps S, Dims d) {
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z;
+    if (x >= d.x || y >= d.y) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int j = -3; j <= 3; ++j) {
+        int xx = x, yy = y, zz = z;
+        if (AXIS == 0) xx = min(max(x + j, 0), d.x - 1);
+        if (AXIS == 1) yy = min(max(y + j, 0), d.y - 1);
+        if (AXIS == 2) zz = min(max(z + j, 0), d.z - 1);
+        float4 v = src[vidx(d, xx, yy, zz)];
+        float s  = S.s[3 - j];
+        sx += v.x * s;
+        sy += v.y * s;
+        sz += v.z * s;
+    }
+    float4* o = dst + vidx(d, x, y, z);
+    if (AXIS == 0) {
+        *o = f4(sx, sy, sz);  // rows assign (solver.cu:290)
+    } else {                  // columns / depth accumulate, w untouched (solver.cu:366,443; utils.hpp:253-258)
+        float4 c = *o;
+        c.x += sx;
+        c.y += sy;
+        c.z += sz;
+        *o = c;
+    }
+}
+
+// update_psi_kernel -- solver.cu:53-69
+__global__ void __launch_bounds__(256) update_psi_kernel(float4* __restrict__ psi, const float4* __restrict__ nUS,
+                                                         float4* __restrict__ updates, float alpha, size_t N) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 u   = mul4(nUS[i], alpha);
+    updates[i] = u;
+    float4 p   = psi[i];
+    p.x -= u.x;
+    p.y -= u.y;
+    p.z -= u.z;
+    psi[i] = p;
+}
+
+// ============================================================================================================
+// Part 2: fused two-pass iteration
+// ============================================================================================================
+
+constexpr int TX = 64;  // tile width = one wave of consecutive x
+
+// --- convergence gate ----------------------------------------------------------------------------------------
+// Pass B folds max ||u||^2 of iteration k into 256 uint32 slots (non-negative floats order like their bit
+// patterns).  A kernel of iteration k+1 receives the slots of iteration k and returns immediately when
+// sqrt_rd(max) <= max_update_norm -- the reference's `break` (solver.cu:183) without a host round trip.
+SOBFU_DEV bool solver_converged(const uint32_t* __restrict__ prev_slots, float max_update_norm) {
+    if (prev_slots == nullptr) return false;
+    __shared__ int s_flag;
+    const int tid = threadIdx.x + blockDim.x * threadIdx.y;
+    if (tid < 64) {
+        uint32_t m = max(max(prev_slots[tid], prev_slots[tid + 64]), max(prev_slots[tid + 128], prev_slots[tid + 192]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
+        if (tid == 0) s_flag = sqrt_rd(__uint_as_float(m)) <= max_update_norm ? 1 : 0;
+    }
+    __syncthreads();
+    return s_flag != 0;
+}
+
+// --- pass A ----------------------------------------------------------------------------------------------------
+struct PassAArgs {
+    const float2* pnp;  // phi_n o psi
+    const float2* pg;   // phi_global
+    const float4* psi;
+    float4* nU;
+    Dims d;
+    float w_reg;
+    int zc;  // slices per workgroup
+    const uint32_t* prev_slots;
+    float max_update_norm;
+};
+
+template <int RPT, int WY>
+__global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
+    constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
+    constexpr int NXH = (2 * TY + 63) / 64;  // wave-tasks for the two x-halo columns
+    constexpr int NTASK = 2 + NXH, TPW = (NTASK + WY - 1) / WY;
+    __shared__ float4 t_psi[2][LH][LW + 2];  // {psi.xyz, F = (phi_n o psi).tsdf} -- psi.w is never read
+
+    if (solver_converged(a.prev_slots, a.max_update_norm)) return;
+
+    const Dims d = a.d;
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, zb = blockIdx.z * a.zc, ze = min(zb + a.zc, d.z);
+    const int x = x0 + lx, xc = min(x, d.x - 1);
+    const size_t plane = (size_t) d.x * d.y;
+
+    int yr[RPT];  // clamped global rows of this lane's strip
+    size_t off[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        yr[r]  = min(y0 + wy * RPT + r, d.y - 1);
+        off[r] = (size_t) xc + (size_t) d.x * yr[r];
+    }
+    // halo tasks: task 0 = row above the tile, task 1 = row below, tasks 2.. = x-halo cells (col -1 / col TX)
+    int h_lr[TPW], h_lc[TPW];  // LDS cell
+    size_t h_off[TPW];
+    bool h_on[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        int task = wy + k * WY;
+        h_on[k]  = task < NTASK;
+        int lr = 0, lc = 0;
+        if (task == 0) { lr = 0; lc = lx + 1; }
+        else if (task == 1) { lr = LH - 1; lc = lx + 1; }
+        else {
+            int e = (task - 2) * 64 + lx;  // 0 .. 2*TY-1
+            h_on[k] = h_on[k] && e < 2 * TY;
+            lr = 1 + (e >> 1);
+            lc = (e & 1) ? LW - 1 : 0;
+        }
+        h_lr[k] = lr;
+        h_lc[k] = lc;
+        int gx = min(max(x0 - 1 + lc, 0), d.x - 1), gy = min(max(y0 - 1 + lr, 0), d.y - 1);
+        h_off[k] = (size_t) gx + (size_t) d.x * gy;
+    }
+
+    // z register pipeline: m = z-1, c = z, n = z+1 (clamped loads; boundary rules applied at use)
+    float4 pm[RPT], pc[RPT], pn[RPT];
+    float fm[RPT], fc[RPT], fn[RPT];
+    float4 hp[TPW];
+    float hf[TPW];
+    {
+        const size_t zm = (size_t) max(zb - 1, 0) * plane, zc0 = (size_t) zb * plane;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            pm[r] = a.psi[zm + off[r]];
+            fm[r] = a.pnp[zm + off[r]].x;
+            pc[r] = a.psi[zc0 + off[r]];
+            fc[r] = a.pnp[zc0 + off[r]].x;
+        }
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+            if (h_on[k]) {
+                hp[k] = a.psi[zc0 + h_off[k]];
+                hf[k] = a.pnp[zc0 + h_off[k]].x;
+            }
+    }
+
+    for (int z = zb; z < ze; ++z) {
+        const int buf = (z - zb) & 1;
+        // stage plane z
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            t_psi[buf][wy * RPT + r + 1][lx + 1] = make_float4(pc[r].x, pc[r].y, pc[r].z, fc[r]);
+        }
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+            if (h_on[k]) t_psi[buf][h_lr[k]][h_lc[k]] = make_float4(hp[k].x, hp[k].y, hp[k].z, hf[k]);
+        // prefetch plane z+1 (main) and the halo of plane z+1
+        const size_t zn = (size_t) min(z + 1, d.z - 1) * plane, zcur = (size_t) z * plane;
+        float2 bg[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            pn[r] = a.psi[zn + off[r]];
+            fn[r] = a.pnp[zn + off[r]].x;
+            bg[r] = a.pg[zcur + off[r]];
+        }
+        if (z + 1 < ze) {
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (h_on[k]) {
+                    hp[k] = a.psi[zn + h_off[k]];
+                    hf[k] = a.pnp[zn + h_off[k]].x;
+                }
+        }
+        __syncthreads();
+
+        const bool zlo = (z == 0), zhi = (z == d.z - 1);
+        const bool xlo = (x == 0), xhi = (x == d.x - 1);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int y = y0 + wy * RPT + r;
+            const int lr = wy * RPT + r + 1;
+            const bool ylo = (y == 0), yhi = (y == d.y - 1);
+            // raw neighbours
+            float4 pxp = t_psi[buf][lr][lx + 2], pxm = t_psi[buf][lr][lx];
+            float fxp = pxp.w, fxm = pxm.w;
+            float4 pyp, pym;
+            float fyp, fym;
+            if (r + 1 < RPT) { pyp = pc[r + 1 < RPT ? r + 1 : r]; fyp = fc[r + 1 < RPT ? r + 1 : r]; }
+            else { pyp = t_psi[buf][lr + 1][lx + 1]; fyp = pyp.w; }
+            if (r > 0) { pym = pc[r > 0 ? r - 1 : r]; fym = fc[r > 0 ? r - 1 : r]; }
+            else { pym = t_psi[buf][lr - 1][lx + 1]; fym = pym.w; }
+            float4 pzp = pn[r], pzm = pm[r];
+            float fzp = fn[r], fzm = fm[r];
+            const float4 c = pc[r];
+            // TsdfDifferentiator boundary rule (vector_fields.cu:165-191): mirror the missing neighbour
+            float gx1 = xhi ? fxm : fxp, gx2 = xlo ? fxp : fxm;
+            float gy1 = yhi ? fym : fyp, gy2 = ylo ? fyp : fym;
+            float gz1 = zhi ? fzm : fzp, gz2 = zlo ? fzp : fzm;
+            float4 g = f4((gx1 - gx2) / 2.f, (gy1 - gy2) / 2.f, (gz1 - gz2) / 2.f);
+            // SecondOrderDifferentiator boundary rule (vector_fields.cu:299-331): both neighbours <- centre
+            if (xlo || xhi) { pxp = c; pxm = c; }
+            if (ylo || yhi) { pyp = c; pym = c; }
+            if (zlo || zhi) { pzp = c; pzm = c; }
+            float4 v = mul4(c, -6.f);
+            v = add4(v, pxp);
+            v = add4(v, pxm);
+            v = add4(v, pyp);
+            v = add4(v, pym);
+            v = add4(v, pzp);
+            v = add4(v, pzm);
+            float4 L = mul4(v, -1.f);
+            // calculate_potential_gradient_kernel (solver.cu:28-31)
+            float diff = fc[r] - bg[r].x;
+            float4 o   = add4(mul4(g, diff), mul4(L, a.w_reg));
+            if (x < d.x && y < d.y) a.nU[zcur + (size_t) x + (size_t) d.x * y] = o;
+        }
+        // shift the z pipeline
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            pm[r] = pc[r];
+            pc[r] = pn[r];
+            fm[r] = fc[r];
+            fc[r] = fn[r];
+        }
+    }
+}
+
+// --- pass B ----------------------------------------------------------------------------------------------------
+struct PassBArgs {
+    const float4* nU;
+    float4* psi;
+    const float2* phi_n;
+    float2* pnp;      // phi_n o psi (output)
+    float4* updates;  // may be null
+    uint32_t* slots;  // 256 x uint32, atomic max of ||u||^2 bit patterns
+    Dims d;
+    Taps S;
+    float alpha;
+    int zc;
+    const uint32_t* prev_slots;
+    float max_update_norm;
+};
+
+template <int RPT, int WY, bool WRITE_UPDATES>
+__global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassBArgs a) {
+    constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
+    constexpr int NXH = (2 * R * TY + 63) / 64;  // wave-tasks for the 2R x-halo columns
+    constexpr int NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
+    __shared__ float4 tile[2][LH][LW + 2];
+    __shared__ uint32_t s_max[WY];
+
+    if (solver_converged(a.prev_slots, a.max_update_norm)) return;
+
+    const Dims d = a.d;
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, zb = blockIdx.z * a.zc, ze = min(zb + a.zc, d.z);
+    const int x = x0 + lx, xc = min(x, d.x - 1);
+    const size_t plane = (size_t) d.x * d.y;
+
+    size_t off[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) off[r] = (size_t) xc + (size_t) d.x * min(y0 + wy * RPT + r, d.y - 1);
+
+    // halo tasks: 0..R-1 rows above, R..2R-1 rows below, then x-halo cells (2R per tile row)
+    int h_lr[TPW], h_lc[TPW];
+    size_t h_off[TPW];
+    bool h_on[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        int task = wy + k * WY;
+        h_on[k]  = task < NTASK;
+        int lr = 0, lc = 0;
+        if (task < R) { lr = task; lc = lx + R; }
+        else if (task < 2 * R) { lr = TY + task; lc = lx + R; }  // TY + R + (task - R)
+        else {
+            int e = (task - 2 * R) * 64 + lx;  // 0 .. 2R*TY-1
+            h_on[k] = h_on[k] && e < 2 * R * TY;
+            int row = e / (2 * R), c = e % (2 * R);
+            lr = R + row;
+            lc = c < R ? c : TX + c;  // R..2R-1 -> TX+R .. TX+2R-1
+        }
+        h_lr[k] = lr;
+        h_lc[k] = lc;
+        int gx = min(max(x0 - R + lc, 0), d.x - 1), gy = min(max(y0 - R + lr, 0), d.y - 1);
+        h_off[k] = (size_t) gx + (size_t) d.x * gy;
+    }
+
+    // z register pipeline q[r][0..6] = planes clamp(z-3 .. z+3)  (clamp-to-edge, solver.cu:396-424)
+    float4 q[RPT][7];
+    float4 hq[TPW];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const size_t zo = (size_t) min(max(zb - 3 + k, 0), d.z - 1) * plane;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) q[r][k] = a.nU[zo + off[r]];
+    }
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+        if (h_on[k]) hq[k] = a.nU[(size_t) zb * plane + h_off[k]];
+
+    float msq = 0.f;
+    for (int z = zb; z < ze; ++z) {
+        const int buf = (z - zb) & 1;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) tile[buf][wy * RPT + r + R][lx + R] = q[r][3];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+            if (h_on[k]) tile[buf][h_lr[k]][h_lc[k]] = hq[k];
+
+        const size_t zcur = (size_t) z * plane;
+        float4 pv[RPT], nq[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) pv[r] = a.psi[zcur + off[r]];
+        if (z + 1 < ze) {
+            const size_t z4 = (size_t) min(z + 4, d.z - 1) * plane, z1 = (size_t) (z + 1) * plane;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) nq[r] = a.nU[z4 + off[r]];
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (h_on[k]) hq[k] = a.nU[z1 + h_off[k]];
+        }
+        __syncthreads();
+
+        // y taps outside this lane's strip
+        float4 yt[R], yb[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            yt[j] = tile[buf][wy * RPT + j][lx + R];                 // strip rows -3, -2, -1
+            yb[j] = tile[buf][wy * RPT + RPT + R + j][lx + R];       // strip rows RPT, RPT+1, RPT+2
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int y = y0 + wy * RPT + r;
+            float sxx = 0.f, sxy = 0.f, sxz = 0.f, syx = 0.f, syy = 0.f, syz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
+#pragma unroll
+            for (int j = -R; j <= R; ++j) {
+                const float s = a.S.s[R - j];
+                float4 vx = (j == 0) ? q[r][3] : tile[buf][wy * RPT + r + R][lx + R + j];
+                sxx += vx.x * s;
+                sxy += vx.y * s;
+                sxz += vx.z * s;
+                const int rr = r + j;
+                float4 vy = rr < 0 ? yt[rr + R < 0 ? 0 : (rr + R > R - 1 ? R - 1 : rr + R)]
+                                   : (rr >= RPT ? yb[rr - RPT > R - 1 ? R - 1 : (rr - RPT < 0 ? 0 : rr - RPT)]
+                                                : q[rr < 0 ? 0 : (rr >= RPT ? RPT - 1 : rr)][3]);
+                syx += vy.x * s;
+                syy += vy.y * s;
+                syz += vy.z * s;
+                float4 vz = q[r][3 + j];
+                szx += vz.x * s;
+                szy += vz.y * s;
+                szz += vz.z * s;
+            }
+            // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)
+            float tx = (sxx + syx) + szx, ty = (sxy + syy) + szy, tz = (sxz + syz) + szz;
+            // update_psi_kernel (solver.cu:64-67)
+            float4 u = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
+            float4 p = pv[r];
+            p.x -= u.x;
+            p.y -= u.y;
+            p.z -= u.z;
+            if (x < d.x && y < d.y) {
+                msq = fmaxf(msq, norm_sq4(u));
+                const size_t i = zcur + (size_t) x + (size_t) d.x * y;
+                a.psi[i] = p;
+                if (WRITE_UPDATES) a.updates[i] = u;
+                a.pnp[i] = interp_tsdf(a.phi_n, d, p.x, p.y, p.z);  // apply_kernel (vector_fields.cu:95-98)
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) q[r][k] = q[r][k + 1];
+            q[r][6] = nq[r];
+        }
+    }
+
+    // max ||u||^2 over the voxels this workgroup owns
+    uint32_t m = __float_as_uint(msq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
+    if (lx == 0) s_max[wy] = m;
+    __syncthreads();
+    if (lx == 0 && wy == 0) {
+#pragma unroll
+        for (int w = 1; w < WY; ++w) m = max(m, s_max[w]);
+        const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        atomicMax(a.slots + (b & 255u), m);
+    }
+}
+
+}  // namespace
+
+// Tile configuration of the fused passes (see DESIGN.md "Kernel tuning").
+#ifndef SOBFU_RPT
+#define SOBFU_RPT 4
+#endif
+#ifndef SOBFU_WY
+#define SOBFU_WY 4
+#endif
+
+namespace sobfu_hip {
+
+int pick_zc(int X, int Y, int Z, int ty) {
+    // enough workgroups to fill 256 CUs a few times over, but long z marches (less pipeline refill)
+    const long tiles = (long) ((X + TX - 1) / TX) * ((Y + ty - 1) / ty);
+    int zc = Z;
+    while (zc > 8 && tiles * ((Z + zc - 1) / zc) < 512) zc = (zc + 1) / 2;
+    return zc;
+}
+
+int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream) {
+    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    if (zc <= 0) zc = pick_zc(X, Y, Z, TY);
+    PassAArgs a{(const float2*) pnp, (const float2*) pg, (const float4*) psi, (float4*) nU, {X, Y, Z}, w_reg, zc, prev_slots, max_update_norm};
+    dim3 grid((X + TX - 1) / TX, (Y + TY - 1) / TY, (Z + zc - 1) / zc);
+    hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
+                  const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
+                  float max_update_norm, int zc, hipStream_t stream) {
+    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    if (zc <= 0) zc = pick_zc(X, Y, Z, TY);
+    PassBArgs a{(const float4*) nU, (float4*) psi, (const float2*) phi_n, (float2*) pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, prev_slots, max_update_norm};
+    for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
+    dim3 grid((X + TX - 1) / TX, (Y + TY - 1) / TY, (Z + zc - 1) / zc);
+    if (updates)
+        hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
+    else
+        hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+}  // namespace sobfu_hip
+
+extern "C" {
+
+int sobfu_hip_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_grad, const float* d_L,
+                                 float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_grad && d_L && d_nabla_U && X > 0 && Y > 0 && Z > 0);
+    size_t N = (size_t) X * Y * Z;
+    hipLaunchKernelGGL(potential_gradient_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       (const float2*) d_phi_n_psi, (const float2*) d_phi_global, (const float4*) d_grad, (const float4*) d_L,
+                       (float4*) d_nabla_U, w_reg, N);
+    return (int) hipGetLastError();
+}
+
+#define CONV_IMPL(name, AXIS)                                                                                       \
+    int name(float* d_dst, const float* d_src, const float taps[7], int w, int h, int d, void* stream) {            \
+        SOBFU_CHECK_ARGS(d_dst && d_src && taps && w > 0 && h > 0 && d > 0 && d_dst != d_src);                       \
+        Taps S;                                                                                                     \
+        for (int i = 0; i < 7; ++i) S.s[i] = taps[i];                                                               \
+        hipLaunchKernelGGL(conv1d_kernel<AXIS>, voxel_grid(w, h, d), voxel_block(), 0, (hipStream_t) stream,         \
+                           (float4*) d_dst, (const float4*) d_src, S, Dims{w, h, d});                               \
+        return (int) hipGetLastError();                                                                             \
+    }
+CONV_IMPL(sobfu_hip_convolution_rows, 0)
+CONV_IMPL(sobfu_hip_convolution_columns, 1)
+CONV_IMPL(sobfu_hip_convolution_depth, 2)
+
+int sobfu_hip_update_psi(float* d_psi, const float* d_nabla_U_S, float* d_updates, float alpha, int X, int Y, int Z, void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && d_nabla_U_S && d_updates && X > 0 && Y > 0 && Z > 0);
+    size_t N = (size_t) X * Y * Z;
+    hipLaunchKernelGGL(update_psi_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       (float4*) d_psi, (const float4*) d_nabla_U_S, (float4*) d_updates, alpha, N);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_fused_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
+                                       float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Z > 1);
+    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Z, nullptr, 0.f, 0, (hipStream_t) stream);
+}
+
+int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
+                                        float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha,
+                                        int X, int Y, int Z, void* stream) {
+    SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Z > 0);
+    return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Z,
+                                    nullptr, 0.f, 0, (hipStream_t) stream);
+}
+
+}  // extern "C"

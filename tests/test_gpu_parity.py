@@ -1,0 +1,419 @@
+"""GPU parity tests: HIP kernels (through the C ABI) vs the CPU oracle on identical inputs.
+
+Bar: bit-exact for every per-iteration kernel and for the whole psi recurrence (all arithmetic is rn ops /
+explicit fma); stated tolerances only where the reference itself uses approximate
+device math (powf in init_sphere, __expf in the bilateral filter).
+"""
+import numpy as np
+import pytest
+
+from sobfu_amd.synthetic import hash_field, render_sphere_depth
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+SIZES = [(64, 64, 64), (40, 24, 20), (17, 9, 5), (70, 33, 19)]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device; the product path has no CPU fallback")
+    from sobfu_amd import ops as _ops
+
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def same(a, b):
+    """bitwise equality (NaN-safe, distinguishes -0/+0)"""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def nmis(a, b):
+    return int((np.ascontiguousarray(a).view(np.uint32) != np.ascontiguousarray(b).view(np.uint32)).sum())
+
+
+def rand_field(dims, seed, scale=1.0):
+    X, Y, Z = dims
+    f = hash_field((Z, Y, X, 4), seed, scale)
+    f[..., 3] = 0
+    return f
+
+
+def rand_volume(dims, seed):
+    X, Y, Z = dims
+    v = hash_field((Z, Y, X, 2), seed, 1.0)
+    v[..., 1] = (hash_field((Z, Y, X), seed + 7) > 0).astype(np.float32)
+    return v
+
+
+def warped_identity(oracle, dims, seed, amp):
+    X, Y, Z = dims
+    psi = oracle.new_field(dims)
+    oracle.init_identity(psi)
+    psi[..., :3] += hash_field((Z, Y, X, 3), seed, amp)
+    return psi
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-kernel parity
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", SIZES)
+def test_identity_gradient_laplacian_jacobian(ops, oracle, dims):
+    X, Y, Z = dims
+    psi_d = ops.new_field(dims)
+    ops.init_identity(psi_d)
+    ident = oracle.new_field(dims)
+    oracle.init_identity(ident)
+    assert same(host(psi_d), ident)
+
+    vol = rand_volume(dims, 3)
+    g_o = oracle.new_field(dims)
+    oracle.tsdf_gradient(vol, g_o)
+    g_d = ops.new_field(dims)
+    ops.tsdf_gradient(dev(vol), g_d)
+    assert same(host(g_d), g_o)
+
+    psi = warped_identity(oracle, dims, 5, 0.7)
+    L_o = oracle.new_field(dims)
+    oracle.laplacian(psi, L_o)
+    L_d = ops.new_field(dims)
+    ops.laplacian(dev(psi), L_d)
+    assert same(host(L_d), L_o)
+
+    for mode in (0, 1):
+        J_o = np.zeros((Z, Y, X, 4, 4), np.float32)
+        oracle.jacobian(psi, J_o, mode)
+        J_d = ops.new_jacobian(dims)
+        ops.jacobian(dev(psi), J_d, mode)
+        assert same(host(J_d), J_o)
+        assert ops.reg_energy_sobolev(J_d) == oracle.reg_energy_sobolev(J_o)
+        if mode == 1:
+            assert ops.reg_energy_sobolev_from_psi(dev(psi)) == oracle.reg_energy_sobolev(J_o)
+
+
+@pytest.mark.parametrize("dims", SIZES)
+def test_potential_gradient_conv_update(ops, oracle, dims):
+    a, b = rand_volume(dims, 11), rand_volume(dims, 12)
+    grad, L = rand_field(dims, 13), rand_field(dims, 14, 3.0)
+    nU_o = oracle.new_field(dims)
+    oracle.potential_gradient(a, b, grad, L, nU_o, 0.6)
+    nU_d = ops.new_field(dims)
+    ops.potential_gradient(dev(a), dev(b), dev(grad), dev(L), nU_d, 0.6)
+    assert same(host(nU_d), nU_o)
+
+    S = oracle.sobolev_filter(7, 0.1)
+    assert same(ops.sobolev_filter(7, 0.1), S)
+    dst_o = oracle.new_field(dims)
+    dst_d = ops.new_field(dims)
+    for name in ("convolution_rows", "convolution_columns", "convolution_depth"):
+        getattr(oracle, name)(dst_o, nU_o, S)
+        getattr(ops, name)(dst_d, nU_d, S)
+        assert same(host(dst_d), dst_o), name
+
+    psi = warped_identity(oracle, dims, 15, 0.3)
+    upd_o = oracle.new_field(dims)
+    psi_d, upd_d = dev(psi), ops.new_field(dims)
+    oracle.update_psi(psi, dst_o, upd_o, 0.001)
+    ops.update_psi(psi_d, dst_d, upd_d, 0.001)
+    assert same(host(psi_d), psi) and same(host(upd_d), upd_o)
+    mo, md = oracle.max_update_norm(upd_o), ops.max_update_norm(upd_d)
+    assert mo == md
+
+
+@pytest.mark.parametrize("dims", SIZES)
+def test_apply_inverse_fuse_energy(ops, oracle, dims):
+    X, Y, Z = dims
+    phi = rand_volume(dims, 21)
+    # displacements large enough to cross voxels and to leave the volume (exercises the clamps), plus exact
+    # lattice hits at 0 and dim-1 (the `hi = g` rule, utils.hpp:61-72)
+    psi = warped_identity(oracle, dims, 22, 2.5)
+    psi[0, 0, :, :3] = 0.0
+    psi[-1, -1, :, 0] = X - 1
+    psi[-1, -1, :, 1] = Y - 1
+    psi[-1, -1, :, 2] = Z - 1
+    out_o = oracle.new_volume(dims)
+    oracle.apply(phi, out_o, psi)
+    out_d = ops.new_volume(dims)
+    ops.apply(dev(phi), out_d, dev(psi))
+    assert same(host(out_d), out_o)
+
+    inv_o = oracle.new_field(dims)
+    oracle.init_identity(inv_o)
+    oracle.estimate_inverse(psi, inv_o, 5)
+    inv_d = ops.new_field(dims)
+    ops.init_identity(inv_d)
+    ops.estimate_inverse(dev(psi), inv_d, 5)
+    assert same(host(inv_d), inv_o)
+
+    g = rand_volume(dims, 23)
+    g[..., 1] = np.floor(np.abs(hash_field((Z, Y, X), 24, 6.0)))
+    n = rand_volume(dims, 25)
+    n[::2, ::3, ::2, 0] = -1.0  # exercise the skip rule (tsdf_volume.cu:118)
+    n[1::2, ::3, ::2, 0] = 0.0
+    g_d = dev(g)
+    oracle.integrate_fuse(g, n, 4.0)
+    ops.integrate_fuse(g_d, dev(n), 4.0)
+    assert same(host(g_d), g)
+
+    assert ops.data_energy(dev(phi), dev(n)) == oracle.data_energy(phi, n)
+    assert ops.reduce_config(X * Y * Z) == oracle.reduce_config(X * Y * Z)
+
+
+def test_tsdf_builders(ops, oracle):
+    dims = (64, 64, 64)
+    size = np.float32(0.25)
+    vs = np.array([size / np.float32(64)] * 3, np.float32)
+    trunc, eta = np.float32(10) * vs[0], np.float32(2) * vs[0]
+    # init_sphere: the reference calls powf(d, 2) (tsdf_volume.cu:262); HIP squares with a correctly rounded
+    # multiply, the oracle calls libm powf -> values agree to a few ulp, weights (sdf > -eta) may flip only on ties
+    o = oracle.new_volume(dims)
+    oracle.init_sphere(o, vs, trunc, eta, (0.13, 0.13, 0.13), 0.012)
+    d = ops.new_volume(dims)
+    ops.init_sphere(d, vs, trunc, eta, (0.13, 0.13, 0.13), 0.012)
+    hd = host(d)
+    assert np.max(np.abs(hd[..., 0] - o[..., 0])) <= 4e-6
+    assert int((hd[..., 1] != o[..., 1]).sum()) <= 2
+    # the other primitives use only IEEE ops + fma: bit-exact
+    for name, arg in (("init_box", (0.03, 0.02, 0.04)), ("init_ellipsoid", (0.05, 0.03, 0.04)), ("init_plane", 0.11),
+                      ("init_torus", (0.05, 0.02))):
+        o = oracle.new_volume(dims)
+        getattr(oracle, name)(o, vs, trunc, arg)
+        d = ops.new_volume(dims)
+        getattr(ops, name)(d, vs, trunc, arg)
+        assert same(host(d), o), name
+    ops.clear_volume(d)
+    assert not host(d).any()
+
+
+def test_depth_pipeline(ops, oracle):
+    """config-1 inputs: depth -> bilateral -> truncate -> dists -> integrate, GPU vs oracle."""
+    intr = (570.342, 570.342, 320.0, 240.0)
+    depth = render_sphere_depth((0.005, 0.0, 0.75), 0.1, intr)
+    dd = dev(depth.view(np.int16))
+    # bilateral: the reference uses __expf; oracle = libm expf, HIP = ocml expf -> allow rare +-1 mm flips
+    b_o = oracle.bilateral(depth, 7, 4.5, 0.005)
+    b_d = host(ops.bilateral_filter(dd, 7, 4.5, 0.005)).view(np.uint16)
+    diff = np.abs(b_d.astype(np.int32) - b_o.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    # from here on feed both sides the oracle's filtered image: everything is bit-exact
+    t_o = b_o.copy()
+    oracle.truncate_depth(t_o, 0.8)
+    t_d = dev(b_o.view(np.int16))
+    ops.truncate_depth(t_d, 0.8)
+    assert np.array_equal(host(t_d).view(np.uint16), t_o)
+    assert (t_o == 0).sum() > (b_o == 0).sum()
+    oracle.truncate_depth(b_o, 1.5)
+    dist_o = oracle.compute_dists(b_o, intr)
+    dist_d = ops.compute_dists(dev(b_o.view(np.int16)), intr)
+    assert same(host(dist_d), dist_o)
+    dims = (64, 64, 64)
+    size = np.float32(0.5)
+    vs = np.array([size / np.float32(64)] * 3, np.float32)
+    trunc, eta = np.float32(5) * vs[0], np.float32(2) * vs[0]
+    R = np.eye(3, dtype=np.float32)
+    t = np.array([-size / np.float32(2), -size / np.float32(2), 0.5], np.float32)
+    v_o = oracle.new_volume(dims)
+    oracle.integrate_depth(dist_o, v_o, vs, trunc, eta, R, t, intr)
+    v_d = ops.new_volume(dims)
+    ops.integrate_depth(dist_d, v_d, vs, trunc, eta, R, t, intr)
+    assert same(host(v_d), v_o)
+    assert int(((v_o[..., 0] != 0) | (v_o[..., 1] != 0)).sum()) == 34812
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused passes == launcher sequence == oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", SIZES + [(130, 37, 41)])
+def test_fused_passes(ops, oracle, dims):
+    pnp, pg, pn = rand_volume(dims, 31), rand_volume(dims, 32), rand_volume(dims, 33)
+    psi = warped_identity(oracle, dims, 34, 1.5)
+    S = oracle.sobolev_filter(7, 0.1)
+    w_reg, alpha = 0.6, 0.1
+    # oracle: the reference's launcher sequence
+    grad, L, nU, nUS, upd = (oracle.new_field(dims) for _ in range(5))
+    oracle.tsdf_gradient(pnp, grad)
+    oracle.laplacian(psi, L)
+    oracle.potential_gradient(pnp, pg, grad, L, nU, w_reg)
+    nU_d = ops.new_field(dims)
+    ops.fused_potential_gradient(dev(pnp), dev(pg), dev(psi), nU_d, w_reg)
+    assert nmis(host(nU_d), nU) == 0
+
+    oracle.convolution_rows(nUS, nU, S)
+    oracle.convolution_columns(nUS, nU, S)
+    oracle.convolution_depth(nUS, nU, S)
+    psi_o = psi.copy()
+    oracle.update_psi(psi_o, nUS, upd, alpha)
+    out_o = oracle.new_volume(dims)
+    oracle.apply(pn, out_o, psi_o)
+    mo = oracle.max_update_norm(upd)[0]
+
+    psi_d, out_d, upd_d = dev(psi), ops.new_volume(dims), ops.new_field(dims)
+    md = ops.fused_smooth_update_apply(nU_d, psi_d, dev(pn), out_d, S, alpha, updates=upd_d)
+    assert nmis(host(psi_d), psi_o) == 0
+    assert nmis(host(upd_d), upd) == 0
+    assert nmis(host(out_d), out_o) == 0
+    assert md == mo
+    # without the updates store
+    psi_d2, out_d2 = dev(psi), ops.new_volume(dims)
+    md2 = ops.fused_smooth_update_apply(nU_d, psi_d2, dev(pn), out_d2, S, alpha)
+    assert same(host(psi_d2), psi_o) and same(host(out_d2), out_o) and md2 == mo
+
+
+# ---------------------------------------------------------------------------------------------------
+# the solver
+# ---------------------------------------------------------------------------------------------------
+def _run1_inputs(oracle):
+    dims = (64, 64, 64)
+    size = np.float32(0.25)
+    vs = np.array([size / np.float32(64)] * 3, np.float32)
+    trunc, eta = np.float32(10) * vs[0], np.float32(2) * vs[0]
+    pg, pn = oracle.new_volume(dims), oracle.new_volume(dims)
+    oracle.init_sphere(pg, vs, trunc, eta, (0.13, 0.13, 0.13), 0.012)
+    oracle.init_sphere(pn, vs, trunc, eta, (0.125, 0.13, 0.13), 0.012)
+    return dims, pg, pn
+
+
+@pytest.mark.parametrize("verbosity", [0, 2])
+def test_solver_estimate_psi_matches_oracle(ops, oracle, verbosity):
+    """test/solver_test.cpp:109-132 set-up (SURVEY Appendix B run 1), 10 iterations, full estimate_psi."""
+    dims, pg, pn = _run1_inputs(oracle)
+    psi = oracle.new_field(dims)
+    oracle.init_identity(psi)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=10, alpha=0.01, w_reg=0.4, verbosity=2)
+
+    sv = ops.Solver(dims, max_iter=10, alpha=0.01, w_reg=0.4, verbosity=verbosity)
+    psi_d, psi_inv_d = ops.new_field(dims), ops.new_field(dims)
+    ops.init_identity(psi_d)
+    pnp_d, pgi_d = ops.new_volume(dims), ops.new_volume(dims)
+    rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+    assert rep.iterations == 10 and rep.converged == 0
+    assert same(host(psi_d), psi)
+    assert same(host(pnp_d), r["phi_n_psi"])
+    assert same(host(psi_inv_d), r["psi_inv"])
+    assert same(host(pgi_d), r["phi_global_psi_inv"])
+    assert same(hist, r["trace"][:, 2])
+    # warp-field L2 error vs the reference restatement (north-star bar: < 1e-5) -- here exactly 0
+    assert float(np.sqrt(((host(psi_d) - psi).astype(np.float64) ** 2).sum())) == 0.0
+    if verbosity == 2:
+        assert rep.last_e_data == r["trace"][-1, 0] and rep.last_e_reg == r["trace"][-1, 1]
+        assert rep.last_max_update_index == r["trace"][-1, 3]
+        assert same(host(sv.updates()), r["updates"])
+        assert any(l.startswith("data energy + w_reg * reg energy = 24.5457 + 0.4 * 0 = 24.5457") for l in sv.log_lines)
+        assert any(l.startswith("max. update norm 0.000383393 at voxel") for l in sv.log_lines)
+    assert sv.log_lines[0] == "iter. no. 1"
+    assert sv.log_lines[-1] == "SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING"
+    sv.close()
+
+
+def test_solver_convergence_break(ops, oracle):
+    """max_update_norm > 0: the device-side gate must stop at exactly the reference's iteration."""
+    dims, pg, pn = _run1_inputs(oracle)
+    psi = oracle.new_field(dims)
+    oracle.init_identity(psi)
+    thr = 0.00038255  # between the max norms of iterations 3 and 4... (trace decreases monotonically)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=70, alpha=0.01, w_reg=0.4, max_update_norm=thr, inverse_iters=48)
+    assert 1 < r["iters"] < 70
+    sv = ops.Solver(dims, max_iter=70, alpha=0.01, w_reg=0.4, max_update_norm=thr)
+    psi_d, psi_inv_d = ops.new_field(dims), ops.new_field(dims)
+    ops.init_identity(psi_d)
+    pnp_d, pgi_d = ops.new_volume(dims), ops.new_volume(dims)
+    rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+    assert rep.iterations == r["iters"] and rep.converged == 1
+    assert same(host(psi_d), psi) and same(host(pnp_d), r["phi_n_psi"]) and same(host(psi_inv_d), r["psi_inv"])
+    assert sv.log_lines[-1] == f"SOLVER CONVERGED AFTER {r['iters']} ITERATIONS"
+    sv.close()
+
+
+def test_solver_serial_frames_warm_start(ops, oracle):
+    """test/solver_test.cpp:162-208 SerialAlignmentTest shape: psi persists across two estimate_psi calls."""
+    dims = (64, 64, 64)
+    size = np.float32(0.25)
+    vs = np.array([size / np.float32(64)] * 3, np.float32)
+    trunc, eta = np.float32(10) * vs[0], np.float32(2) * vs[0]
+    pg = oracle.new_volume(dims)
+    oracle.init_sphere(pg, vs, trunc, eta, (0.13, 0.13, 0.13), 0.02)
+    psi = oracle.new_field(dims)
+    oracle.init_identity(psi)
+    sv = ops.Solver(dims, max_iter=6, alpha=0.005, w_reg=0.4)
+    psi_d, psi_inv_d = ops.new_field(dims), ops.new_field(dims)
+    ops.init_identity(psi_d)
+    pnp_d, pgi_d = ops.new_volume(dims), ops.new_volume(dims)
+    for c in ((0.125, 0.13, 0.132), (0.123, 0.13, 0.132)):
+        pn = oracle.new_volume(dims)
+        oracle.init_sphere(pn, vs, trunc, eta, c, 0.02)
+        r = oracle.estimate_psi(pg, pn, psi, max_iter=6, alpha=0.005, w_reg=0.4)
+        sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+        assert same(host(psi_d), psi) and same(host(pgi_d), r["phi_global_psi_inv"])
+    sv.close()
+
+
+def test_solver_rejects_bad_filter(ops):
+    from sobfu_amd._lib import HipError
+
+    with pytest.raises(HipError):
+        ops.Solver((16, 16, 16), max_iter=1, alpha=0.1, w_reg=0.2, lam=0.3)
+    with pytest.raises(HipError):
+        ops.Solver((16, 16, 16), max_iter=1, alpha=0.1, w_reg=0.2, s=3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size (256^3, BASELINE config 3) properties the oracle is too slow to check voxel by voxel
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_256_fused_equals_launchers_and_properties(ops, oracle):
+    dims = (256, 256, 256)
+    X, Y, Z = dims
+    g = torch.Generator(device="cuda").manual_seed(0)
+    pnp = torch.rand((Z, Y, X, 2), device="cuda", generator=g) * 2 - 1
+    pg = torch.rand((Z, Y, X, 2), device="cuda", generator=g) * 2 - 1
+    pn = torch.rand((Z, Y, X, 2), device="cuda", generator=g) * 2 - 1
+    psi = ops.new_field(dims)
+    ops.init_identity(psi)
+    psi[..., :3] += (torch.rand((Z, Y, X, 3), device="cuda", generator=g) - 0.5)
+    S = oracle.sobolev_filter(7, 0.1)
+    # launcher sequence (independent kernels) vs fused passes, bit for bit, on 16.7M voxels
+    grad, L, nU, nUS, upd = (ops.new_field(dims) for _ in range(5))
+    ops.tsdf_gradient(pnp, grad)
+    ops.laplacian(psi, L)
+    ops.potential_gradient(pnp, pg, grad, L, nU, 0.6)
+    nU_f = ops.new_field(dims)
+    ops.fused_potential_gradient(pnp, pg, psi, nU_f, 0.6)
+    assert torch.equal(nU.view(torch.int32), nU_f.view(torch.int32))
+    del grad, L
+    ops.convolution_rows(nUS, nU, S)
+    ops.convolution_columns(nUS, nU, S)
+    ops.convolution_depth(nUS, nU, S)
+    psi_l = psi.clone()
+    ops.update_psi(psi_l, nUS, upd, 0.001)
+    out_l = ops.new_volume(dims)
+    ops.apply(pn, out_l, psi_l)
+    m_l = ops.max_update_norm(upd)[0]
+    psi_f, out_f = psi.clone(), ops.new_volume(dims)
+    m_f = ops.fused_smooth_update_apply(nU_f, psi_f, pn, out_f, S, 0.001)
+    assert torch.equal(psi_l.view(torch.int32), psi_f.view(torch.int32))
+    assert torch.equal(out_l.view(torch.int32), out_f.view(torch.int32))
+    assert m_l == m_f
+    del nUS, upd, psi_l, out_l, psi_f, out_f, nU_f
+    # DC gain 3 of the sum of three unit-sum filters, clamp-to-edge => exact everywhere up to
+    # rounding of the tap sums; psi = identity warps phi onto itself exactly (lerp with t = 0)
+    nU[...] = 0
+    nU[..., 0] = 1.0
+    ident = ops.new_field(dims)
+    ops.init_identity(ident)
+    psi_c, out_c = ident.clone(), ops.new_volume(dims)
+    m = ops.fused_smooth_update_apply(nU, psi_c, pn, out_c, S, 0.5)
+    u = (ident - psi_c)[..., 0]
+    assert float((u - 1.5).abs().max()) < 1e-6 and float((ident - psi_c)[..., 1:].abs().max()) == 0.0
+    assert abs(m - 1.5) < 1e-6
+    out_i = ops.new_volume(dims)
+    ops.apply(pn, out_i, ident)
+    assert torch.equal(out_i.view(torch.int32), pn.view(torch.int32))
