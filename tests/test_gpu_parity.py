@@ -207,9 +207,9 @@ def test_depth_pipeline(ops, oracle):
     assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
     # from here on feed both sides the oracle's filtered image: everything is bit-exact
     t_o = b_o.copy()
-    oracle.truncate_depth(t_o, 0.8)
+    oracle.truncate_depth(t_o, 0.7)
     t_d = dev(b_o.view(np.int16))
-    ops.truncate_depth(t_d, 0.8)
+    ops.truncate_depth(t_d, 0.7)
     assert np.array_equal(host(t_d).view(np.uint16), t_o)
     assert (t_o == 0).sum() > (b_o == 0).sum()
     oracle.truncate_depth(b_o, 1.5)
