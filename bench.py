@@ -71,8 +71,8 @@ def cpu_baseline(P, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--dim", type=int, default=256, help="grid edge (256 = the BASELINE metric's grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

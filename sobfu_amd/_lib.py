@@ -8,7 +8,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libsobfu_hip.so")
+LIB_PATH = os.environ.get("SOBFU_HIP_LIB") or os.path.join(HERE, "libsobfu_hip.so")  # env override: kernel-tuning experiments
 HEADER = os.path.join(ROOT, "include", "sobfu_hip.h")
 
 
