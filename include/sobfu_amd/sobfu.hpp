@@ -1,0 +1,590 @@
+// sobfu_amd/sobfu.hpp -- C++ shells that rebuild the reference's host class surface for the solver hot path on
+// top of the C ABI (include/sobfu_hip.h).  Header-only, C++14, host code only (g++ or hipcc); links against
+// libsobfu_hip.so and libamdhip64.so.
+//
+// Mirrors, with the same names, argument meaning and error behaviour:
+//   Params                                   include/sobfu/params.hpp:7-37
+//   kfusion::Intr                            include/kfusion/types.hpp, src/kfusion/precomp.cpp:9-16
+//   kfusion::cuda::DeviceMemory (CudaData)   include/kfusion/cuda/device_memory.hpp:20-102
+//   kfusion::cuda::DeviceArray2D<T>          include/kfusion/cuda/device_array.hpp (subset: create/upload/download/ptr/step)
+//   kfusion::cuda::TsdfVolume                include/kfusion/cuda/tsdf_volume.hpp:17-92
+//   kfusion::cuda::{depthBilateralFilter, depthTruncation, computeDists, waitAllDefaultStream}
+//                                            include/kfusion/cuda/imgproc.hpp:11-28
+//   kfusion::device::{TsdfVolume POD, clear_volume, integrate x2, init_*}  include/kfusion/internal.hpp:59-78,189-198
+//   sobfu::device::{VectorField & typedefs, Jacobian, clear, init_identity, apply, estimate_inverse,
+//                   TsdfDifferentiator, SecondOrderDifferentiator, Differentiator, Reductor, launchers}
+//                                            include/sobfu/vector_fields.hpp:117-241, reductor.hpp:24-50, solver.hpp:109-136
+//   sobfu::cuda::{VectorField, DeformationField, Jacobian, Solver}
+//                                            include/sobfu/vector_fields.hpp:14-112, solver.hpp:52-101
+//
+// Errors: like the reference (src/kfusion/device_memory.cpp:7-10, include/kfusion/safe_call.hpp:12-22) any device
+// error prints "error: <msg>\t<file>:<line>" and calls exit(0).  Define SOBFU_AMD_THROW to get std::runtime_error.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "sobfu_hip.h"
+
+// ---- minimal stand-ins for the OpenCV types that leak into the reference's API ----------------------------------
+#ifndef SOBFU_AMD_HAVE_OPENCV
+namespace cv {
+template <class T, int N>
+struct Vec {
+    T val[N];
+    Vec() { for (int i = 0; i < N; ++i) val[i] = T(); }
+    Vec(T a, T b, T c) { static_assert(N == 3, "3-vector ctor"); val[0] = a; val[1] = b; val[2] = c; }
+    static Vec all(T v) { Vec r; for (int i = 0; i < N; ++i) r.val[i] = v; return r; }
+    T& operator[](int i) { return val[i]; }
+    const T& operator[](int i) const { return val[i]; }
+    template <class U> operator Vec<U, N>() const { Vec<U, N> r; for (int i = 0; i < N; ++i) r.val[i] = (U) val[i]; return r; }
+};
+typedef Vec<int, 3> Vec3i;
+typedef Vec<float, 3> Vec3f;
+// rigid transform x -> R x + t (only what the path uses: translate, inv, composition)
+struct Affine3f {
+    float R[9];
+    float t[3];
+    Affine3f() { std::memset(R, 0, sizeof R); R[0] = R[4] = R[8] = 1.f; t[0] = t[1] = t[2] = 0.f; }
+    static Affine3f Identity() { return Affine3f(); }
+    Affine3f translate(const Vec3f& d) const { Affine3f a = *this; for (int i = 0; i < 3; ++i) a.t[i] += d[i]; return a; }
+    Affine3f inv() const {  // rigid: R^T, -R^T t
+        Affine3f a;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a.R[3 * i + j] = R[3 * j + i];
+        for (int i = 0; i < 3; ++i) a.t[i] = -(a.R[3 * i] * t[0] + a.R[3 * i + 1] * t[1] + a.R[3 * i + 2] * t[2]);
+        return a;
+    }
+    Affine3f operator*(const Affine3f& b) const {  // this o b
+        Affine3f a;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            a.R[3 * i + j] = 0.f;
+            for (int k = 0; k < 3; ++k) a.R[3 * i + j] += R[3 * i + k] * b.R[3 * k + j];
+        }
+        for (int i = 0; i < 3; ++i) a.t[i] = R[3 * i] * b.t[0] + R[3 * i + 1] * b.t[1] + R[3 * i + 2] * b.t[2] + t[i];
+        return a;
+    }
+};
+template <class T>
+struct Ptr : std::shared_ptr<T> {
+    Ptr() {}
+    Ptr(T* p) : std::shared_ptr<T>(p) {}
+    Ptr(const std::shared_ptr<T>& p) : std::shared_ptr<T>(p) {}
+};
+}  // namespace cv
+#endif
+
+// Mat4f of the reference (include/kfusion/internal.hpp:12-14)
+struct Mat4f {
+    float4 data[4];
+};
+
+namespace kfusion {
+typedef cv::Vec3i Vec3i;
+typedef cv::Vec3f Vec3f;
+typedef cv::Affine3f Affine3f;
+
+struct Intr {
+    float fx, fy, cx, cy;
+    Intr() : fx(0), fy(0), cx(0), cy(0) {}
+    Intr(float fx_, float fy_, float cx_, float cy_) : fx(fx_), fy(fy_), cx(cx_), cy(cy_) {}
+    Intr operator()(int level) const { int d = 1 << level; return Intr(fx / d, fy / d, cx / d, cy / d); }
+};
+
+namespace cuda {
+// error(): print and exit(0), as src/kfusion/device_memory.cpp:7-10
+inline void error(const char* msg, const char* file, int line, const char* func = "") {
+#ifdef SOBFU_AMD_THROW
+    throw std::runtime_error(std::string(msg) + " at " + file + ":" + std::to_string(line) + " " + func);
+#else
+    std::printf("error: %s\t%s:%d\n", msg, file, line);
+    std::fflush(stdout);
+    std::exit(0);
+#endif
+}
+}  // namespace cuda
+}  // namespace kfusion
+
+#define sobfuSafeCall(expr)                                                                        \
+    do {                                                                                           \
+        int _rc = (int) (expr);                                                                    \
+        if (_rc != 0) ::kfusion::cuda::error(sobfu_hip_error_string(_rc), __FILE__, __LINE__, ""); \
+    } while (0)
+#define cudaSafeCall sobfuSafeCall  // the reference's spelling (include/kfusion/safe_call.hpp)
+
+// ---- Params (include/sobfu/params.hpp) ---------------------------------------------------------------------------
+struct Params {
+    int cols = 640, rows = 480;
+    cv::Vec3i volume_dims;
+    cv::Vec3f volume_size;
+    cv::Affine3f volume_pose;
+    kfusion::Intr intr;
+    float icp_truncate_depth_dist = 0.f;
+    float bilateral_sigma_depth = 0.f, bilateral_sigma_spatial = 0.f;
+    int bilateral_kernel_size = 0;
+    float tsdf_trunc_dist = 0.f, eta = 0.f;
+    float tsdf_max_weight = 0.f;
+    float gradient_delta_factor = 0.f;
+    int start_frame = 0;
+    int verbosity = 0;
+    int s = 7, max_iter = 0;
+    float max_update_norm = 0.f, lambda = 0.1f, alpha = 0.f, w_reg = 0.f;
+    cv::Vec3f voxel_sizes() const {
+        return cv::Vec3f(volume_size[0] / volume_dims[0], volume_size[1] / volume_dims[1], volume_size[2] / volume_dims[2]);
+    }
+};
+
+namespace kfusion {
+namespace cuda {
+
+inline void setDevice(int device) { sobfuSafeCall(hipSetDevice(device)); }
+inline void waitAllDefaultStream() { sobfuSafeCall(hipDeviceSynchronize()); }
+inline void printShortCudaDeviceInfo(int device) {
+    hipDeviceProp_t p;
+    sobfuSafeCall(hipGetDeviceProperties(&p, device));
+    std::printf("[%s] %d CUs, %.1f GB\n", p.name, p.multiProcessorCount, p.totalGlobalMem / 1e9);
+}
+
+// ---- DeviceMemory: ref-counted hipMalloc blob (include/kfusion/cuda/device_memory.hpp:20-102) -------------------
+class DeviceMemory {
+public:
+    DeviceMemory() : data_(nullptr), sizeBytes_(0), refcount_(nullptr) {}
+    explicit DeviceMemory(size_t n) : data_(nullptr), sizeBytes_(0), refcount_(nullptr) { create(n); }
+    DeviceMemory(void* p, size_t n) : data_(p), sizeBytes_(n), refcount_(nullptr) {}  // user buffer: no refcounting
+    DeviceMemory(const DeviceMemory& o) : data_(o.data_), sizeBytes_(o.sizeBytes_), refcount_(o.refcount_) { if (refcount_) ++*refcount_; }
+    DeviceMemory& operator=(const DeviceMemory& o) {
+        if (this != &o) {
+            if (o.refcount_) ++*o.refcount_;
+            release();
+            data_ = o.data_; sizeBytes_ = o.sizeBytes_; refcount_ = o.refcount_;
+        }
+        return *this;
+    }
+    ~DeviceMemory() { release(); }
+    void create(size_t n) {
+        if (n == sizeBytes_) return;
+        if (n > 0) {
+            if (data_) release();
+            sizeBytes_ = n;
+            sobfuSafeCall(hipMalloc(&data_, sizeBytes_));
+            refcount_ = new int(1);
+        }
+    }
+    void release() {
+        if (refcount_ && --*refcount_ == 0) {
+            delete refcount_;
+            sobfuSafeCall(hipFree(data_));
+        }
+        data_ = nullptr; sizeBytes_ = 0; refcount_ = nullptr;
+    }
+    void copyTo(DeviceMemory& other) const {
+        if (empty()) { other.release(); return; }
+        other.create(sizeBytes_);
+        sobfuSafeCall(hipMemcpy(other.data_, data_, sizeBytes_, hipMemcpyDeviceToDevice));
+    }
+    void upload(const void* host, size_t n) { create(n); sobfuSafeCall(hipMemcpy(data_, host, n, hipMemcpyHostToDevice)); }
+    void download(void* host) const { sobfuSafeCall(hipMemcpy(host, data_, sizeBytes_, hipMemcpyDeviceToHost)); }
+    void swap(DeviceMemory& o) { std::swap(data_, o.data_); std::swap(sizeBytes_, o.sizeBytes_); std::swap(refcount_, o.refcount_); }
+    template <class T> T* ptr() { return (T*) data_; }
+    template <class T> const T* ptr() const { return (const T*) data_; }
+    bool empty() const { return !data_; }
+    size_t sizeBytes() const { return sizeBytes_; }
+
+private:
+    void* data_;
+    size_t sizeBytes_;
+    int* refcount_;
+};
+typedef DeviceMemory CudaData;
+
+// ---- DeviceArray2D<T>: the subset the path uses (rows x cols image with a byte step) ----------------------------
+template <class T>
+class DeviceArray2D {
+public:
+    DeviceArray2D() : rows_(0), cols_(0), step_(0) {}
+    DeviceArray2D(int rows, int cols) : rows_(0), cols_(0), step_(0) { create(rows, cols); }
+    void create(int rows, int cols) {
+        if (rows == rows_ && cols == cols_) return;
+        rows_ = rows; cols_ = cols;
+        step_ = ((size_t) cols * sizeof(T) + 255) / 256 * 256;  // 256-B aligned rows (cudaMallocPitch-like)
+        mem_.create(step_ * rows);
+    }
+    void upload(const void* host, size_t host_step, int rows, int cols) {
+        create(rows, cols);
+        sobfuSafeCall(hipMemcpy2D(mem_.ptr<void>(), step_, host, host_step, (size_t) cols * sizeof(T), rows, hipMemcpyHostToDevice));
+    }
+    void download(void* host, size_t host_step) const {
+        sobfuSafeCall(hipMemcpy2D(host, host_step, mem_.ptr<void>(), step_, (size_t) cols_ * sizeof(T), rows_, hipMemcpyDeviceToHost));
+    }
+    T* ptr() { return mem_.ptr<T>(); }
+    const T* ptr() const { return mem_.ptr<T>(); }
+    int rows() const { return rows_; }
+    int cols() const { return cols_; }
+    size_t step() const { return step_; }
+    bool empty() const { return mem_.empty(); }
+
+private:
+    DeviceMemory mem_;
+    int rows_, cols_;
+    size_t step_;
+};
+typedef DeviceArray2D<unsigned short> Depth;
+typedef DeviceArray2D<float> Dists;
+
+// ---- image pre-steps (include/kfusion/cuda/imgproc.hpp:11-28, src/kfusion/imgproc.cpp:3-41) ---------------------
+inline void depthBilateralFilter(const Depth& in, Depth& out, int kernel_size, float sigma_spatial, float sigma_depth) {
+    out.create(in.rows(), in.cols());
+    sobfuSafeCall(sobfu_hip_bilateral_filter(in.ptr(), (int) in.step(), out.ptr(), (int) out.step(), in.rows(), in.cols(),
+                                             kernel_size, sigma_spatial, sigma_depth, nullptr));
+}
+inline void depthTruncation(Depth& depth, float threshold) {
+    sobfuSafeCall(sobfu_hip_truncate_depth(depth.ptr(), (int) depth.step(), depth.rows(), depth.cols(), threshold, nullptr));
+}
+inline void computeDists(const Depth& depth, Dists& dists, const Intr& intr) {
+    dists.create(depth.rows(), depth.cols());
+    sobfuSafeCall(sobfu_hip_compute_dists(depth.ptr(), (int) depth.step(), dists.ptr(), (int) dists.step(), depth.rows(),
+                                          depth.cols(), intr.fx, intr.fy, intr.cx, intr.cy, nullptr));
+}
+}  // namespace cuda
+
+// ---- device PODs + launchers (include/kfusion/internal.hpp:59-78,189-198) ----------------------------------------
+namespace device {
+typedef int3 Vec3i;
+typedef float3 Vec3f;
+struct Mat3f { float3 data[3]; };
+struct Aff3f { Mat3f R; Vec3f t; };
+struct Projector {
+    float2 f, c;
+    Projector() {}
+    Projector(float fx, float fy, float cx, float cy) { f.x = fx; f.y = fy; c.x = cx; c.y = cy; }
+};
+struct TsdfVolume {
+    float2* const data;
+    const int3 dims;
+    const float3 voxel_size;
+    const float trunc_dist, eta, max_weight;
+    TsdfVolume(float2* d, int3 dm, float3 vs, float trunc, float eta_, float maxw)
+        : data(d), dims(dm), voxel_size(vs), trunc_dist(trunc), eta(eta_), max_weight(maxw) {}
+};
+inline void clear_volume(TsdfVolume& v) { sobfuSafeCall(sobfu_hip_clear_volume((float*) v.data, v.dims.x, v.dims.y, v.dims.z, nullptr)); }
+inline void integrate(TsdfVolume& g, TsdfVolume& n) {
+    sobfuSafeCall(sobfu_hip_integrate_fuse((float*) g.data, (const float*) n.data, g.dims.x, g.dims.y, g.dims.z, g.max_weight, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());  // tsdf_volume.cu:172
+}
+inline void integrate(const cuda::Dists& dists, TsdfVolume& v, const Aff3f& a, const Projector& p) {
+    float R[9] = {a.R.data[0].x, a.R.data[0].y, a.R.data[0].z, a.R.data[1].x, a.R.data[1].y, a.R.data[1].z,
+                  a.R.data[2].x, a.R.data[2].y, a.R.data[2].z};
+    float t[3] = {a.t.x, a.t.y, a.t.z}, vs[3] = {v.voxel_size.x, v.voxel_size.y, v.voxel_size.z};
+    sobfuSafeCall(sobfu_hip_integrate_depth(dists.ptr(), (int) dists.step(), dists.rows(), dists.cols(), (float*) v.data, v.dims.x,
+                                            v.dims.y, v.dims.z, vs, v.trunc_dist, v.eta, R, t, p.f.x, p.f.y, p.c.x, p.c.y, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());  // tsdf_volume.cu:161
+}
+#define SOBFU_AMD_VS(v) float vs[3] = {(v).voxel_size.x, (v).voxel_size.y, (v).voxel_size.z}
+inline void init_sphere(TsdfVolume& v, const float3& c, const float& r) {
+    SOBFU_AMD_VS(v); float cc[3] = {c.x, c.y, c.z};
+    sobfuSafeCall(sobfu_hip_init_sphere((float*) v.data, v.dims.x, v.dims.y, v.dims.z, vs, v.trunc_dist, v.eta, cc, r, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());
+}
+inline void init_box(TsdfVolume& v, const float3& b) {
+    SOBFU_AMD_VS(v); float bb[3] = {b.x, b.y, b.z};
+    sobfuSafeCall(sobfu_hip_init_box((float*) v.data, v.dims.x, v.dims.y, v.dims.z, vs, v.trunc_dist, bb, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());
+}
+inline void init_ellipsoid(TsdfVolume& v, const float3& r) {
+    SOBFU_AMD_VS(v); float rr[3] = {r.x, r.y, r.z};
+    sobfuSafeCall(sobfu_hip_init_ellipsoid((float*) v.data, v.dims.x, v.dims.y, v.dims.z, vs, v.trunc_dist, rr, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());
+}
+inline void init_plane(TsdfVolume& v, const float& z) {
+    SOBFU_AMD_VS(v);
+    sobfuSafeCall(sobfu_hip_init_plane((float*) v.data, v.dims.x, v.dims.y, v.dims.z, vs, v.trunc_dist, z, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());
+}
+inline void init_torus(TsdfVolume& v, const float2& t) {
+    SOBFU_AMD_VS(v); float tt[2] = {t.x, t.y};
+    sobfuSafeCall(sobfu_hip_init_torus((float*) v.data, v.dims.x, v.dims.y, v.dims.z, vs, v.trunc_dist, tt, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());
+}
+#undef SOBFU_AMD_VS
+}  // namespace device
+
+template <class D, class S> inline D device_cast(const S& s);
+template <> inline int3 device_cast<int3, cv::Vec3i>(const cv::Vec3i& v) { int3 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; return r; }
+template <> inline float3 device_cast<float3, cv::Vec3f>(const cv::Vec3f& v) { float3 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; return r; }
+template <> inline device::Aff3f device_cast<device::Aff3f, cv::Affine3f>(const cv::Affine3f& a) {
+    device::Aff3f r;
+    for (int i = 0; i < 3; ++i) { r.R.data[i].x = a.R[3 * i]; r.R.data[i].y = a.R[3 * i + 1]; r.R.data[i].z = a.R[3 * i + 2]; }
+    r.t.x = a.t[0]; r.t.y = a.t[1]; r.t.z = a.t[2];
+    return r;
+}
+
+namespace cuda {
+// ---- TsdfVolume host owner (include/kfusion/cuda/tsdf_volume.hpp:17-92, src/kfusion/tsdf_volume.cpp:18-146) -----
+class TsdfVolume {
+public:
+    explicit TsdfVolume(const Params& p)
+        : trunc_dist_(p.tsdf_trunc_dist), eta_(p.eta), max_weight_(p.tsdf_max_weight), dims_(p.volume_dims), size_(p.volume_size),
+          pose_(p.volume_pose), gradient_delta_factor_(p.gradient_delta_factor), raycast_step_factor_(0.f) { create(dims_); }
+    virtual ~TsdfVolume() {}
+    void create(const Vec3i& dims) {
+        dims_ = dims;
+        data_.create((size_t) dims_[0] * dims_[1] * dims_[2] * 2 * sizeof(float));
+        clear();
+    }
+    Vec3i getDims() const { return dims_; }
+    Vec3f getVoxelSize() const { return Vec3f(size_[0] / dims_[0], size_[1] / dims_[1], size_[2] / dims_[2]); }
+    const CudaData data() const { return data_; }
+    CudaData data() { return data_; }
+    Vec3f getSize() const { return size_; }
+    void setSize(const Vec3f& s) { size_ = s; }
+    float getTruncDist() const { return trunc_dist_; }
+    void setTruncDist(float& d) { trunc_dist_ = d; }
+    float getEta() const { return eta_; }
+    void setEta(float& e) { eta_ = e; }
+    float getMaxWeight() const { return max_weight_; }
+    void setMaxWeight(float& w) { max_weight_ = w; }
+    Affine3f getPose() const { return pose_; }
+    void setPose(const Affine3f& p) { pose_ = p; }
+    float getGradientDeltaFactor() const { return gradient_delta_factor_; }
+    void setGradientDeltaFactor(float& f) { gradient_delta_factor_ = f; }
+    float getRaycastStepFactor() const { return raycast_step_factor_; }
+    void setRaycastStepFactor(float& f) { raycast_step_factor_ = f; }
+    virtual void clear() { device::TsdfVolume v = pod(); device::clear_volume(v); }
+    void swap(CudaData& d) { data_.swap(d); }
+    virtual void applyAffine(const Affine3f& a) { pose_ = a * pose_; }
+    virtual void integrate(const TsdfVolume& phi_n_psi) {
+        device::TsdfVolume g = pod();
+        device::TsdfVolume n((float2*) phi_n_psi.data_.ptr<float2>(), g.dims, g.voxel_size, trunc_dist_, eta_, max_weight_);
+        device::integrate(g, n);
+    }
+    virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr) {
+        Affine3f vol2cam = camera_pose.inv() * pose_;  // src/kfusion/tsdf_volume.cpp:96
+        device::TsdfVolume v = pod();
+        device::integrate(dists, v, device_cast<device::Aff3f>(vol2cam), device::Projector(intr.fx, intr.fy, intr.cx, intr.cy));
+    }
+    virtual void initBox(const float3& b) { device::TsdfVolume v = pod(); device::init_box(v, b); }
+    virtual void initEllipsoid(const float3& r) { device::TsdfVolume v = pod(); device::init_ellipsoid(v, r); }
+    virtual void initPlane(const float& z) { device::TsdfVolume v = pod(); device::init_plane(v, z); }
+    virtual void initSphere(const float3& c, const float& r) { device::TsdfVolume v = pod(); device::init_sphere(v, c, r); }
+    virtual void initTorus(const float2& t) { device::TsdfVolume v = pod(); device::init_torus(v, t); }
+    device::TsdfVolume pod() {
+        return device::TsdfVolume(data_.ptr<float2>(), device_cast<int3>(dims_), device_cast<float3>(getVoxelSize()), trunc_dist_, eta_, max_weight_);
+    }
+
+private:
+    CudaData data_;
+    float trunc_dist_, eta_, max_weight_;
+    Vec3i dims_;
+    Vec3f size_;
+    Affine3f pose_;
+    float gradient_delta_factor_, raycast_step_factor_;
+};
+}  // namespace cuda
+}  // namespace kfusion
+
+// ================================================================================================================
+// sobfu
+// ================================================================================================================
+namespace sobfu {
+namespace device {
+
+// VectorField POD + typedefs (include/sobfu/vector_fields.hpp:124-136,146,164,191,216)
+struct VectorField {
+    VectorField(float4* const d, const int3 dm) : data(d), dims(dm) {}
+    float4* const data;
+    const int3 dims;
+};
+typedef VectorField DeformationField;
+typedef VectorField TsdfGradient;
+typedef VectorField Laplacian;
+typedef VectorField PotentialGradient;
+struct Jacobian {
+    Jacobian(Mat4f* const d, int3 dm) : data(d), dims(dm) {}
+    Mat4f* const data;
+    const int3 dims;
+};
+
+inline void clear(VectorField& f) { sobfuSafeCall(sobfu_hip_clear_field((float*) f.data, f.dims.x, f.dims.y, f.dims.z, nullptr)); }
+inline void clear(Jacobian& J) {
+    sobfuSafeCall(sobfu_hip_clear_jacobian((float*) J.data, J.dims.x, J.dims.y, J.dims.z, nullptr));
+    sobfuSafeCall(hipDeviceSynchronize());
+}
+inline void init_identity(DeformationField& psi) { sobfuSafeCall(sobfu_hip_init_identity((float*) psi.data, psi.dims.x, psi.dims.y, psi.dims.z, nullptr)); }
+inline void apply(const kfusion::device::TsdfVolume& phi, kfusion::device::TsdfVolume& warped, const DeformationField& psi) {
+    sobfuSafeCall(sobfu_hip_apply((const float*) phi.data, (float*) warped.data, (const float*) psi.data, phi.dims.x, phi.dims.y, phi.dims.z, nullptr));
+}
+inline void estimate_inverse(DeformationField& psi, DeformationField& psi_inv) {
+    sobfuSafeCall(sobfu_hip_estimate_inverse((const float*) psi.data, (float*) psi_inv.data, psi.dims.x, psi.dims.y, psi.dims.z, 48, nullptr));
+}
+
+struct TsdfDifferentiator {
+    explicit TsdfDifferentiator(kfusion::device::TsdfVolume& v) : vol(v) {}
+    void calculate(TsdfGradient& g) {
+        sobfuSafeCall(sobfu_hip_tsdf_gradient((const float*) vol.data, (float*) g.data, g.dims.x, g.dims.y, g.dims.z, nullptr));
+    }
+    kfusion::device::TsdfVolume vol;
+};
+struct SecondOrderDifferentiator {
+    explicit SecondOrderDifferentiator(DeformationField& p) : psi(p) {}
+    void calculate(Laplacian& L) { sobfuSafeCall(sobfu_hip_laplacian((const float*) psi.data, (float*) L.data, L.dims.x, L.dims.y, L.dims.z, nullptr)); }
+    DeformationField psi;
+};
+struct Differentiator {
+    explicit Differentiator(DeformationField& p) : psi(p) {}
+    void calculate(Jacobian& J) { sobfuSafeCall(sobfu_hip_jacobian((const float*) psi.data, (float*) J.data, J.dims.x, J.dims.y, J.dims.z, 0, nullptr)); }
+    void calculate_deformation_jacobian(Jacobian& J) {
+        sobfuSafeCall(sobfu_hip_jacobian((const float*) psi.data, (float*) J.data, J.dims.x, J.dims.y, J.dims.z, 1, nullptr));
+    }
+    DeformationField psi;
+};
+
+// solver launchers (include/sobfu/solver.hpp:109-136).  The reference keeps the taps in a __constant__ symbol set by
+// set_convolution_kernel (solver.cu:229-234); the C ABI takes them by value, so the shell keeps the last-set taps.
+inline float* conv_taps() { static float taps[7] = {0, 0, 0, 1, 0, 0, 0}; return taps; }
+inline void set_convolution_kernel(float* d_kernel) {
+    sobfuSafeCall(hipMemcpy(conv_taps(), d_kernel, 7 * sizeof(float), hipMemcpyDeviceToHost));
+}
+inline void convolution_rows(float4* dst, float4* src, int w, int h, int d) { sobfuSafeCall(sobfu_hip_convolution_rows((float*) dst, (const float*) src, conv_taps(), w, h, d, nullptr)); }
+inline void convolution_columns(float4* dst, float4* src, int w, int h, int d) { sobfuSafeCall(sobfu_hip_convolution_columns((float*) dst, (const float*) src, conv_taps(), w, h, d, nullptr)); }
+inline void convolution_depth(float4* dst, float4* src, int w, int h, int d) { sobfuSafeCall(sobfu_hip_convolution_depth((float*) dst, (const float*) src, conv_taps(), w, h, d, nullptr)); }
+inline void calculate_potential_gradient(kfusion::device::TsdfVolume& pnp, kfusion::device::TsdfVolume& pg, TsdfGradient& g, Laplacian& L,
+                                         PotentialGradient& nU, float w_reg) {
+    sobfuSafeCall(sobfu_hip_potential_gradient((const float*) pnp.data, (const float*) pg.data, (const float*) g.data, (const float*) L.data,
+                                               (float*) nU.data, w_reg, pnp.dims.x, pnp.dims.y, pnp.dims.z, nullptr));
+}
+inline void update_psi(DeformationField& psi, PotentialGradient& nUS, float4* updates, float alpha) {
+    sobfuSafeCall(sobfu_hip_update_psi((float*) psi.data, (const float*) nUS.data, (float*) updates, alpha, psi.dims.x, psi.dims.y, psi.dims.z, nullptr));
+}
+
+// Reductor (include/sobfu/reductor.hpp:24-50, src/sobfu/reductor.cpp)
+struct Reductor {
+    Reductor(int3 dims_, float vsz_, float trunc_dist_) : dims(dims_), vsz(vsz_), trunc_dist(trunc_dist_) {
+        no_voxels = dims.x * dims.y * dims.z;
+        sobfuSafeCall(sobfu_hip_reduce_config(no_voxels, &blocks, &threads));
+        sobfuSafeCall(hipMalloc(&scratch, (size_t) blocks * 8));
+        sobfuSafeCall(hipMalloc((void**) &updates, (size_t) no_voxels * sizeof(float4)));
+    }
+    ~Reductor() { (void) hipFree(scratch); (void) hipFree(updates); }
+    Reductor(const Reductor&) = delete;
+    Reductor& operator=(const Reductor&) = delete;
+    float data_energy(float2* phi_global, float2* phi_n) {
+        float e;
+        sobfuSafeCall(sobfu_hip_data_energy((const float*) phi_global, (const float*) phi_n, no_voxels, scratch, &e, nullptr));
+        return e;
+    }
+    float reg_energy_sobolev(Mat4f* J) {
+        float e;
+        sobfuSafeCall(sobfu_hip_reg_energy_sobolev((const float*) J, no_voxels, scratch, &e, nullptr));
+        return e;
+    }
+    float2 max_update_norm() {
+        float o[2];
+        sobfuSafeCall(sobfu_hip_max_update_norm((const float*) updates, no_voxels, scratch, o, nullptr));
+        float2 r; r.x = o[0]; r.y = o[1];
+        return r;
+    }
+    int3 dims;
+    float vsz, trunc_dist;
+    int no_voxels, blocks, threads;
+    float4* updates;
+    void* scratch;
+};
+}  // namespace device
+
+namespace cuda {
+// host owners (include/sobfu/vector_fields.hpp:20-112, src/sobfu/vector_fields.cpp)
+class VectorField {
+public:
+    explicit VectorField(cv::Vec3i d) : dims(d) {
+        data.create((size_t) dims[0] * dims[1] * dims[2] * sizeof(float4));
+        clear();
+    }
+    virtual ~VectorField() {}
+    cv::Vec3i get_dims() const { return dims; }
+    kfusion::cuda::CudaData get_data() { return data; }
+    const kfusion::cuda::CudaData get_data() const { return data; }
+    void clear() { device::VectorField f(data.ptr<float4>(), kfusion::device_cast<int3>(dims)); device::clear(f); }
+    int get_no_nans() {  // debug helper of the reference (src/sobfu/vector_fields.cpp:56-79)
+        size_t n = (size_t) dims[0] * dims[1] * dims[2];
+        std::unique_ptr<float4[]> h(new float4[n]);
+        data.download(h.get());
+        int c = 0;
+        for (size_t i = 0; i < n; ++i) c += (h[i].x != h[i].x || h[i].y != h[i].y || h[i].z != h[i].z);
+        return c;
+    }
+
+protected:
+    kfusion::cuda::CudaData data;
+    cv::Vec3i dims;
+};
+typedef VectorField TsdfGradient;
+typedef VectorField Laplacian;
+typedef VectorField PotentialGradient;
+
+class DeformationField : public VectorField {
+public:
+    explicit DeformationField(cv::Vec3i d) : VectorField(d) { clear(); }
+    void clear() { device::DeformationField p(data.ptr<float4>(), kfusion::device_cast<int3>(dims)); device::init_identity(p); }
+    void apply(const cv::Ptr<kfusion::cuda::TsdfVolume> phi, cv::Ptr<kfusion::cuda::TsdfVolume> phi_psi) {
+        kfusion::device::TsdfVolume a = phi->pod(), b = phi_psi->pod();
+        device::DeformationField p(data.ptr<float4>(), a.dims);
+        device::apply(a, b, p);
+        kfusion::cuda::waitAllDefaultStream();  // src/sobfu/vector_fields.cpp:122
+    }
+    void get_inverse(DeformationField& psi_inv) {
+        int3 d = kfusion::device_cast<int3>(dims);
+        device::DeformationField a(data.ptr<float4>(), d), b(psi_inv.data.ptr<float4>(), d);
+        device::estimate_inverse(a, b);
+    }
+};
+
+class Jacobian {
+public:
+    explicit Jacobian(cv::Vec3i d) : dims(d) {
+        data.create((size_t) dims[0] * dims[1] * dims[2] * sizeof(Mat4f));
+        clear();
+    }
+    kfusion::cuda::CudaData get_data() { return data; }
+    void clear() { device::Jacobian J(data.ptr<Mat4f>(), kfusion::device_cast<int3>(dims)); device::clear(J); }
+
+private:
+    kfusion::cuda::CudaData data;
+    cv::Vec3i dims;
+};
+
+// Solver (include/sobfu/solver.hpp:52-101, src/sobfu/solver.cpp:7-101): the workspace + hot loop live behind the
+// opaque C handle; estimate_psi has the reference's signature and side effects (mutates psi, psi_inv, phi_n_psi,
+// phi_global_psi_inv) and prints the reference's progress lines to stdout.
+class Solver {
+public:
+    explicit Solver(Params& p) : h_(nullptr) {
+        sobfu_hip_solver_params sp;
+        sp.verbosity = p.verbosity; sp.max_iter = p.max_iter; sp.s = p.s; sp.max_update_norm = p.max_update_norm;
+        sp.lambda = p.lambda; sp.alpha = p.alpha; sp.w_reg = p.w_reg;
+        sobfuSafeCall(sobfu_hip_solver_create(&h_, p.volume_dims[0], p.volume_dims[1], p.volume_dims[2], &sp));
+    }
+    ~Solver() { sobfu_hip_solver_destroy(h_); }  // (the reference's defaulted dtor leaks everything, solver.cpp:67)
+    Solver(const Solver&) = delete;
+    Solver& operator=(const Solver&) = delete;
+    void estimate_psi(const cv::Ptr<kfusion::cuda::TsdfVolume> phi_global, cv::Ptr<kfusion::cuda::TsdfVolume> phi_global_psi_inv,
+                      const cv::Ptr<kfusion::cuda::TsdfVolume> phi_n, cv::Ptr<kfusion::cuda::TsdfVolume> phi_n_psi,
+                      std::shared_ptr<DeformationField> psi, std::shared_ptr<DeformationField> psi_inv) {
+        sobfuSafeCall(sobfu_hip_solver_estimate_psi(h_, phi_global->data().ptr<float>(), phi_global_psi_inv->data().ptr<float>(),
+                                                    phi_n->data().ptr<float>(), phi_n_psi->data().ptr<float>(),
+                                                    psi->get_data().ptr<float>(), psi_inv->get_data().ptr<float>(), &last_report,
+                                                    nullptr, nullptr));
+    }
+    sobfu_hip_solver* handle() { return h_; }
+    sobfu_hip_solver_report last_report{};
+
+private:
+    sobfu_hip_solver* h_;
+};
+}  // namespace cuda
+}  // namespace sobfu

@@ -1,0 +1,34 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_round.sh r01   -- bench line + rocprofv3 kernel stats + PMC passes -> gpurun_out/<tag>/
+R="$(cd "$(dirname "$0")/.." && pwd)"; tag=${1:-r01}; O=$R/gpurun_out/$tag; mkdir -p $O
+cd $R
+python bench.py 2>$O/bench.err > $O/bench.json
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+python $R/tools/rocprof_summary.py $O/kt/r_results.db > $O/rocprof_kernel_stats.md
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace -d $O/pmc$i -o r -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline >/dev/null 2>&1
+done
+python - <<PY
+import sqlite3, glob, json
+rows = {}
+for db in sorted(glob.glob("$O/pmc*/r_results.db")):
+    c = sqlite3.connect(db)
+    for name, cn, avg, n in c.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events where name like '%fused_%' group by name, counter_name"):
+        k = "pass_a" if "potential" in name else "pass_b"
+        rows.setdefault(k, {})[cn] = avg
+out = {"note": "rocprofv3 --pmc, one counter set per run, averages per launch at 256^3; FETCH_SIZE/WRITE_SIZE in KiB. "
+               "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of wide streaming reads -> "
+               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "counters": rows}
+for k in rows:
+    if "FETCH_SIZE" in rows[k] and "WRITE_SIZE" in rows[k]:
+        out[k + "_hbm_bytes_per_launch"] = (2 * rows[k]["FETCH_SIZE"] + rows[k]["WRITE_SIZE"]) * 1024
+json.dump(out, open("$O/pmc.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}))
+PY
+rm -rf $O/kt $O/pmc[0-9]   # keep the summaries, drop the raw databases
+head -c 600 $O/bench.json; echo; cat $O/rocprof_kernel_stats.md | head -6
