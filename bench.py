@@ -95,7 +95,12 @@ def main():
     from sobfu_amd import ops
 
     P = boxing_params(args.dim)
-    if world > 1:
+    force_tiled = os.environ.get("SOBFU_FORCE_TILED") == "1"  # exercise the slab path on one GPU (debugging)
+    if world > 1 or force_tiled:
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         from sobfu_amd import tiled
 
         res = tiled.bench_tiled(P, args.steps, args.warmup, rank, world)
@@ -126,7 +131,7 @@ def main():
                    workspace=sv.workspace_bytes(), parallelism="single")
         sv.close()
 
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([res["seconds"]], dtype=torch.float64, device="cuda")
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,10 +169,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P)
-        print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:  # after the process group is gone, so the JSON is the LAST line on stdout (RCCL prints a banner there)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

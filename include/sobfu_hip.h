@@ -152,6 +152,26 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
                                         float* d_phi_n_psi, float* d_updates, uint32_t* d_max_sq_slots,
                                         const float taps[7], float alpha, int X, int Y, int Z, void* stream);
 
+/* Slab-tile variants for the multi-GPU path: every field argument is a LOCAL slab
+ * (X, Y, Lz) that carries halo planes along z; d_phi_n is the WHOLE (X, Y, Zg) volume (the warp gathers at absolute
+ * coordinates); only planes [z_own_lo, z_own_hi) enter the max-norm.  Clamp / mirror rules apply at the slab's array
+ * edges, which coincide with the volume boundary exactly where a slab has no halo.  d_prev_slots (may be NULL) and
+ * max_update_norm form the device-side convergence gate (see the solver handle). */
+int sobfu_hip_tile_init_identity(float* d_psi, int X, int Y, int Lz, int zbase, void* stream); /* psi.z = z + zbase */
+/* d_phi / d_psi (of estimate_inverse) are WHOLE (X, Y, Zg) volumes; outputs are local slabs whose plane 0 is global
+ * plane zbase. */
+int sobfu_hip_tile_apply(const float* d_phi, int Zg, float* d_phi_warped, const float* d_psi, int X, int Y, int Lz,
+                         void* stream);
+int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv, int X, int Y, int Lz, int zbase,
+                                    int n_sweeps, void* stream);
+int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
+                                      float* d_nabla_U, float w_reg, int X, int Y, int Lz, const uint32_t* d_prev_slots,
+                                      float max_update_norm, void* stream);
+int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
+                                       float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha,
+                                       int X, int Y, int Lz, int Zg, int z_own_lo, int z_own_hi,
+                                       const uint32_t* d_prev_slots, float max_update_norm, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * solver handle  (sobfu::cuda::Solver, include/sobfu/solver.hpp:52-101, src/sobfu/solver.cpp:7-101)
  * ---------------------------------------------------------------------------------------------------- */

@@ -167,6 +167,11 @@ def apply(phi, phi_warped, psi):
     lib().so_apply(_p(phi), _p(phi_warped), _p(psi), *_dims(phi))
 
 
+def apply_tile(phi_full, phi_warped_slab, psi_slab):
+    X, Y, Lz = _dims(psi_slab)
+    lib().so_apply_tile(_p(phi_full), C.c_int(phi_full.shape[0]), _p(phi_warped_slab), _p(psi_slab), X, Y, Lz)
+
+
 def estimate_inverse(psi, psi_inv, n_iters=48):
     lib().so_estimate_inverse(_p(psi), _p(psi_inv), *_dims(psi), C.c_int(n_iters))
 

@@ -340,6 +340,17 @@ void so_apply(const f2 *phi, f2 *phi_warped, const f4 *psi, int X, int Y, int Z)
     }
 }
 
+/* apply_kernel on a z-slab: phi is the whole (X, Y, Zg) volume, psi / phi_warped are (X, Y, Lz) slabs whose psi
+ * values are absolute voxel coordinates (multi-GPU tiling tests; same arithmetic as so_apply) */
+void so_apply_tile(const f2 *phi, int Zg, f2 *phi_warped, const f4 *psi, int X, int Y, int Lz) {
+    size_t N = (size_t) X * Y * Lz;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < N; ++i) {
+        f4 p          = psi[i];
+        phi_warped[i] = interp_tsdf(phi, X, Y, Zg, p.x, p.y, p.z);
+    }
+}
+
 /* estimate_inverse_kernel x n_iters -- vector_fields.cu:111-138 (reference: 48 sweeps, in place) */
 void so_estimate_inverse(const f4 *psi, f4 *psi_inv, int X, int Y, int Z, int n_iters) {
     for (int it = 0; it < n_iters; ++it) {

@@ -14,31 +14,33 @@ namespace {
     if (x >= (d).x || y >= (d).y) return;
 
 // init_identity_kernel -- vector_fields.cu:64-79.  (float) z equals the reference's z-fold sum of 1.f exactly.
-__global__ void __launch_bounds__(256) init_identity_kernel(float4* __restrict__ psi, Dims d) {
+// zbase: global z of local plane 0 (multi-GPU slabs; 0 on a single GPU)
+__global__ void __launch_bounds__(256) init_identity_kernel(float4* __restrict__ psi, Dims d, int zbase) {
     VOXEL_XYZ(d);
-    psi[vidx(d, x, y, z)] = f4((float) x, (float) y, (float) z);
+    psi[vidx(d, x, y, z)] = f4((float) x, (float) y, (float) (z + zbase));
 }
 
 // apply_kernel -- vector_fields.cu:81-100
+// pd: dims of phi (the whole volume); d: dims of psi / out (== pd on a single GPU, a z-slab on multiple GPUs)
 __global__ void __launch_bounds__(256) apply_kernel(const float2* __restrict__ phi, float2* __restrict__ out,
-                                                    const float4* __restrict__ psi, Dims d) {
+                                                    const float4* __restrict__ psi, Dims d, Dims pd) {
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
     float4 p = psi[i];
-    out[i]   = interp_tsdf(phi, d, p.x, p.y, p.z);
+    out[i]   = interp_tsdf(phi, pd, p.x, p.y, p.z);
 }
 
 // estimate_inverse_kernel x n_sweeps -- vector_fields.cu:111-138.  A sweep reads psi (never written) and the
 // voxel's OWN psi_inv value only, so the reference's 48 launches collapse into one kernel that iterates the
 // fixed point in registers: psi_inv is read once and written once instead of 48 times, bit-identical result.
 __global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
-                                                                  Dims d, int n_sweeps) {
+                                                                  Dims d, Dims pd, int zbase, int n_sweeps) {
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
     float4 v = psi_inv[i];
-    const float4 id = f4((float) x, (float) y, (float) z);
+    const float4 id = f4((float) x, (float) y, (float) (z + zbase));
     for (int it = 0; it < n_sweeps; ++it) {
-        float4 u = interp_disp(psi, d, v.x, v.y, v.z);
+        float4 u = interp_disp(psi, pd, v.x, v.y, v.z);
         v        = sub4(id, mul4(u, 1.f));
     }
     psi_inv[i] = v;
@@ -107,20 +109,44 @@ int sobfu_hip_clear_field(float* d_field, int X, int Y, int Z, void* stream) {
 
 int sobfu_hip_init_identity(float* d_psi, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && X > 0 && Y > 0 && Z > 0);
-    LAUNCH_VOXEL(init_identity_kernel, X, Y, Z, stream, (float4*) d_psi, Dims{X, Y, Z});
+    LAUNCH_VOXEL(init_identity_kernel, X, Y, Z, stream, (float4*) d_psi, Dims{X, Y, Z}, 0);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile_init_identity(float* d_psi, int X, int Y, int Lz, int zbase, void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && X > 0 && Y > 0 && Lz > 0 && zbase >= 0);
+    LAUNCH_VOXEL(init_identity_kernel, X, Y, Lz, stream, (float4*) d_psi, Dims{X, Y, Lz}, zbase);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile_apply(const float* d_phi, int Zg, float* d_phi_warped, const float* d_psi, int X, int Y, int Lz, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi && d_phi_warped && d_psi && X > 0 && Y > 0 && Lz > 0 && Zg > 0 && d_phi != d_phi_warped);
+    LAUNCH_VOXEL(apply_kernel, X, Y, Lz, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{X, Y, Lz},
+                 Dims{X, Y, Zg});
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv, int X, int Y, int Lz, int zbase, int n_sweeps,
+                                    void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && d_psi_inv && X > 0 && Y > 0 && Lz > 0 && Zg > 0 && zbase >= 0 && n_sweeps >= 0 && d_psi != d_psi_inv);
+    if (n_sweeps == 0) return 0;
+    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Lz},
+                 Dims{X, Y, Zg}, zbase, n_sweeps);
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_apply(const float* d_phi, float* d_phi_warped, const float* d_psi, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_phi && d_phi_warped && d_psi && X > 0 && Y > 0 && Z > 0 && d_phi != d_phi_warped);
-    LAUNCH_VOXEL(apply_kernel, X, Y, Z, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{X, Y, Z});
+    LAUNCH_VOXEL(apply_kernel, X, Y, Z, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{X, Y, Z},
+                 Dims{X, Y, Z});
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_estimate_inverse(const float* d_psi, float* d_psi_inv, int X, int Y, int Z, int n_sweeps, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && d_psi_inv && X > 0 && Y > 0 && Z > 0 && n_sweeps >= 0 && d_psi != d_psi_inv);
     if (n_sweeps == 0) return 0;
-    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, n_sweeps);
+    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, Dims{X, Y, Z}, 0,
+                 n_sweeps);
     return (int) hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU
                   const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream);
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream);
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z = 0, int own_lo = 0, int own_hi = 0);
 }  // namespace sobfu_hip
 
 namespace {

@@ -306,6 +306,10 @@ struct PassBArgs {
     int zc;
     const uint32_t* prev_slots;
     float max_update_norm;
+    // multi-GPU slab tiles: the fields are local slabs (d) that carry halo planes, phi_n is the whole volume (pd);
+    // only planes [own_lo, own_hi) are owned by this rank and enter the max-norm.  Single GPU: pd == d, [0, d.z).
+    Dims pd;
+    int own_lo, own_hi;
 };
 
 template <int RPT, int WY, bool WRITE_UPDATES>
@@ -428,11 +432,11 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
             p.y -= u.y;
             p.z -= u.z;
             if (x < d.x && y < d.y) {
-                msq = fmaxf(msq, norm_sq4(u));
+                if (z >= a.own_lo && z < a.own_hi) msq = fmaxf(msq, norm_sq4(u));
                 const size_t i = zcur + (size_t) x + (size_t) d.x * y;
                 a.psi[i] = p;
                 if (WRITE_UPDATES) a.updates[i] = u;
-                a.pnp[i] = interp_tsdf(a.phi_n, d, p.x, p.y, p.z);  // apply_kernel (vector_fields.cu:95-98)
+                a.pnp[i] = interp_tsdf(a.phi_n, a.pd, p.x, p.y, p.z);  // apply_kernel (vector_fields.cu:95-98)
             }
         }
 #pragma unroll
@@ -492,10 +496,11 @@ int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU
 
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream) {
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi) {
+    if (phi_Z <= 0) { phi_Z = Z; own_lo = 0; own_hi = Z; }
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
     if (zc <= 0) zc = pick_zc(X, Y, Z, TY);
-    PassBArgs a{(const float4*) nU, (float4*) psi, (const float2*) phi_n, (float2*) pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, prev_slots, max_update_norm};
+    PassBArgs a{(const float4*) nU, (float4*) psi, (const float2*) phi_n, (float2*) pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + zc - 1) / zc));
     if (updates)
@@ -553,7 +558,27 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
     SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Z > 0);
     if ((size_t) X * Y * Z > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Z,
-                                    nullptr, 0.f, 0, (hipStream_t) stream);
+                                    nullptr, 0.f, 0, (hipStream_t) stream, 0, 0, 0);
+}
+
+int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
+                                      float w_reg, int X, int Y, int Lz, const uint32_t* d_prev_slots, float max_update_norm,
+                                      void* stream) {
+    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Lz > 1);
+    if ((size_t) X * Y * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
+    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Lz, d_prev_slots, max_update_norm, 0,
+                                    (hipStream_t) stream);
+}
+
+int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
+                                       float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha, int X, int Y,
+                                       int Lz, int Zg, int z_own_lo, int z_own_hi, const uint32_t* d_prev_slots,
+                                       float max_update_norm, void* stream) {
+    SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Lz > 0 && Zg >= 1 &&
+                     z_own_lo >= 0 && z_own_lo <= z_own_hi && z_own_hi <= Lz);
+    if ((size_t) X * Y * Lz > (size_t) 0x7fffffff || (size_t) X * Y * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
+    return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Lz,
+                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi);
 }
 
 }  // extern "C"

@@ -1,0 +1,234 @@
+"""Multi-GPU solver loop: the volume is cut into z-slabs, one rank (one process, one GPU) per slab.
+
+SURVEY.md section 8(e).  Frames of a sequence are sequentially dependent (psi persists), so the path shards by
+VOLUME TILE.  Slabs along z (z is the slowest-varying axis of the layout) make every halo a contiguous block of
+planes: halo exchange is zero-copy `isend/irecv` straight out of / into the field arrays -- no pack kernels.
+
+Per rank:  psi, phi_n o psi, phi_global, nabla_U are LOCAL slabs (X, Y, Lz) = owned planes + HALO (=3) planes towards
+each neighbour; phi_n is replicated (the warp gathers at absolute coordinates anywhere in the volume).
+
+One iteration (Option A of the survey: two face-only exchanges, every halo value is computed by its owner):
+    E1  exchange psi, phi_n o psi   (radius 1)          -> pass A needs +-1 neighbours
+    A   nabla_U  on the whole slab
+    E2  exchange nabla_U            (radius 3)          -> pass B needs +-3 neighbours
+    B   psi -= alpha * (Sx+Sy+Sz) nabla_U, phi_n o psi, max ||u||^2 over OWNED planes
+    R   all_reduce(MAX) of the 256 max-norm slots -- only when max_update_norm >= 0 (otherwise the test never fires)
+Kernels run over the whole slab; what they write into halo planes is overwritten by the next exchange.  Clamp /
+mirror rules act at a slab's array edge, which is the volume boundary exactly where the slab has no halo, so the
+result equals the single-GPU run bit for bit (the max is order-independent).
+
+The kernel backend is pluggable: `HipBackend` (product; C ABI on torch CUDA tensors over RCCL) -- the CPU tests inject an
+oracle-backed backend over gloo to check the decomposition logic without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HALO = 3
+SLOTS = 256
+
+
+class SlabLayout:
+    """Which z planes a rank owns and how its local slab is laid out."""
+
+    def __init__(self, dims, world, rank, halo=HALO):
+        X, Y, Z = (int(d) for d in dims)
+        if Z < world * halo:
+            raise ValueError(f"Z={Z} is too thin for {world} slabs with halo {halo}")
+        base, rem = divmod(Z, world)
+        starts = [r * base + min(r, rem) for r in range(world + 1)]
+        self.dims, self.world, self.rank, self.halo = (X, Y, Z), world, rank, halo
+        self.z0, self.z1 = starts[rank], starts[rank + 1]
+        self.lo = halo if rank > 0 else 0            # halo planes below
+        self.hi = halo if rank < world - 1 else 0    # halo planes above
+        self.Lz = (self.z1 - self.z0) + self.lo + self.hi
+        self.own_lo, self.own_hi = self.lo, self.lo + (self.z1 - self.z0)
+        self.zbase = self.z0 - self.lo               # global z of local plane 0
+        if world > 1 and (self.z1 - self.z0) < halo:
+            raise ValueError("a slab must own at least `halo` planes")
+
+    def local_shape(self, channels):
+        X, Y, _ = self.dims
+        return (self.Lz, Y, X, channels)
+
+    def take(self, full):
+        """local slab (with halos) cut out of a full-volume array/tensor"""
+        return full[self.zbase:self.zbase + self.Lz]
+
+    def owned(self, local):
+        return local[self.own_lo:self.own_hi]
+
+
+def exchange_halos(layout: SlabLayout, fields, group=None):
+    """fields: list of (tensor (Lz, ...), radius).  Zero-copy neighbour exchange of `radius` owned planes."""
+    L = layout
+    ops = []
+    for t, w in fields:
+        assert t.shape[0] == L.Lz and t.is_contiguous() and 0 < w <= L.halo
+        if L.rank > 0:
+            ops.append(dist.P2POp(dist.isend, t[L.own_lo:L.own_lo + w], L.rank - 1, group))
+            ops.append(dist.P2POp(dist.irecv, t[L.own_lo - w:L.own_lo], L.rank - 1, group))
+        if L.rank < L.world - 1:
+            ops.append(dist.P2POp(dist.isend, t[L.own_hi - w:L.own_hi], L.rank + 1, group))
+            ops.append(dist.P2POp(dist.irecv, t[L.own_hi:L.own_hi + w], L.rank + 1, group))
+    if not ops:
+        return
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+
+
+class HipBackend:
+    """Per-slab kernels through the C ABI (include/sobfu_hip.h `sobfu_hip_tile_*`)."""
+
+    def __init__(self):
+        from . import _lib, ops
+
+        self._lib, self._ops = _lib, ops
+
+    device = "cuda"
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def init_identity(self, psi, layout):
+        X, Y, _ = layout.dims
+        self._lib.check(self._lib.lib().sobfu_hip_tile_init_identity(C.c_void_p(psi.data_ptr()), X, Y, layout.Lz, layout.zbase,
+                                                                     self._stream()), "tile_init_identity")
+
+    def apply(self, phi_full, out, psi, layout):
+        X, Y, Z = layout.dims
+        self._lib.check(self._lib.lib().sobfu_hip_tile_apply(C.c_void_p(phi_full.data_ptr()), Z, C.c_void_p(out.data_ptr()),
+                                                             C.c_void_p(psi.data_ptr()), X, Y, layout.Lz, self._stream()), "tile_apply")
+
+    def pass_a(self, pnp, pg, psi, nU, w_reg, prev_slots, thr, layout):
+        X, Y, _ = layout.dims
+        prev = C.c_void_p(prev_slots.data_ptr()) if prev_slots is not None else None
+        self._lib.check(self._lib.lib().sobfu_hip_tile_potential_gradient(
+            C.c_void_p(pnp.data_ptr()), C.c_void_p(pg.data_ptr()), C.c_void_p(psi.data_ptr()), C.c_void_p(nU.data_ptr()),
+            C.c_float(w_reg), X, Y, layout.Lz, prev, C.c_float(thr), self._stream()), "tile_potential_gradient")
+
+    def pass_b(self, nU, psi, phi_n_full, pnp, slots, taps, alpha, prev_slots, thr, layout):
+        X, Y, Z = layout.dims
+        prev = C.c_void_p(prev_slots.data_ptr()) if prev_slots is not None else None
+        self._lib.check(self._lib.lib().sobfu_hip_tile_smooth_update_apply(
+            C.c_void_p(nU.data_ptr()), C.c_void_p(psi.data_ptr()), C.c_void_p(phi_n_full.data_ptr()), C.c_void_p(pnp.data_ptr()), None,
+            C.c_void_p(slots.data_ptr()), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), X, Y, layout.Lz, Z,
+            layout.own_lo, layout.own_hi, prev, C.c_float(thr), self._stream()), "tile_smooth_update_apply")
+
+    def sobolev_filter(self, s, lam):
+        return self._ops.sobolev_filter(s, lam)
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+
+def _sqrt_rd(m_bits: int) -> float:
+    m = np.array([m_bits], np.uint32).view(np.float32)[0]
+    r = np.sqrt(m, dtype=np.float32)
+    if r > 0 and np.float64(r) * np.float64(r) > np.float64(m):
+        r = np.nextafter(r, np.float32(-np.inf), dtype=np.float32)
+    return float(r)
+
+
+class TiledSolver:
+    """The gradient-descent loop of sobfu::device::estimate_psi (reference src/sobfu/cuda/solver.cu:106-193) on slabs."""
+
+    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, backend=None, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.group = group
+        self.backend = backend or HipBackend()
+        self.layout = SlabLayout(dims, self.world, self.rank)
+        self.alpha, self.w_reg, self.thr = float(alpha), float(w_reg), float(max_update_norm)
+        if s < 7:
+            raise ValueError("S < 7 is unsupported (the kernels use 7 taps, reference solver.cu:211-234)")
+        self.taps = np.asarray(self.backend.sobolev_filter(s, lam), np.float32)[:7]
+        dev = self.backend.device
+        self.nabla_U = torch.zeros(self.layout.local_shape(4), dtype=torch.float32, device=dev)
+        self.slots = None
+
+    # -- state helpers ------------------------------------------------------------------------------------------
+    def new_local(self, channels):
+        return torch.zeros(self.layout.local_shape(channels), dtype=torch.float32, device=self.backend.device)
+
+    def identity_psi(self):
+        psi = self.new_local(4)
+        self.backend.init_identity(psi, self.layout)
+        return psi
+
+    def iterate(self, phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters):
+        """Runs n_iters iterations (fewer if the convergence test fires).  Returns (iterations, per-iteration max norms)."""
+        L, be = self.layout, self.backend
+        can_converge = self.thr >= 0.0
+        be.apply(phi_n_full, phi_n_psi_local, psi_local, L)  # solver.cu:106
+        slots = torch.zeros((n_iters + 1, SLOTS), dtype=torch.int32, device=be.device)
+        self.slots = slots
+        for it in range(1, n_iters + 1):
+            prev = slots[it - 1] if (it > 1 and can_converge) else None
+            if self.world > 1:
+                exchange_halos(L, [(psi_local, 1), (phi_n_psi_local, 1)], self.group)
+            be.pass_a(phi_n_psi_local, phi_global_local, psi_local, self.nabla_U, self.w_reg, prev, self.thr, L)
+            if self.world > 1:
+                exchange_halos(L, [(self.nabla_U, 3)], self.group)
+            be.pass_b(self.nabla_U, psi_local, phi_n_full, phi_n_psi_local, slots[it], self.taps, self.alpha, prev, self.thr, L)
+            if self.world > 1 and can_converge:
+                dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
+        if self.world > 1 and not can_converge:
+            dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=self.group)
+        be.synchronize()
+        mx = slots[1:].max(dim=1).values.cpu().numpy().view(np.uint32)
+        norms = np.array([_sqrt_rd(int(b)) for b in mx], np.float32)
+        done = n_iters
+        if can_converge:
+            for k, v in enumerate(norms):
+                if v <= self.thr:  # solver.cu:183 -- later iterations were device-side no-ops
+                    done = k + 1
+                    break
+        return done, norms[:done]
+
+    def gather_owned(self, local):
+        """all_gather of the owned planes -> full volume on every rank (z-concatenation)."""
+        own = self.layout.owned(local).contiguous()
+        if self.world == 1:
+            return own
+        base, rem = divmod(self.layout.dims[2], self.world)
+        parts = [torch.empty((base + (1 if r < rem else 0),) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
+                 for r in range(self.world)]
+        dist.all_gather(parts, own, group=self.group)
+        return torch.cat(parts, dim=0)
+
+
+def bench_tiled(P, steps, warmup, rank, world):
+    """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N z-slabs (strong scaling)."""
+    from . import ops
+
+    dims = P["dims"]
+    X, Y, Z = dims
+    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
+    solver = TiledSolver(dims, alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
+    L = solver.layout
+    # every rank builds the full analytic TSDFs (replicated phi_n; phi_global is then cut to the local slab)
+    pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
+    ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
+    pg = L.take(pg_full).clone()
+    del pg_full
+    pnp = solver.new_local(2)
+    psi = solver.identity_psi()
+    if warmup > 0:
+        solver.iterate(pg, pn_full, pnp, psi, warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    done, norms = solver.iterate(pg, pn_full, pnp, psi, steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    assert done == steps and np.isfinite(norms).all() and float(norms.max()) > 0
+    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=int(solver.nabla_U.numel() * 4),
+                parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange")

@@ -1,0 +1,104 @@
+"""Worker for tests/test_tiled_cpu.py: runs sobfu_amd.tiled.TiledSolver over gloo with an ORACLE-backed per-slab kernel
+backend (test infrastructure: checks the decomposition / halo-exchange / reduction logic on CPU, bit for bit against the
+single-process oracle solve).  Usage: python _tiled_worker.py <rank> <world> <port> <out.npz> <thr>"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import oracle as O  # noqa: E402
+from sobfu_amd import tiled  # noqa: E402
+from sobfu_amd.synthetic import hash_field  # noqa: E402
+
+DIMS = (20, 12, 24)
+ITERS = 6
+
+
+class OracleBackend:
+    device = "cpu"
+
+    def init_identity(self, psi, layout):
+        a = psi.numpy()
+        O.init_identity(a)
+        a[..., 2] += np.float32(layout.zbase)
+
+    def apply(self, phi_full, out, psi, layout):
+        O.apply_tile(phi_full.numpy(), out.numpy(), psi.numpy())
+
+    @staticmethod
+    def _gate(prev, thr):
+        if prev is None:
+            return False
+        return tiled._sqrt_rd(int(prev.numpy().view(np.uint32).max())) <= thr
+
+    def pass_a(self, pnp, pg, psi, nU, w_reg, prev, thr, layout):
+        if self._gate(prev, thr):
+            return
+        dims = (layout.dims[0], layout.dims[1], layout.Lz)
+        g, L = O.new_field(dims), O.new_field(dims)
+        O.tsdf_gradient(pnp.numpy(), g)
+        O.laplacian(psi.numpy(), L)
+        O.potential_gradient(pnp.numpy(), pg.numpy(), g, L, nU.numpy(), w_reg)
+
+    def pass_b(self, nU, psi, phi_n_full, pnp, slots, taps, alpha, prev, thr, layout):
+        if self._gate(prev, thr):
+            return
+        dims = (layout.dims[0], layout.dims[1], layout.Lz)
+        nUS, upd = O.new_field(dims), O.new_field(dims)
+        O.convolution_rows(nUS, nU.numpy(), taps)
+        O.convolution_columns(nUS, nU.numpy(), taps)
+        O.convolution_depth(nUS, nU.numpy(), taps)
+        O.update_psi(psi.numpy(), nUS, upd, alpha)
+        O.apply_tile(phi_n_full.numpy(), pnp.numpy(), psi.numpy())
+        u = upd[layout.own_lo:layout.own_hi]
+        sq = (u[..., 0] * u[..., 0] + u[..., 1] * u[..., 1]) + u[..., 2] * u[..., 2]
+        s = slots.numpy().view(np.uint32)
+        s[0] = max(s[0], np.float32(sq.max()).view(np.uint32))
+
+    def sobolev_filter(self, s, lam):
+        return O.sobolev_filter(s, lam)
+
+    def synchronize(self):
+        pass
+
+
+def inputs():
+    X, Y, Z = DIMS
+    pg = hash_field((Z, Y, X, 2), 101)
+    pn = hash_field((Z, Y, X, 2), 102)
+    pg[..., 1] = 1
+    pn[..., 1] = (hash_field((Z, Y, X), 103) > -0.5).astype(np.float32)
+    return pg, pn
+
+
+def main():
+    rank, world, port, out, thr = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], float(sys.argv[5])
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O.set_num_threads(1)
+    torch.set_num_threads(1)
+    pg, pn = inputs()
+    sv = tiled.TiledSolver(DIMS, alpha=0.05, w_reg=0.4, max_update_norm=thr, backend=OracleBackend())
+    L = sv.layout
+    pg_l = torch.from_numpy(np.ascontiguousarray(L.take(pg)))
+    pn_full = torch.from_numpy(pn)
+    pnp = sv.new_local(2)
+    psi = sv.identity_psi()
+    done, norms = sv.iterate(pg_l, pn_full, pnp, psi, ITERS)
+    # second solve, warm-started (psi persists across frames)
+    done2, norms2 = sv.iterate(pg_l, pn_full, pnp, psi, 3)
+    psi_full = sv.gather_owned(psi)
+    pnp_full = sv.gather_owned(pnp)
+    if rank == 0:
+        np.savez(out, psi=psi_full.numpy(), pnp=pnp_full.numpy(), norms=norms, done=done, norms2=norms2, done2=done2)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -417,3 +417,50 @@ def test_full_size_256_fused_equals_launchers_and_properties(ops, oracle):
     out_i = ops.new_volume(dims)
     ops.apply(pn, out_i, ident)
     assert torch.equal(out_i.view(torch.int32), pn.view(torch.int32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-GPU slab kernels (sobfu_hip_tile_*) on one GPU: slabs with exchanged halos == full volume
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_kernels_match_full_volume(ops, oracle, world):
+    from sobfu_amd import tiled
+
+    dims = (70, 24, 36)
+    X, Y, Z = dims
+    pg, pn = rand_volume(dims, 41), rand_volume(dims, 42)
+    psi0 = warped_identity(oracle, dims, 43, 1.2)
+    S = oracle.sobolev_filter(7, 0.1)
+    w_reg, alpha = 0.6, 0.1
+    be = tiled.HipBackend()
+    # full-volume reference on the GPU (itself bit-exact vs the oracle, tests above)
+    psi_f, pnp_f, nU_f = dev(psi0), ops.new_volume(dims), ops.new_field(dims)
+    ops.apply(dev(pn), pnp_f, psi_f)
+    ops.fused_potential_gradient(pnp_f, dev(pg), psi_f, nU_f, w_reg)
+    pnp_in = pnp_f.clone()
+    m_full = ops.fused_smooth_update_apply(nU_f, psi_f, dev(pn), pnp_f, S, alpha)
+    pn_d = dev(pn)
+    m_tiles = 0.0
+    for r in range(world):
+        L = tiled.SlabLayout(dims, world, r)
+        # slabs cut from the full arrays = what the halo exchange delivers
+        psi_l, pnp_l, pg_l = (L.take(t).clone().contiguous() for t in (dev(psi0), pnp_in, dev(pg)))
+        idl = torch.zeros(L.local_shape(4), device="cuda")
+        be.init_identity(idl, L)
+        ident = oracle.new_field(dims)
+        oracle.init_identity(ident)
+        assert same(host(idl), L.take(ident))
+        out_l = torch.zeros(L.local_shape(2), device="cuda")
+        be.apply(pn_d, out_l, psi_l, L)
+        assert torch.equal(out_l.view(torch.int32), pnp_l.view(torch.int32))
+        nU_l = torch.zeros(L.local_shape(4), device="cuda")
+        be.pass_a(pnp_l, pg_l, psi_l, nU_l, w_reg, None, 0.0, L)
+        # pass A is exact wherever the radius-1 stencil stays inside the slab: owned planes (+2 halo planes)
+        assert torch.equal(L.owned(nU_l).view(torch.int32), nU_f[L.z0:L.z1].view(torch.int32))
+        nU_l = L.take(nU_f).clone().contiguous()  # E2: radius-3 halos from the owners
+        slots = torch.zeros(256, dtype=torch.int32, device="cuda")
+        be.pass_b(nU_l, psi_l, pn_d, pnp_l, slots, S, alpha, None, 0.0, L)
+        assert torch.equal(L.owned(psi_l).view(torch.int32), psi_f[L.z0:L.z1].view(torch.int32))
+        assert torch.equal(L.owned(pnp_l).view(torch.int32), pnp_f[L.z0:L.z1].view(torch.int32))
+        m_tiles = max(m_tiles, tiled._sqrt_rd(int(slots.max().cpu().numpy().view(np.uint32))))
+    assert m_tiles == m_full
