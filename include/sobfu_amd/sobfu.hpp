@@ -588,3 +588,105 @@ private:
 };
 }  // namespace cuda
 }  // namespace sobfu
+
+// ================================================================================================================
+// Headless frame driver: SobFusion::operator() without PCL / viz / marching cubes, and the
+// .ini parameter schema of the reference app.
+// ================================================================================================================
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace sobfu_amd {
+
+// Reads the reference's parameter file (params/*.ini; schema src/apps/demo.cpp:87-160, derived values :71-74).
+// Unknown keys (e.g. RHO_0 in params_boxing.ini:40, which makes the reference's own parser throw) are ignored.
+// Returns false if the file cannot be opened.
+inline bool read_params_ini(const std::string& path, Params& p, std::map<std::string, std::string>* raw = nullptr) {
+    std::ifstream f(path);
+    if (!f) return false;
+    std::map<std::string, std::string> kv;
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t h = line.find('#');
+        if (h != std::string::npos) line.erase(h);
+        size_t e = line.find('=');
+        if (e == std::string::npos) continue;
+        auto trim = [](std::string s) {
+            size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+            return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+        };
+        kv[trim(line.substr(0, e))] = trim(line.substr(e + 1));
+    }
+    auto F = [&](const char* k, float& v) { auto it = kv.find(k); if (it != kv.end()) v = std::strtof(it->second.c_str(), nullptr); };
+    auto I = [&](const char* k, int& v) { auto it = kv.find(k); if (it != kv.end()) v = (int) std::strtol(it->second.c_str(), nullptr, 10); };
+    I("VOL_DIMS_X", p.volume_dims[0]); I("VOL_DIMS_Y", p.volume_dims[1]); I("VOL_DIMS_Z", p.volume_dims[2]);
+    F("VOL_SIZE_X", p.volume_size[0]); F("VOL_SIZE_Y", p.volume_size[1]); F("VOL_SIZE_Z", p.volume_size[2]);
+    F("TSDF_MAX_WEIGHT", p.tsdf_max_weight);
+    F("GRADIENT_DELTA_FACTOR", p.gradient_delta_factor);
+    F("INTR_FX", p.intr.fx); F("INTR_FY", p.intr.fy); F("INTR_CX", p.intr.cx); F("INTR_CY", p.intr.cy);
+    F("TRUNC_DEPTH", p.icp_truncate_depth_dist);
+    F("BILATERAL_SIGMA_DEPTH", p.bilateral_sigma_depth); F("BILATERAL_SIGMA_SPATIAL", p.bilateral_sigma_spatial);
+    I("BILATERAL_KERNEL_SIZE", p.bilateral_kernel_size);
+    I("START_FRAME", p.start_frame); I("MAX_ITER", p.max_iter);
+    F("MAX_UPDATE_NORM", p.max_update_norm);
+    I("S", p.s); F("LAMBDA", p.lambda); F("ALPHA", p.alpha); F("W_REG", p.w_reg);
+    float trunc_vox = 0.f, eta_vox = 0.f, tz = 0.f;
+    F("TSDF_TRUNC_DIST", trunc_vox); F("ETA", eta_vox); F("VOL_POSE_T_Z", tz);
+    p.tsdf_trunc_dist = trunc_vox * p.voxel_sizes()[0];  // demo.cpp:71
+    p.eta             = eta_vox * p.voxel_sizes()[0];    // demo.cpp:72
+    p.volume_pose     = cv::Affine3f().translate(cv::Vec3f(-p.volume_size[0] / 2.f, -p.volume_size[1] / 2.f, tz));  // :73-74
+    if (raw) *raw = kv;
+    return true;
+}
+}  // namespace sobfu_amd
+
+// SobFusion (include/sobfu/sob_fusion.hpp, src/sobfu/sob_fusion.cpp:71-145) -- per-frame driver: bilateral filter ->
+// depth truncation -> dists; frame 0 builds phi_global and allocates everything; frame n builds phi_n, fuses it
+// directly while n < START_FRAME, otherwise estimates psi (warm-started) and fuses phi_n o psi.
+class SobFusion {
+public:
+    explicit SobFusion(const Params& p) : frame_counter_(0), params(p), camera_pose_(cv::Affine3f::Identity()) {
+        dists_.create(params.rows, params.cols);
+    }
+    Params& getParams() { return params; }
+    bool operator()(const kfusion::cuda::Depth& depth) {
+        std::printf("--- FRAME NO. %d ---\n", frame_counter_);
+        kfusion::cuda::depthBilateralFilter(depth, filtered_, params.bilateral_kernel_size, params.bilateral_sigma_spatial,
+                                            params.bilateral_sigma_depth);                              // sob_fusion.cpp:78
+        kfusion::cuda::depthTruncation(filtered_, params.icp_truncate_depth_dist);                     // :85
+        kfusion::cuda::computeDists(filtered_, dists_, params.intr);                                   // :91
+        if (frame_counter_ == 0) {                                                                     // :93-123
+            phi_global = cv::Ptr<kfusion::cuda::TsdfVolume>(new kfusion::cuda::TsdfVolume(params));
+            phi_global->integrate(dists_, camera_pose_, params.intr);
+            phi_global_psi_inv = cv::Ptr<kfusion::cuda::TsdfVolume>(new kfusion::cuda::TsdfVolume(params));
+            phi_n              = cv::Ptr<kfusion::cuda::TsdfVolume>(new kfusion::cuda::TsdfVolume(params));
+            phi_n_psi          = cv::Ptr<kfusion::cuda::TsdfVolume>(new kfusion::cuda::TsdfVolume(params));
+            psi     = std::make_shared<sobfu::cuda::DeformationField>(params.volume_dims);
+            psi_inv = std::make_shared<sobfu::cuda::DeformationField>(params.volume_dims);
+            solver  = std::make_shared<sobfu::cuda::Solver>(params);
+            return ++frame_counter_, true;
+        }
+        phi_n->clear();                                                                                // :129
+        phi_n->integrate(dists_, camera_pose_, params.intr);                                           // :130
+        if (frame_counter_ < params.start_frame) {                                                     // :136-139
+            phi_global->integrate(*phi_n);
+            return ++frame_counter_, true;
+        }
+        solver->estimate_psi(phi_global, phi_global_psi_inv, phi_n, phi_n_psi, psi, psi_inv);          // :141
+        phi_global->integrate(*phi_n_psi);                                                             // :142
+        return ++frame_counter_, true;
+    }
+    std::shared_ptr<sobfu::cuda::DeformationField> getDeformationField() { return psi; }
+
+    cv::Ptr<kfusion::cuda::TsdfVolume> phi_global, phi_global_psi_inv, phi_n, phi_n_psi;
+    std::shared_ptr<sobfu::cuda::DeformationField> psi, psi_inv;
+    std::shared_ptr<sobfu::cuda::Solver> solver;
+
+private:
+    int frame_counter_;
+    Params params;
+    cv::Affine3f camera_pose_;  // fixed to identity, sob_fusion.cpp:33
+    kfusion::cuda::Depth filtered_;
+    kfusion::cuda::Dists dists_;
+};

@@ -12,16 +12,34 @@ OUT = os.path.join(ROOT, "build", "host_shell_tests")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
+APP = os.path.join(ROOT, "build", "sobfu_headless")
+
+
+def _compile(src: str, out: str) -> None:
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__",
+                           f"-I{ROCM}/include", f"-I{os.path.join(ROOT, 'include')}", src, "-o", out, f"-L{HERE}", "-lsobfu_hip",
+                           f"-L{ROCM}/lib", "-lamdhip64", f"-Wl,-rpath,{HERE}", f"-Wl,-rpath,{ROCM}/lib", "-Wl,-rpath,$ORIGIN/../sobfu_amd"])
+
+
+def build_app(force: bool = False) -> str:
+    """apps/sobfu_headless.cpp: the headless frame-loop app over the shells."""
+    src = os.path.join(ROOT, "apps", "sobfu_headless.cpp")
+    deps = [src, os.path.join(ROOT, "include", "sobfu_amd", "sobfu.hpp"), os.path.join(HERE, "libsobfu_hip.so")]
+    if force or not os.path.exists(APP) or any(os.path.getmtime(APP) < os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(APP), exist_ok=True)
+        _compile(src, APP)
+    return APP
+
+
 def build_host(force: bool = False) -> str:
+    build_app(force)
     src = os.path.join(ROOT, "tests", "cpp", "host_shell_tests.cpp")
     deps = [src, os.path.join(ROOT, "include", "sobfu_amd", "sobfu.hpp"), os.path.join(ROOT, "include", "sobfu_hip.h"),
             os.path.join(HERE, "libsobfu_hip.so")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__",
-                           f"-I{ROCM}/include", f"-I{os.path.join(ROOT, 'include')}", src, "-o", OUT, f"-L{HERE}", "-lsobfu_hip",
-                           f"-L{ROCM}/lib", "-lamdhip64", f"-Wl,-rpath,{HERE}", f"-Wl,-rpath,{ROCM}/lib", "-Wl,-rpath,$ORIGIN/../sobfu_amd"])
+    _compile(src, OUT)
     return OUT
 
 

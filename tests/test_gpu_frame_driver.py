@@ -1,0 +1,65 @@
+"""Headless frame driver (apps/sobfu_headless.cpp = SobFusion::operator() counterpart over the C++ shells) on the GPU,
+BASELINE config 1, against the known-answer values of SURVEY.md Appendix B run 2.
+
+The depth pre-step runs the bilateral filter with the device's expf (the reference uses __expf): a few pixels may differ
+by 1 mm from the oracle's libm version, so sums are compared with a small tolerance instead of bit for bit (the bit-exact
+checks of every stage downstream of the filter are in test_gpu_parity.py)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    from sobfu_amd import build, build_host
+
+    build.build_hip()
+    exe = build_host.build_app()
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def _stats(out, name):
+    return [(float(a), float(b), int(c)) for a, b, c in
+            re.findall(rf"^{name}: sum_tsdf=(\S+) sum_weight=(\S+) non_truncated_observed=(\d+)", out, re.M)]
+
+
+def test_config1_two_frames():
+    out = _run(os.path.join(ROOT, "params", "config1_sphere_64.ini"), "--synthetic", "2", "--vverbose")
+    assert "--- FRAME NO. 0 ---" in out and "--- FRAME NO. 1 ---" in out
+    pg, pn = _stats(out, "phi_global"), _stats(out, "phi_n")
+    # frame 0: phi_global = integrate(depth 0); Appendix B: -19581.2063 / 8468 / 2909
+    assert abs(pg[0][0] + 19581.2063) < 0.5 and abs(pg[0][1] - 8468) <= 3 and abs(pg[0][2] - 2909) <= 6
+    # frame 1: phi_n: -19552.2192 / 8470 / 2921
+    assert abs(pn[0][0] + 19552.2192) < 0.5 and abs(pn[0][1] - 8470) <= 3 and abs(pn[0][2] - 2921) <= 6
+    # energies printed by the solver, iteration 1 and 10 (Appendix B run 2): 1059.91 + 0.2 * 0, 255.322 + 0.2 * 234.173
+    e = [(float(a), float(b)) for a, b in re.findall(r"data energy \+ w_reg \* reg energy = (\S+) \+ 0\.2 \* (\S+) =", out)]
+    assert len(e) == 10
+    assert abs(e[0][0] - 1059.91) < 0.5 and e[0][1] == 0.0
+    assert abs(e[9][0] - 255.322) < 0.3 and abs(e[9][1] - 234.173) < 0.3
+    norms = [float(v) for v in re.findall(r"max\. update norm (\S+) at voxel", out)]
+    assert len(norms) == 10 and abs(norms[0] - 0.234661) < 2e-3 and abs(norms[9] - 0.0237178) < 5e-4
+    assert "SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING" in out
+    # after the solve: phi_n o psi -19567.7977 / 8561 / 4363; fused phi_global -19566.7973 / 17029 / 4531;
+    # phi_global o psi^-1 -19571.7471 / 8601 / 4392
+    s = _stats(out, "phi_n_psi")[0]
+    assert abs(s[0] + 19567.7977) < 0.6 and abs(s[1] - 8561) <= 4 and abs(s[2] - 4363) <= 10
+    assert abs(pg[1][0] + 19566.7973) < 0.8 and abs(pg[1][1] - 17029) <= 6 and abs(pg[1][2] - 4531) <= 12
+    s = _stats(out, "phi_global_psi_inv")[0]
+    assert abs(s[0] + 19571.7471) < 0.6 and abs(s[1] - 8601) <= 4 and abs(s[2] - 4392) <= 10
+
+
+def test_start_frame_gating_and_unknown_keys(tmp_path):
+    """START_FRAME > frame index fuses phi_n directly (sob_fusion.cpp:136-139); unknown keys (RHO_0) are ignored."""
+    ini = tmp_path / "p.ini"
+    src = open(os.path.join(ROOT, "params", "config1_sphere_64.ini")).read().replace("START_FRAME=1", "START_FRAME=2")
+    ini.write_text(src + "\nRHO_0=1.0\nSOME_FUTURE_KEY=abc\n")
+    out = _run(str(ini), "--synthetic", "3", "--max-iter", "3")
+    assert out.count("solver: iterations=3") == 1          # only frame 2 runs the solver
+    pg = _stats(out, "phi_global")
+    assert pg[1][1] > pg[0][1] and pg[2][1] > pg[1][1]     # weights accumulate on every frame
