@@ -19,6 +19,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 
+# solver_kernels.hip: hipcc's SLP vectoriser turns the 7-tap y chain of the compact pass B into <7 x float> shuffles that
+# it lowers through 64 B/lane of scratch (pass B 390 us instead of 180 us at 256^3); without SLP the kernels also need
+# ~30 fewer VGPRs.  Measured, interleaved A/B: DESIGN.md section 4.1.
+PER_FILE_FLAGS = {"solver_kernels.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -42,7 +48,7 @@ def build_hip(force: bool = False, extra_flags=(), verbose: bool = False) -> str
         op = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, *extra_flags, "-c", sp, "-o", op])
+            jobs.append([_hipcc(), *FLAGS, *PER_FILE_FLAGS.get(src, []), *extra_flags, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

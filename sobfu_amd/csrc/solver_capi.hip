@@ -8,6 +8,7 @@
 // the solver stops, and every array it leaves behind, are exactly the reference's.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,12 +18,15 @@
 #include "sobfu_host.hpp"
 
 namespace sobfu_hip {
-int pick_zc(int X, int Y, int Z, int ty);
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
-                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream);
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact);
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream, int phi_Z = 0, int own_lo = 0, int own_hi = 0);
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact);
+int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
+int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
+int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream);
 }  // namespace sobfu_hip
 
 namespace {
@@ -54,6 +58,13 @@ struct sobfu_hip_solver {
     // device workspace
     float* nabla_U     = nullptr;  // 16 B/voxel
     float* updates     = nullptr;  // 16 B/voxel, allocated on first need (verbosity > 0 or keep_updates)
+    // compact iteration state (12-byte psi, 4-byte tsdf-only phi_global / phi_n / phi_n o psi), allocated on first
+    // quiet solve; nabla_U doubles as the 12-byte nabla_U buffer
+    float* c_psi = nullptr;  // 12 B/voxel
+    float* c_f   = nullptr;  //  4 B/voxel  (phi_n o psi).tsdf
+    float* c_g   = nullptr;  //  4 B/voxel  phi_global.tsdf
+    float* c_n   = nullptr;  //  4 B/voxel  phi_n.tsdf
+    bool compact = true;
     uint32_t* slots    = nullptr;  // (slots_iters + 1) x 256
     void* red_scratch  = nullptr;  // 65536 x 8 B block partials
     int slots_iters    = 0;
@@ -66,7 +77,7 @@ struct sobfu_hip_solver {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     double ms_a = 0, ms_b = 0;
-    int prof_launches = 0;
+    int prof_launches = 0, prof_pending = 0;
 
     void log(const std::string& line) const {
         if (log_set) {
@@ -95,6 +106,16 @@ int ensure_slots(sobfu_hip_solver* s, int iters) {
     SOBFU_HIP_TRY(hipMalloc((void**) &s->slots, (size_t) (iters + 1) * kSlots * 4));
     s->slots_iters = iters;
     s->bytes += (size_t) (iters + 1) * kSlots * 4;
+    return 0;
+}
+
+int ensure_compact(sobfu_hip_solver* s) {
+    if (s->c_psi) return 0;
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_psi, s->N * 12));
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_f, s->N * 4));
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_g, s->N * 4));
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_n, s->N * 4));
+    s->bytes += s->N * 24;
     return 0;
 }
 
@@ -136,7 +157,8 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
     r.last_max_update_index = NAN;
     r.last_e_data = r.last_e_reg = NAN;
 
-    SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
+    const bool compact = s->compact && p.verbosity == 0 && max_iter > 0;
+    if (!compact) SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
     if (max_iter <= 0) {
         SOBFU_HIP_TRY(hipStreamSynchronize(st));
         if (rep) *rep = r;
@@ -155,6 +177,18 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
     int done = 0;  // iterations known to have executed
     bool converged = false;
 
+    // compact mode: iterate on private 12-byte psi / nabla_U and tsdf-only TSDF copies; the API buffers are rebuilt after
+    // the loop (psi.xyz written back, phi_n o psi = apply(phi_n, psi) once) -- same values as iterating in place
+    const float *it_pnp = pnp, *it_pg = pg, *it_pn = pn;
+    float *it_psi = psi, *it_out = pnp;
+    if (compact) {
+        SOBFU_TRY(ensure_compact(s));
+        SOBFU_TRY(sobfu_hip::launch_pack_vec(psi, s->c_psi, s->N, st));
+        SOBFU_TRY(sobfu_hip::launch_extract_tsdf(pg, s->c_g, s->N, st));
+        SOBFU_TRY(sobfu_hip::launch_extract_tsdf(pn, s->c_n, s->N, st));
+        SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(s->c_n, s->c_f, s->c_psi, X, Y, Z, st));  // solver.cu:106
+        it_pnp = s->c_f; it_pg = s->c_g; it_pn = s->c_n; it_psi = s->c_psi; it_out = s->c_f;
+    }
     const bool prof = s->profiling && !verbose;
     if (prof) SOBFU_TRY(ensure_events(s, (size_t) 3 * max_iter));
     int launched = 0;
@@ -164,10 +198,10 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
             const uint32_t* prev = (it > 1) ? s->slots + (size_t) (it - 1) * kSlots : nullptr;
             uint32_t* cur        = s->slots + (size_t) it * kSlots;
             if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1)], st));
-            SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st));
+            SOBFU_TRY(sobfu_hip::launch_pass_a(it_pnp, it_pg, it_psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st, compact));
             if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1) + 1], st));
-            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, prev,
-                                               p.max_update_norm, 0, st));
+            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, it_psi, it_pn, it_out, upd, cur, s->taps, p.alpha, X, Y, Z, prev,
+                                               p.max_update_norm, 0, st, 0, 0, 0, compact));
             if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1) + 2], st));
             launched = it;
             if (can_converge && (it % kCheckEvery == 0 || it == max_iter)) {
@@ -200,17 +234,11 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
             }
             done = max_iter;
         }
-        if (prof) {
-            SOBFU_HIP_TRY(hipStreamSynchronize(st));
-            for (int it = 1; it <= (done < launched ? done : launched); ++it) {
-                float a = 0, b = 0;
-                SOBFU_HIP_TRY(hipEventElapsedTime(&a, s->events[3 * (it - 1)], s->events[3 * (it - 1) + 1]));
-                SOBFU_HIP_TRY(hipEventElapsedTime(&b, s->events[3 * (it - 1) + 1], s->events[3 * (it - 1) + 2]));
-                s->ms_a += a;
-                s->ms_b += b;
-                s->prof_launches += 1;
-            }
+        if (compact) {
+            SOBFU_TRY(sobfu_hip::launch_unpack_vec(s->c_psi, psi, s->N, st));
+            SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // the state solver.cu:168 leaves behind
         }
+        if (prof) s->prof_pending = done < launched ? done : launched;  // elapsed times are read in get_profile()
         // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
         for (int it = 1; it <= done; ++it)
             if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
@@ -227,8 +255,8 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
                        fmt_g(r.last_e_reg) + " = " + fmt_g(e));
             }
             uint32_t* cur = s->slots + (size_t) it * kSlots;
-            SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st));
-            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st));
+            SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st, false));
+            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st, 0, 0, 0, false));
             float mx[2];
             SOBFU_TRY(sobfu_hip_max_update_norm(upd, (int) s->N, s->red_scratch, mx, st));  // solver.cu:172
             r.last_max_update_norm  = mx[0];
@@ -307,6 +335,7 @@ int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const s
     auto* s = new sobfu_hip_solver();
     s->X = X; s->Y = Y; s->Z = Z;
     s->N = (size_t) X * Y * Z;
+    if (const char* e = getenv("SOBFU_COMPACT")) s->compact = atoi(e) != 0;  // tuning override
     int rc = set_params(s, params);
     if (rc == 0) rc = (int) hipMalloc((void**) &s->nabla_U, s->N * 16);
     if (rc == 0) rc = (int) hipMalloc(&s->red_scratch, 65536 * 8);
@@ -328,6 +357,8 @@ int sobfu_hip_solver_destroy(sobfu_hip_solver* s) {
     if (s->updates) (void) hipFree(s->updates);
     if (s->slots) (void) hipFree(s->slots);
     if (s->red_scratch) (void) hipFree(s->red_scratch);
+    for (float* q : {s->c_psi, s->c_f, s->c_g, s->c_n})
+        if (q) (void) hipFree(q);
     for (hipEvent_t e : s->events) (void) hipEventDestroy(e);
     delete s;
     return 0;
@@ -360,14 +391,30 @@ int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* 
     return 0;
 }
 
+int sobfu_hip_solver_set_compact(sobfu_hip_solver* s, int enable) {
+    SOBFU_CHECK_ARGS(s);
+    s->compact = enable != 0;
+    return 0;
+}
+
 int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int enable) {
     SOBFU_CHECK_ARGS(s);
     s->profiling = enable != 0;
+    if (s->profiling) SOBFU_TRY(ensure_events(s, (size_t) 3 * (s->p.max_iter > 0 ? s->p.max_iter : 1)));  // not inside a timed solve
     return 0;
 }
 
 int sobfu_hip_solver_get_profile(sobfu_hip_solver* s, float* ms_pass_a, float* ms_pass_b, int* launches, int reset) {
     SOBFU_CHECK_ARGS(s);
+    for (int it = 1; it <= s->prof_pending; ++it) {  // events of the last profiled solve (already synchronised)
+        float a = 0, b = 0;
+        SOBFU_HIP_TRY(hipEventElapsedTime(&a, s->events[3 * (it - 1)], s->events[3 * (it - 1) + 1]));
+        SOBFU_HIP_TRY(hipEventElapsedTime(&b, s->events[3 * (it - 1) + 1], s->events[3 * (it - 1) + 2]));
+        s->ms_a += a;
+        s->ms_b += b;
+        s->prof_launches += 1;
+    }
+    s->prof_pending = 0;
     if (ms_pass_a) *ms_pass_a = (float) s->ms_a;
     if (ms_pass_b) *ms_pass_b = (float) s->ms_b;
     if (launches) *launches = s->prof_launches;

@@ -89,6 +89,49 @@ __global__ void __launch_bounds__(256) update_psi_kernel(float4* __restrict__ ps
 
 constexpr int TX = 64;  // tile width = one wave of consecutive x
 
+// --- storage formats ------------------------------------------------------------------------------------------------
+// API format (COMPACT = false): the reference's layouts -- psi / nabla_U float4 (w == 0), TSDF volumes float2.
+// Compact format (COMPACT = true), private to the solver handle while it iterates: psi / nabla_U as packed 12-byte
+// xyz triples (the w lane is a constant 0 that would cost 25 % of their traffic) and tsdf-only 4-byte copies of
+// phi_global, phi_n and phi_n o psi (the weight lane is not read by the iteration; it is rebuilt once after the
+// loop).  Same arithmetic on the same values => bit-identical results, 76 instead of 112 bytes per voxel-iteration.
+struct P3 {  // 12-byte element of the compact fields (only used for pointer arithmetic / sizeof)
+    float x, y, z;
+};
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef v3f __attribute__((aligned(4))) v3f_u;  // 12-byte access, 4-byte aligned -> global_load/store_dwordx3
+template <bool C>
+SOBFU_DEV float4 ldv(const void* base, size_t i) {
+    if (C) {
+        v3f v = *(const v3f_u*) ((const float*) base + 3 * i);
+        return make_float4(v.x, v.y, v.z, 0.f);
+    }
+    return ((const float4*) base)[i];
+}
+template <bool C>
+SOBFU_DEV void stv(void* base, size_t i, const float4& v) {
+    if (C) {
+        v3f o = {v.x, v.y, v.z};
+        *(v3f_u*) ((float*) base + 3 * i) = o;
+    } else {
+        ((float4*) base)[i] = v;
+    }
+}
+template <bool C>
+SOBFU_DEV float ldt(const void* base, size_t i) {  // tsdf of voxel i
+    return C ? ((const float*) base)[i] : ((const float2*) base)[i].x;
+}
+// interpolate_tsdf on a tsdf-only volume (utils.hpp:50-86 without the weight fetch)
+SOBFU_DEV float interp_tsdf_only(const float* __restrict__ v, const Dims& d, float px, float py, float pz) {
+    Tri a = tri_setup(px, d.x), b = tri_setup(py, d.y), c = tri_setup(pz, d.z);
+    const size_t sy = (size_t) d.x, sz = (size_t) d.x * d.y;
+    const float* pg = v + (size_t) b.g * sy + (size_t) c.g * sz;
+    const size_t dy = (size_t) (b.h - b.g) * sy, dz = (size_t) (c.h - c.g) * sz;
+    float hhh = pg[a.h + dy + dz], hhg = pg[a.h + dy], hgh = pg[a.h + dz], hgg = pg[a.h];
+    float ghh = pg[a.g + dy + dz], ghg = pg[a.g + dy], ggh = pg[a.g + dz], ggg = pg[a.g];
+    return lerp1(lerp1(lerp1(hhh, hhg, c.t), lerp1(hgh, hgg, c.t), b.t), lerp1(lerp1(ghh, ghg, c.t), lerp1(ggh, ggg, c.t), b.t), a.t);
+}
+
 // --- workgroup -> tile map ---------------------------------------------------------------------------------------
 // Linear workgroup id -> (x tile fastest, then y, then z-chunk).  With SOBFU_XCD_SWIZZLE the id is first remapped so
 // that each XCD (workgroup b runs on XCD b % 8 -- observed, used for speed only) owns a contiguous run of tiles and
@@ -132,10 +175,10 @@ SOBFU_DEV bool solver_converged(const uint32_t* __restrict__ prev_slots, float m
 
 // --- pass A ----------------------------------------------------------------------------------------------------
 struct PassAArgs {
-    const float2* pnp;  // phi_n o psi
-    const float2* pg;   // phi_global
-    const float4* psi;
-    float4* nU;
+    const void* pnp;  // phi_n o psi
+    const void* pg;   // phi_global
+    const void* psi;
+    void* nU;
     Dims d;
     float w_reg;
     int zc;  // slices per workgroup
@@ -143,7 +186,7 @@ struct PassAArgs {
     float max_update_norm;
 };
 
-template <int RPT, int WY>
+template <int RPT, int WY, bool COMPACT>
 __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
     constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
     constexpr int NXH = (2 * TY + 63) / 64;  // wave-tasks for the two x-halo columns
@@ -198,16 +241,16 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
         const size_t zm = (size_t) max(zb - 1, 0) * plane, zc0 = (size_t) zb * plane;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            pm[r] = a.psi[zm + off[r]];
-            fm[r] = a.pnp[zm + off[r]].x;
-            pc[r] = a.psi[zc0 + off[r]];
-            fc[r] = a.pnp[zc0 + off[r]].x;
+            pm[r] = ldv<COMPACT>(a.psi, zm + off[r]);
+            fm[r] = ldt<COMPACT>(a.pnp, zm + off[r]);
+            pc[r] = ldv<COMPACT>(a.psi, zc0 + off[r]);
+            fc[r] = ldt<COMPACT>(a.pnp, zc0 + off[r]);
         }
 #pragma unroll
         for (int k = 0; k < TPW; ++k)
             if (h_on[k]) {
-                hp[k] = a.psi[zc0 + h_off[k]];
-                hf[k] = a.pnp[zc0 + h_off[k]].x;
+                hp[k] = ldv<COMPACT>(a.psi, zc0 + h_off[k]);
+                hf[k] = ldt<COMPACT>(a.pnp, zc0 + h_off[k]);
             }
     }
 
@@ -223,19 +266,19 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
             if (h_on[k]) t_psi[buf][h_lr[k]][h_lc[k]] = make_float4(hp[k].x, hp[k].y, hp[k].z, hf[k]);
         // prefetch plane z+1 (main) and the halo of plane z+1
         const size_t zn = (size_t) min(z + 1, d.z - 1) * plane, zcur = (size_t) z * plane;
-        float2 bg[RPT];
+        float bg[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            pn[r] = a.psi[zn + off[r]];
-            fn[r] = a.pnp[zn + off[r]].x;
-            bg[r] = a.pg[zcur + off[r]];
+            pn[r] = ldv<COMPACT>(a.psi, zn + off[r]);
+            fn[r] = ldt<COMPACT>(a.pnp, zn + off[r]);
+            bg[r] = ldt<COMPACT>(a.pg, zcur + off[r]);
         }
         if (z + 1 < ze) {
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
                 if (h_on[k]) {
-                    hp[k] = a.psi[zn + h_off[k]];
-                    hf[k] = a.pnp[zn + h_off[k]].x;
+                    hp[k] = ldv<COMPACT>(a.psi, zn + h_off[k]);
+                    hf[k] = ldt<COMPACT>(a.pnp, zn + h_off[k]);
                 }
         }
         __syncthreads();
@@ -277,9 +320,9 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
             v = add4(v, pzm);
             float4 L = mul4(v, -1.f);
             // calculate_potential_gradient_kernel (solver.cu:28-31)
-            float diff = fc[r] - bg[r].x;
+            float diff = fc[r] - bg[r];
             float4 o   = add4(mul4(g, diff), mul4(L, a.w_reg));
-            if (x < d.x && y < d.y) a.nU[zcur + (size_t) x + (size_t) d.x * y] = o;
+            if (x < d.x && y < d.y) stv<COMPACT>(a.nU, zcur + (size_t) x + (size_t) d.x * y, o);
         }
         // shift the z pipeline
 #pragma unroll
@@ -294,11 +337,11 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 
 // --- pass B ----------------------------------------------------------------------------------------------------
 struct PassBArgs {
-    const float4* nU;
-    float4* psi;
-    const float2* phi_n;
-    float2* pnp;      // phi_n o psi (output)
-    float4* updates;  // may be null
+    const void* nU;
+    void* psi;
+    const void* phi_n;
+    void* pnp;        // phi_n o psi (output)
+    float4* updates;  // may be null (always float4)
     uint32_t* slots;  // 256 x uint32, atomic max of ||u||^2 bit patterns
     Dims d;
     Taps S;
@@ -312,7 +355,7 @@ struct PassBArgs {
     int own_lo, own_hi;
 };
 
-template <int RPT, int WY, bool WRITE_UPDATES>
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT>
 __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassBArgs a) {
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
     constexpr int NXH = (2 * R * TY + 63) / 64;  // wave-tasks for the 2R x-halo columns
@@ -364,11 +407,11 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
     for (int k = 0; k < 7; ++k) {
         const size_t zo = (size_t) min(max(zb - 3 + k, 0), d.z - 1) * plane;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) q[r][k] = a.nU[zo + off[r]];
+        for (int r = 0; r < RPT; ++r) q[r][k] = ldv<COMPACT>(a.nU, zo + off[r]);
     }
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
-        if (h_on[k]) hq[k] = a.nU[(size_t) zb * plane + h_off[k]];
+        if (h_on[k]) hq[k] = ldv<COMPACT>(a.nU, (size_t) zb * plane + h_off[k]);
 
     float msq = 0.f;
     for (int z = zb; z < ze; ++z) {
@@ -382,14 +425,14 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
         const size_t zcur = (size_t) z * plane;
         float4 pv[RPT], nq[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) pv[r] = a.psi[zcur + off[r]];
+        for (int r = 0; r < RPT; ++r) pv[r] = ldv<COMPACT>(a.psi, zcur + off[r]);
         if (z + 1 < ze) {
             const size_t z4 = (size_t) min(z + 4, d.z - 1) * plane, z1 = (size_t) (z + 1) * plane;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) nq[r] = a.nU[z4 + off[r]];
+            for (int r = 0; r < RPT; ++r) nq[r] = ldv<COMPACT>(a.nU, z4 + off[r]);
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) hq[k] = a.nU[z1 + h_off[k]];
+                if (h_on[k]) hq[k] = ldv<COMPACT>(a.nU, z1 + h_off[k]);
         }
         __syncthreads();
 
@@ -434,15 +477,22 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
             if (x < d.x && y < d.y) {
                 if (z >= a.own_lo && z < a.own_hi) msq = fmaxf(msq, norm_sq4(u));
                 const size_t i = zcur + (size_t) x + (size_t) d.x * y;
-                a.psi[i] = p;
+                stv<COMPACT>(a.psi, i, p);
                 if (WRITE_UPDATES) a.updates[i] = u;
-                a.pnp[i] = interp_tsdf(a.phi_n, a.pd, p.x, p.y, p.z);  // apply_kernel (vector_fields.cu:95-98)
+                // apply_kernel (vector_fields.cu:95-98)
+                if (COMPACT) ((float*) a.pnp)[i] = interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
+                else ((float2*) a.pnp)[i] = interp_tsdf((const float2*) a.phi_n, a.pd, p.x, p.y, p.z);
             }
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) q[r][k] = q[r][k + 1];
+            for (int k = 0; k < 6; ++k) {
+                q[r][k] = q[r][k + 1];
+                // keep the shift as plain register moves (hipcc otherwise SLP-vectorises the 7-deep shift of the compact
+                // variant into a <7 x float> shuffle that it lowers through 64 B of scratch per lane)
+                asm volatile("" : "+v"(q[r][k].x), "+v"(q[r][k].y), "+v"(q[r][k].z));
+            }
             q[r][6] = nq[r];
         }
     }
@@ -460,6 +510,32 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
     }
 }
 
+// --- compact-format conversions (once per solve, not per iteration) ----------------------------------------------
+__global__ void __launch_bounds__(256) pack_vec_kernel(const float4* __restrict__ src, P3* __restrict__ dst, size_t N) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    stv<true>(dst, i, src[i]);
+}
+// writes xyz back into the API float4 field; w is left untouched, as update_psi_kernel leaves it (utils.hpp:260-265)
+__global__ void __launch_bounds__(256) unpack_vec_kernel(const P3* __restrict__ src, float4* __restrict__ dst, size_t N) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 v = ldv<true>(src, i);
+    *(v3f_u*) ((float*) (dst + i)) = v3f{v.x, v.y, v.z};
+}
+__global__ void __launch_bounds__(256) extract_tsdf_kernel(const float2* __restrict__ src, float* __restrict__ dst, size_t N) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) dst[i] = src[i].x;
+}
+__global__ void __launch_bounds__(256) apply_tsdf_only_kernel(const float* __restrict__ phi, float* __restrict__ out,
+                                                              const P3* __restrict__ psi, Dims d) {
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z;
+    if (x >= d.x || y >= d.y) return;
+    size_t i = vidx(d, x, y, z);
+    float4 p = ldv<true>(psi, i);
+    out[i]   = interp_tsdf_only(phi, d, p.x, p.y, p.z);
+}
+
 }  // namespace
 
 // Tile configuration of the fused passes (see DESIGN.md "Kernel tuning").
@@ -472,43 +548,66 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
 
 namespace sobfu_hip {
 
-int pick_zc(int X, int Y, int Z, int ty) {
-    if (const char* e = getenv("SOBFU_ZC")) {  // tuning override
+int pick_zc(int X, int Y, int Z, int ty, int min_groups, const char* env) {
+    if (const char* e = getenv(env)) {  // tuning override
         int v = atoi(e);
         if (v > 0) return v < Z ? v : Z;
     }
     // enough workgroups to fill 256 CUs a few times over, but long z marches (less pipeline refill)
     const long tiles = (long) ((X + TX - 1) / TX) * ((Y + ty - 1) / ty);
     int zc = Z;
-    while (zc > 8 && tiles * ((Z + zc - 1) / zc) < 512) zc = (zc + 1) / 2;
+    while (zc > 8 && tiles * ((Z + zc - 1) / zc) < min_groups) zc = (zc + 1) / 2;
     return zc;
 }
 
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
-                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream) {
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    if (zc <= 0) zc = pick_zc(X, Y, Z, TY);
-    PassAArgs a{(const float2*) pnp, (const float2*) pg, (const float4*) psi, (float4*) nU, {X, Y, Z}, w_reg, zc, prev_slots, max_update_norm};
+    if (zc <= 0) zc = pick_zc(X, Y, Z, TY, 1024, "SOBFU_ZC_A");  // pass A: short 3-plane pipeline, more groups win
+    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, prev_slots, max_update_norm};
     dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + zc - 1) / zc));
-    hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
+    if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
+    else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
     return (int) hipGetLastError();
 }
 
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi) {
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact) {
     if (phi_Z <= 0) { phi_Z = Z; own_lo = 0; own_hi = Z; }
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    if (zc <= 0) zc = pick_zc(X, Y, Z, TY);
-    PassBArgs a{(const float4*) nU, (float4*) psi, (const float2*) phi_n, (float2*) pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
+    if (zc <= 0) zc = pick_zc(X, Y, Z, TY, 512, "SOBFU_ZC_B");   // pass B: 7-plane pipeline refill favours long marches
+    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + zc - 1) / zc));
-    if (updates)
-        hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
-    else
-        hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
+#define SOBFU_LAUNCH_B(UPD, CMP) \
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP>), grid, dim3(TX, SOBFU_WY), 0, stream, a)
+    if (updates && compact) SOBFU_LAUNCH_B(true, true);
+    else if (updates) SOBFU_LAUNCH_B(true, false);
+    else if (compact) SOBFU_LAUNCH_B(false, true);
+    else SOBFU_LAUNCH_B(false, false);
+#undef SOBFU_LAUNCH_B
     return (int) hipGetLastError();
 }
+
+#define SOBFU_LIN(N) dim3((unsigned) (((N) + 255) / 256)), dim3(256), 0, stream
+int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_vec_kernel, SOBFU_LIN(N), (const float4*) src4, (P3*) dst3, N);
+    return (int) hipGetLastError();
+}
+int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream) {
+    hipLaunchKernelGGL(unpack_vec_kernel, SOBFU_LIN(N), (const P3*) src3, (float4*) dst4, N);
+    return (int) hipGetLastError();
+}
+int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream) {
+    hipLaunchKernelGGL(extract_tsdf_kernel, SOBFU_LIN(N), (const float2*) src2, dst1, N);
+    return (int) hipGetLastError();
+}
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream) {
+    hipLaunchKernelGGL(apply_tsdf_only_kernel, voxel_grid(X, Y, Z), voxel_block(), 0, stream, phi1, out1, (const P3*) psi3, Dims{X, Y, Z});
+    return (int) hipGetLastError();
+}
+#undef SOBFU_LIN
 
 }  // namespace sobfu_hip
 
@@ -549,7 +648,7 @@ int sobfu_hip_fused_potential_gradient(const float* d_phi_n_psi, const float* d_
                                        float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Z > 1);
     if ((size_t) X * Y * Z > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
-    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Z, nullptr, 0.f, 0, (hipStream_t) stream);
+    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Z, nullptr, 0.f, 0, (hipStream_t) stream, false);
 }
 
 int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
@@ -558,7 +657,7 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
     SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Z > 0);
     if ((size_t) X * Y * Z > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Z,
-                                    nullptr, 0.f, 0, (hipStream_t) stream, 0, 0, 0);
+                                    nullptr, 0.f, 0, (hipStream_t) stream, 0, 0, 0, false);
 }
 
 int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
@@ -567,7 +666,7 @@ int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_p
     SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Lz > 1);
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Lz, d_prev_slots, max_update_norm, 0,
-                                    (hipStream_t) stream);
+                                    (hipStream_t) stream, false);
 }
 
 int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
@@ -578,7 +677,7 @@ int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, con
                      z_own_lo >= 0 && z_own_lo <= z_own_hi && z_own_hi <= Lz);
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff || (size_t) X * Y * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Lz,
-                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi);
+                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, false);
 }
 
 }  // extern "C"

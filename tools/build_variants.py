@@ -7,11 +7,11 @@ os.makedirs(out, exist_ok=True)
 for spec in sys.argv[1:]:
     parts = spec.split("x")
     rpt, wy = int(parts[0]), int(parts[1])
-    extra = [f"-D{d}" for d in parts[2:]]  # e.g. 1x8xSOBFU_XCD_SWIZZLE=1
+    extra = [(d if d.startswith("-") else f"-D{d}") for d in parts[2:]]  # e.g. 1x8xSOBFU_XCD_SWIZZLE=1 or 1x8x-fno-slp-vectorize
     objs = []
     for src in build.SOURCES:
         o = os.path.join(out, f"{src[:-4]}_{spec}.o")
-        flags = build.FLAGS + ([f"-DSOBFU_RPT={rpt}", f"-DSOBFU_WY={wy}", *extra] if src == "solver_kernels.hip" else [])
+        flags = build.FLAGS + build.PER_FILE_FLAGS.get(src, []) + ([f"-DSOBFU_RPT={rpt}", f"-DSOBFU_WY={wy}", *extra] if src == "solver_kernels.hip" else [])
         if src != "solver_kernels.hip":
             o = os.path.join(build.HERE, "build", src.replace(".hip", ".o"))
         else:

@@ -9,13 +9,11 @@ pg, pn, pnp = ops.new_volume(dims), ops.new_volume(dims), ops.new_volume(dims)
 ops.init_sphere(pg, P["vs"], P["trunc"], P["eta"], c0, r); ops.init_sphere(pn, P["vs"], P["trunc"], P["eta"], c1, r)
 psi = ops.new_field(dims); ops.init_identity(psi)
 for thr in (1e-10, -1.0):
-    sv = ops.Solver(dims, max_iter=100, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=thr)
-    sv.iterate(pg, pn, pnp, psi, 5)
-    for prof in (False, True):
-        sv.set_profiling(prof)
-        for n in (50, 100):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            sv.iterate(pg, pn, pnp, psi, n)
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            print(f"thr={thr} prof={prof} n={n}: {1e6*dt/n:.1f} us/iter", sv.get_profile())
+    sv = ops.Solver(dims, max_iter=400, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=thr)
+    sv.iterate(pg, pn, pnp, psi, 50)
+    for n in (1, 10, 30, 100, 300, 30, 10):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sv.iterate(pg, pn, pnp, psi, n)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"thr={thr} n={n}: total {1e3*dt:.2f} ms  = {1e6*dt/n:.1f} us/iter")
     sv.close()
