@@ -164,13 +164,22 @@ int sobfu_hip_tile_apply(const float* d_phi, int Zg, float* d_phi_warped, const 
                          void* stream);
 int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv, int X, int Y, int Lz, int zbase,
                                     int n_sweeps, void* stream);
+/* compact != 0: the field arguments are in the compact iteration format -- psi / nabla_U 12-byte xyz triples, phi_n o
+ * psi / phi_global / phi_n tsdf-only floats (built with the conversion entry points below). */
 int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
                                       float* d_nabla_U, float w_reg, int X, int Y, int Lz, const uint32_t* d_prev_slots,
-                                      float max_update_norm, void* stream);
+                                      float max_update_norm, int compact, void* stream);
 int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
                                        float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha,
                                        int X, int Y, int Lz, int Zg, int z_own_lo, int z_own_hi,
-                                       const uint32_t* d_prev_slots, float max_update_norm, void* stream);
+                                       const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
+/* Compact-format conversions (n = number of voxels): float4 <-> packed xyz (unpack leaves .w untouched), float2
+ * {tsdf, weight} -> tsdf, and the tsdf-only warp of a slab (phi: whole (X, Y, Zg) tsdf-only volume). */
+int sobfu_hip_pack_vec3(const float* d_src4, float* d_dst3, size_t n, void* stream);
+int sobfu_hip_unpack_vec3(const float* d_src3, float* d_dst4, size_t n, void* stream);
+int sobfu_hip_extract_tsdf(const float* d_src2, float* d_dst1, size_t n, void* stream);
+int sobfu_hip_tile_apply_tsdf_only(const float* d_phi1, int Zg, float* d_out1, const float* d_psi3, int X, int Y, int Lz,
+                                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * solver handle  (sobfu::cuda::Solver, include/sobfu/solver.hpp:52-101, src/sobfu/solver.cpp:7-101)

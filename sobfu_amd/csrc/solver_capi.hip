@@ -26,7 +26,7 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
 int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
 int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
 int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
-int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream);
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z = 0);
 }  // namespace sobfu_hip
 
 namespace {

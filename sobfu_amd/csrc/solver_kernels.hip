@@ -528,12 +528,12 @@ __global__ void __launch_bounds__(256) extract_tsdf_kernel(const float2* __restr
     if (i < N) dst[i] = src[i].x;
 }
 __global__ void __launch_bounds__(256) apply_tsdf_only_kernel(const float* __restrict__ phi, float* __restrict__ out,
-                                                              const P3* __restrict__ psi, Dims d) {
+                                                              const P3* __restrict__ psi, Dims d, Dims pd) {
     const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z;
     if (x >= d.x || y >= d.y) return;
     size_t i = vidx(d, x, y, z);
     float4 p = ldv<true>(psi, i);
-    out[i]   = interp_tsdf_only(phi, d, p.x, p.y, p.z);
+    out[i]   = interp_tsdf_only(phi, pd, p.x, p.y, p.z);
 }
 
 }  // namespace
@@ -603,8 +603,9 @@ int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t st
     hipLaunchKernelGGL(extract_tsdf_kernel, SOBFU_LIN(N), (const float2*) src2, dst1, N);
     return (int) hipGetLastError();
 }
-int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream) {
-    hipLaunchKernelGGL(apply_tsdf_only_kernel, voxel_grid(X, Y, Z), voxel_block(), 0, stream, phi1, out1, (const P3*) psi3, Dims{X, Y, Z});
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z) {
+    hipLaunchKernelGGL(apply_tsdf_only_kernel, voxel_grid(X, Y, Z), voxel_block(), 0, stream, phi1, out1, (const P3*) psi3, Dims{X, Y, Z},
+                       Dims{X, Y, phi_Z > 0 ? phi_Z : Z});
     return (int) hipGetLastError();
 }
 #undef SOBFU_LIN
@@ -662,22 +663,39 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
 
 int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
                                       float w_reg, int X, int Y, int Lz, const uint32_t* d_prev_slots, float max_update_norm,
-                                      void* stream) {
+                                      int compact, void* stream) {
     SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Lz > 1);
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Lz, d_prev_slots, max_update_norm, 0,
-                                    (hipStream_t) stream, false);
+                                    (hipStream_t) stream, compact != 0);
+}
+
+int sobfu_hip_pack_vec3(const float* d_src4, float* d_dst3, size_t n, void* stream) {
+    SOBFU_CHECK_ARGS(d_src4 && d_dst3 && n > 0);
+    return sobfu_hip::launch_pack_vec(d_src4, d_dst3, n, (hipStream_t) stream);
+}
+int sobfu_hip_unpack_vec3(const float* d_src3, float* d_dst4, size_t n, void* stream) {
+    SOBFU_CHECK_ARGS(d_src3 && d_dst4 && n > 0);
+    return sobfu_hip::launch_unpack_vec(d_src3, d_dst4, n, (hipStream_t) stream);
+}
+int sobfu_hip_extract_tsdf(const float* d_src2, float* d_dst1, size_t n, void* stream) {
+    SOBFU_CHECK_ARGS(d_src2 && d_dst1 && n > 0);
+    return sobfu_hip::launch_extract_tsdf(d_src2, d_dst1, n, (hipStream_t) stream);
+}
+int sobfu_hip_tile_apply_tsdf_only(const float* d_phi1, int Zg, float* d_out1, const float* d_psi3, int X, int Y, int Lz, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi1 && d_out1 && d_psi3 && X > 0 && Y > 0 && Lz > 0 && Zg > 0);
+    return sobfu_hip::launch_apply_tsdf_only(d_phi1, d_out1, d_psi3, X, Y, Lz, (hipStream_t) stream, Zg);
 }
 
 int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
                                        float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha, int X, int Y,
                                        int Lz, int Zg, int z_own_lo, int z_own_hi, const uint32_t* d_prev_slots,
-                                       float max_update_norm, void* stream) {
+                                       float max_update_norm, int compact, void* stream) {
     SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Lz > 0 && Zg >= 1 &&
                      z_own_lo >= 0 && z_own_lo <= z_own_hi && z_own_hi <= Lz);
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff || (size_t) X * Y * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Lz,
-                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, false);
+                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, compact != 0);
 }
 
 }  // extern "C"

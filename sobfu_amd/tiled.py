@@ -4,18 +4,19 @@ SURVEY.md section 8(e).  Frames of a sequence are sequentially dependent (psi pe
 VOLUME TILE.  Slabs along z (z is the slowest-varying axis of the layout) make every halo a contiguous block of
 planes: halo exchange is zero-copy `isend/irecv` straight out of / into the field arrays -- no pack kernels.
 
-Per rank:  psi, phi_n o psi, phi_global, nabla_U are LOCAL slabs (X, Y, Lz) = owned planes + HALO (=3) planes towards
+Per rank:  psi, phi_n o psi, phi_global, nabla_U are LOCAL slabs (X, Y, Lz) = owned planes + HALO (=4) planes towards
 each neighbour; phi_n is replicated (the warp gathers at absolute coordinates anywhere in the volume).
 
-One iteration (Option A of the survey: two face-only exchanges, every halo value is computed by its owner):
-    E1  exchange psi, phi_n o psi   (radius 1)          -> pass A needs +-1 neighbours
-    A   nabla_U  on the whole slab
-    E2  exchange nabla_U            (radius 3)          -> pass B needs +-3 neighbours
-    B   psi -= alpha * (Sx+Sy+Sz) nabla_U, phi_n o psi, max ||u||^2 over OWNED planes
+One iteration = ONE exchange (Option B of the survey, which in a 1-D decomposition needs no edge data):
+    A   nabla_U on the whole slab            exact on the OWNED planes (reads psi, phi_n o psi at owned +-1)
+    E   exchange nabla_U (4 planes / face)    -> nabla_U exact on owned +-4
+    B   psi -= alpha * (Sx+Sy+Sz) nabla_U, phi_n o psi on the whole slab: the radius-3 convolution is exact on
+        owned +-1, so psi and phi_n o psi stay exact on owned +-1 -- what the next pass A needs -- without ever being
+        exchanged (invariant; identity psi satisfies it at the start);  max ||u||^2 over OWNED planes only
     R   all_reduce(MAX) of the 256 max-norm slots -- only when max_update_norm >= 0 (otherwise the test never fires)
-Kernels run over the whole slab; what they write into halo planes is overwritten by the next exchange.  Clamp /
-mirror rules act at a slab's array edge, which is the volume boundary exactly where the slab has no halo, so the
-result equals the single-GPU run bit for bit (the max is order-independent).
+Values the kernels write further out in the halo are never read.  Clamp / mirror rules act at a slab's array edge,
+which is the volume boundary exactly where the slab has no halo, so the result equals the single-GPU run bit for bit
+(the max is order-independent).
 
 The kernel backend is pluggable: `HipBackend` (product; C ABI on torch CUDA tensors over RCCL) -- the CPU tests inject an
 oracle-backed backend over gloo to check the decomposition logic without a GPU.
@@ -29,7 +30,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HALO = 3
+HALO = 4
 SLOTS = 256
 
 
@@ -82,43 +83,90 @@ def exchange_halos(layout: SlabLayout, fields, group=None):
         r.wait()
 
 
+class _SlabState:
+    """What a backend keeps for one solve: nabla_U (exchanged by the driver) + whatever format it iterates in."""
+
+    def __init__(self, layout, nabla_U):
+        self.layout, self.nabla_U = layout, nabla_U
+
+
 class HipBackend:
-    """Per-slab kernels through the C ABI (include/sobfu_hip.h `sobfu_hip_tile_*`)."""
+    """Per-slab kernels through the C ABI (include/sobfu_hip.h `sobfu_hip_tile_*`).
 
-    def __init__(self):
-        from . import _lib, ops
-
-        self._lib, self._ops = _lib, ops
+    Iterates in the compact format (12-byte psi / nabla_U, tsdf-only phi_global / phi_n / phi_n o psi -- fewer bytes both
+    through HBM and over xGMI); `begin` converts the caller's API-format slabs, `end` rebuilds them."""
 
     device = "cuda"
+
+    def __init__(self, compact=True):
+        from . import _lib, ops
+
+        self._lib, self._ops, self.compact = _lib, ops, bool(compact)
+        self._cache = {}
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def _call(self, name, *args):
+        self._lib.check(getattr(self._lib.lib(), name)(*args, self._stream()), name)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
     def init_identity(self, psi, layout):
         X, Y, _ = layout.dims
-        self._lib.check(self._lib.lib().sobfu_hip_tile_init_identity(C.c_void_p(psi.data_ptr()), X, Y, layout.Lz, layout.zbase,
-                                                                     self._stream()), "tile_init_identity")
+        self._call("sobfu_hip_tile_init_identity", self._p(psi), X, Y, layout.Lz, layout.zbase)
 
-    def apply(self, phi_full, out, psi, layout):
+    def _buf(self, key, shape):
+        t = self._cache.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32, device="cuda")
+            self._cache[key] = t
+        return t
+
+    def begin(self, layout, pg_local, pn_full, pnp_local, psi_local):
         X, Y, Z = layout.dims
-        self._lib.check(self._lib.lib().sobfu_hip_tile_apply(C.c_void_p(phi_full.data_ptr()), Z, C.c_void_p(out.data_ptr()),
-                                                             C.c_void_p(psi.data_ptr()), X, Y, layout.Lz, self._stream()), "tile_apply")
+        Lz = layout.Lz
+        st = _SlabState(layout, None)
+        st.pn_full, st.pnp, st.psi = pn_full, pnp_local, psi_local
+        if not self.compact:
+            st.nabla_U = self._buf("nU4", (Lz, Y, X, 4))
+            st.c_psi, st.c_f, st.c_g, st.c_n = psi_local, pnp_local, pg_local, pn_full
+            self._call("sobfu_hip_tile_apply", self._p(pn_full), Z, self._p(pnp_local), self._p(psi_local), X, Y, Lz)
+            return st
+        st.nabla_U = self._buf("nU3", (Lz, Y, X, 3))
+        st.c_psi, st.c_f, st.c_g = self._buf("psi3", (Lz, Y, X, 3)), self._buf("f", (Lz, Y, X)), self._buf("g", (Lz, Y, X))
+        st.c_n = self._buf("n", (Z, Y, X))
+        nl, nf = C.c_size_t(Lz * Y * X), C.c_size_t(Z * Y * X)
+        self._call("sobfu_hip_pack_vec3", self._p(psi_local), self._p(st.c_psi), nl)
+        self._call("sobfu_hip_extract_tsdf", self._p(pg_local), self._p(st.c_g), nl)
+        self._call("sobfu_hip_extract_tsdf", self._p(pn_full), self._p(st.c_n), nf)
+        self._call("sobfu_hip_tile_apply_tsdf_only", self._p(st.c_n), Z, self._p(st.c_f), self._p(st.c_psi), X, Y, Lz)  # solver.cu:106
+        return st
 
-    def pass_a(self, pnp, pg, psi, nU, w_reg, prev_slots, thr, layout):
-        X, Y, _ = layout.dims
-        prev = C.c_void_p(prev_slots.data_ptr()) if prev_slots is not None else None
-        self._lib.check(self._lib.lib().sobfu_hip_tile_potential_gradient(
-            C.c_void_p(pnp.data_ptr()), C.c_void_p(pg.data_ptr()), C.c_void_p(psi.data_ptr()), C.c_void_p(nU.data_ptr()),
-            C.c_float(w_reg), X, Y, layout.Lz, prev, C.c_float(thr), self._stream()), "tile_potential_gradient")
+    def pass_a(self, st, w_reg, prev_slots, thr):
+        L = st.layout
+        X, Y, _ = L.dims
+        prev = self._p(prev_slots) if prev_slots is not None else None
+        self._call("sobfu_hip_tile_potential_gradient", self._p(st.c_f), self._p(st.c_g), self._p(st.c_psi), self._p(st.nabla_U),
+                   C.c_float(w_reg), X, Y, L.Lz, prev, C.c_float(thr), 1 if self.compact else 0)
 
-    def pass_b(self, nU, psi, phi_n_full, pnp, slots, taps, alpha, prev_slots, thr, layout):
-        X, Y, Z = layout.dims
-        prev = C.c_void_p(prev_slots.data_ptr()) if prev_slots is not None else None
-        self._lib.check(self._lib.lib().sobfu_hip_tile_smooth_update_apply(
-            C.c_void_p(nU.data_ptr()), C.c_void_p(psi.data_ptr()), C.c_void_p(phi_n_full.data_ptr()), C.c_void_p(pnp.data_ptr()), None,
-            C.c_void_p(slots.data_ptr()), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), X, Y, layout.Lz, Z,
-            layout.own_lo, layout.own_hi, prev, C.c_float(thr), self._stream()), "tile_smooth_update_apply")
+    def pass_b(self, st, slots, taps, alpha, prev_slots, thr):
+        L = st.layout
+        X, Y, Z = L.dims
+        prev = self._p(prev_slots) if prev_slots is not None else None
+        self._call("sobfu_hip_tile_smooth_update_apply", self._p(st.nabla_U), self._p(st.c_psi), self._p(st.c_n), self._p(st.c_f), None,
+                   self._p(slots), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), X, Y, L.Lz, Z, L.own_lo, L.own_hi,
+                   prev, C.c_float(thr), 1 if self.compact else 0)
+
+    def end(self, st):
+        if not self.compact:
+            return
+        L = st.layout
+        X, Y, Z = L.dims
+        self._call("sobfu_hip_unpack_vec3", self._p(st.c_psi), self._p(st.psi), C.c_size_t(L.Lz * Y * X))
+        self._call("sobfu_hip_tile_apply", self._p(st.pn_full), Z, self._p(st.pnp), self._p(st.psi), X, Y, L.Lz)  # state of solver.cu:168
 
     def sobolev_filter(self, s, lam):
         return self._ops.sobolev_filter(s, lam)
@@ -148,8 +196,6 @@ class TiledSolver:
         if s < 7:
             raise ValueError("S < 7 is unsupported (the kernels use 7 taps, reference solver.cu:211-234)")
         self.taps = np.asarray(self.backend.sobolev_filter(s, lam), np.float32)[:7]
-        dev = self.backend.device
-        self.nabla_U = torch.zeros(self.layout.local_shape(4), dtype=torch.float32, device=dev)
         self.slots = None
 
     # -- state helpers ------------------------------------------------------------------------------------------
@@ -165,21 +211,20 @@ class TiledSolver:
         """Runs n_iters iterations (fewer if the convergence test fires).  Returns (iterations, per-iteration max norms)."""
         L, be = self.layout, self.backend
         can_converge = self.thr >= 0.0
-        be.apply(phi_n_full, phi_n_psi_local, psi_local, L)  # solver.cu:106
+        st = be.begin(L, phi_global_local, phi_n_full, phi_n_psi_local, psi_local)  # includes the warp of solver.cu:106
         slots = torch.zeros((n_iters + 1, SLOTS), dtype=torch.int32, device=be.device)
         self.slots = slots
         for it in range(1, n_iters + 1):
             prev = slots[it - 1] if (it > 1 and can_converge) else None
+            be.pass_a(st, self.w_reg, prev, self.thr)
             if self.world > 1:
-                exchange_halos(L, [(psi_local, 1), (phi_n_psi_local, 1)], self.group)
-            be.pass_a(phi_n_psi_local, phi_global_local, psi_local, self.nabla_U, self.w_reg, prev, self.thr, L)
-            if self.world > 1:
-                exchange_halos(L, [(self.nabla_U, 3)], self.group)
-            be.pass_b(self.nabla_U, psi_local, phi_n_full, phi_n_psi_local, slots[it], self.taps, self.alpha, prev, self.thr, L)
+                exchange_halos(L, [(st.nabla_U, HALO)], self.group)
+            be.pass_b(st, slots[it], self.taps, self.alpha, prev, self.thr)
             if self.world > 1 and can_converge:
                 dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
         if self.world > 1 and not can_converge:
             dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=self.group)
+        be.end(st)
         be.synchronize()
         mx = slots[1:].max(dim=1).values.cpu().numpy().view(np.uint32)
         norms = np.array([_sqrt_rd(int(b)) for b in mx], np.float32)
@@ -230,5 +275,5 @@ def bench_tiled(P, steps, warmup, rank, world):
     dist.barrier()
     dt = time.perf_counter() - t0
     assert done == steps and np.isfinite(norms).all() and float(norms.max()) > 0
-    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=int(solver.nabla_U.numel() * 4),
+    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None,
                 parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange")

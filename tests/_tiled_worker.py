@@ -19,7 +19,13 @@ DIMS = (20, 12, 24)
 ITERS = 6
 
 
+class _State:
+    pass
+
+
 class OracleBackend:
+    """begin / pass_a / pass_b / end protocol of sobfu_amd.tiled backends, on numpy views of CPU tensors (API format)."""
+
     device = "cpu"
 
     def init_identity(self, psi, layout):
@@ -27,8 +33,12 @@ class OracleBackend:
         O.init_identity(a)
         a[..., 2] += np.float32(layout.zbase)
 
-    def apply(self, phi_full, out, psi, layout):
-        O.apply_tile(phi_full.numpy(), out.numpy(), psi.numpy())
+    def begin(self, layout, pg, pn_full, pnp, psi):
+        st = _State()
+        st.layout, st.pg, st.pn, st.pnp, st.psi = layout, pg.numpy(), pn_full.numpy(), pnp.numpy(), psi.numpy()
+        st.nabla_U = torch.zeros(layout.local_shape(4), dtype=torch.float32)
+        O.apply_tile(st.pn, st.pnp, st.psi)
+        return st
 
     @staticmethod
     def _gate(prev, thr):
@@ -36,29 +46,35 @@ class OracleBackend:
             return False
         return tiled._sqrt_rd(int(prev.numpy().view(np.uint32).max())) <= thr
 
-    def pass_a(self, pnp, pg, psi, nU, w_reg, prev, thr, layout):
+    def pass_a(self, st, w_reg, prev, thr):
         if self._gate(prev, thr):
             return
-        dims = (layout.dims[0], layout.dims[1], layout.Lz)
-        g, L = O.new_field(dims), O.new_field(dims)
-        O.tsdf_gradient(pnp.numpy(), g)
-        O.laplacian(psi.numpy(), L)
-        O.potential_gradient(pnp.numpy(), pg.numpy(), g, L, nU.numpy(), w_reg)
+        L = st.layout
+        dims = (L.dims[0], L.dims[1], L.Lz)
+        g, Lap = O.new_field(dims), O.new_field(dims)
+        O.tsdf_gradient(st.pnp, g)
+        O.laplacian(st.psi, Lap)
+        O.potential_gradient(st.pnp, st.pg, g, Lap, st.nabla_U.numpy(), w_reg)
 
-    def pass_b(self, nU, psi, phi_n_full, pnp, slots, taps, alpha, prev, thr, layout):
+    def pass_b(self, st, slots, taps, alpha, prev, thr):
         if self._gate(prev, thr):
             return
-        dims = (layout.dims[0], layout.dims[1], layout.Lz)
+        L = st.layout
+        dims = (L.dims[0], L.dims[1], L.Lz)
+        nU = st.nabla_U.numpy()
         nUS, upd = O.new_field(dims), O.new_field(dims)
-        O.convolution_rows(nUS, nU.numpy(), taps)
-        O.convolution_columns(nUS, nU.numpy(), taps)
-        O.convolution_depth(nUS, nU.numpy(), taps)
-        O.update_psi(psi.numpy(), nUS, upd, alpha)
-        O.apply_tile(phi_n_full.numpy(), pnp.numpy(), psi.numpy())
-        u = upd[layout.own_lo:layout.own_hi]
+        O.convolution_rows(nUS, nU, taps)
+        O.convolution_columns(nUS, nU, taps)
+        O.convolution_depth(nUS, nU, taps)
+        O.update_psi(st.psi, nUS, upd, alpha)
+        O.apply_tile(st.pn, st.pnp, st.psi)
+        u = upd[L.own_lo:L.own_hi]
         sq = (u[..., 0] * u[..., 0] + u[..., 1] * u[..., 1]) + u[..., 2] * u[..., 2]
         s = slots.numpy().view(np.uint32)
         s[0] = max(s[0], np.float32(sq.max()).view(np.uint32))
+
+    def end(self, st):
+        pass
 
     def sobolev_filter(self, s, lam):
         return O.sobolev_filter(s, lam)

@@ -422,8 +422,11 @@ def test_full_size_256_fused_equals_launchers_and_properties(ops, oracle):
 # ---------------------------------------------------------------------------------------------------
 # multi-GPU slab kernels (sobfu_hip_tile_*) on one GPU: slabs with exchanged halos == full volume
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_tile_kernels_match_full_volume(ops, oracle, world):
+def test_tile_kernels_match_full_volume(ops, oracle, world, compact):
+    """One iteration on every slab of a 2- / 3-way cut, with the single nabla_U exchange emulated by slicing the
+    full-volume result: owned +-1 planes of psi / phi_n o psi and the owned max must equal the full-volume kernels."""
     from sobfu_amd import tiled
 
     dims = (70, 24, 36)
@@ -432,35 +435,34 @@ def test_tile_kernels_match_full_volume(ops, oracle, world):
     psi0 = warped_identity(oracle, dims, 43, 1.2)
     S = oracle.sobolev_filter(7, 0.1)
     w_reg, alpha = 0.6, 0.1
-    be = tiled.HipBackend()
-    # full-volume reference on the GPU (itself bit-exact vs the oracle, tests above)
+    be = tiled.HipBackend(compact=compact)
     psi_f, pnp_f, nU_f = dev(psi0), ops.new_volume(dims), ops.new_field(dims)
     ops.apply(dev(pn), pnp_f, psi_f)
     ops.fused_potential_gradient(pnp_f, dev(pg), psi_f, nU_f, w_reg)
-    pnp_in = pnp_f.clone()
     m_full = ops.fused_smooth_update_apply(nU_f, psi_f, dev(pn), pnp_f, S, alpha)
     pn_d = dev(pn)
     m_tiles = 0.0
     for r in range(world):
         L = tiled.SlabLayout(dims, world, r)
-        # slabs cut from the full arrays = what the halo exchange delivers
-        psi_l, pnp_l, pg_l = (L.take(t).clone().contiguous() for t in (dev(psi0), pnp_in, dev(pg)))
         idl = torch.zeros(L.local_shape(4), device="cuda")
         be.init_identity(idl, L)
         ident = oracle.new_field(dims)
         oracle.init_identity(ident)
         assert same(host(idl), L.take(ident))
-        out_l = torch.zeros(L.local_shape(2), device="cuda")
-        be.apply(pn_d, out_l, psi_l, L)
-        assert torch.equal(out_l.view(torch.int32), pnp_l.view(torch.int32))
-        nU_l = torch.zeros(L.local_shape(4), device="cuda")
-        be.pass_a(pnp_l, pg_l, psi_l, nU_l, w_reg, None, 0.0, L)
-        # pass A is exact wherever the radius-1 stencil stays inside the slab: owned planes (+2 halo planes)
-        assert torch.equal(L.owned(nU_l).view(torch.int32), nU_f[L.z0:L.z1].view(torch.int32))
-        nU_l = L.take(nU_f).clone().contiguous()  # E2: radius-3 halos from the owners
+        psi_l, pg_l = (L.take(t).clone().contiguous() for t in (dev(psi0), dev(pg)))
+        pnp_l = torch.zeros(L.local_shape(2), device="cuda")
+        st = be.begin(L, pg_l, pn_d, pnp_l, psi_l)
+        be.pass_a(st, w_reg, None, 0.0)
+        nU_own = L.owned(st.nabla_U)[..., :3]
+        assert torch.equal(nU_own.contiguous().view(torch.int32), nU_f[L.z0:L.z1][..., :3].contiguous().view(torch.int32))
+        st.nabla_U[..., :3] = L.take(nU_f)[..., :3]  # the exchange: 4 halo planes of nabla_U from their owners
         slots = torch.zeros(256, dtype=torch.int32, device="cuda")
-        be.pass_b(nU_l, psi_l, pn_d, pnp_l, slots, S, alpha, None, 0.0, L)
-        assert torch.equal(L.owned(psi_l).view(torch.int32), psi_f[L.z0:L.z1].view(torch.int32))
-        assert torch.equal(L.owned(pnp_l).view(torch.int32), pnp_f[L.z0:L.z1].view(torch.int32))
+        be.pass_b(st, slots, S, alpha, None, 0.0)
+        be.end(st)
+        torch.cuda.synchronize()
+        lo, hi = max(L.z0 - 1, 0), min(L.z1 + 1, Z)
+        a, b = lo - L.zbase, hi - L.zbase
+        assert torch.equal(psi_l[a:b].view(torch.int32), psi_f[lo:hi].view(torch.int32))
+        assert torch.equal(pnp_l[a:b].view(torch.int32), pnp_f[lo:hi].view(torch.int32))
         m_tiles = max(m_tiles, tiled._sqrt_rd(int(slots.max().cpu().numpy().view(np.uint32))))
     assert m_tiles == m_full
