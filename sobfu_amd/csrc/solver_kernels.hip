@@ -556,7 +556,7 @@ int pick_zc(int X, int Y, int Z, int ty, int min_groups, const char* env) {
     // enough workgroups to fill 256 CUs a few times over, but long z marches (less pipeline refill)
     const long tiles = (long) ((X + TX - 1) / TX) * ((Y + ty - 1) / ty);
     int zc = Z;
-    while (zc > 8 && tiles * ((Z + zc - 1) / zc) < min_groups) zc = (zc + 1) / 2;
+    while (zc > 2 && tiles * ((Z + zc - 1) / zc) < min_groups) zc = (zc + 1) / 2;  // small grids are latency-bound: many short marches
     return zc;
 }
 

@@ -65,8 +65,8 @@ class SlabLayout:
         return local[self.own_lo:self.own_hi]
 
 
-def exchange_halos(layout: SlabLayout, fields, group=None):
-    """fields: list of (tensor (Lz, ...), radius).  Zero-copy neighbour exchange of `radius` owned planes."""
+def halo_ops(layout: SlabLayout, fields, group=None):
+    """P2P op list of one exchange (built once per solve: the views stay valid while the buffers live)."""
     L = layout
     ops = []
     for t, w in fields:
@@ -77,10 +77,18 @@ def exchange_halos(layout: SlabLayout, fields, group=None):
         if L.rank < L.world - 1:
             ops.append(dist.P2POp(dist.isend, t[L.own_hi - w:L.own_hi], L.rank + 1, group))
             ops.append(dist.P2POp(dist.irecv, t[L.own_hi:L.own_hi + w], L.rank + 1, group))
-    if not ops:
-        return
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
+    return ops
+
+
+def run_halo_ops(ops):
+    if ops:
+        for r in dist.batch_isend_irecv(ops):  # one grouped RCCL launch; wait() only orders the current stream after it
+            r.wait()
+
+
+def exchange_halos(layout: SlabLayout, fields, group=None):
+    """fields: list of (tensor (Lz, ...), radius).  Zero-copy neighbour exchange of `radius` owned planes."""
+    run_halo_ops(halo_ops(layout, fields, group))
 
 
 class _SlabState:
@@ -214,11 +222,12 @@ class TiledSolver:
         st = be.begin(L, phi_global_local, phi_n_full, phi_n_psi_local, psi_local)  # includes the warp of solver.cu:106
         slots = torch.zeros((n_iters + 1, SLOTS), dtype=torch.int32, device=be.device)
         self.slots = slots
+        xch = halo_ops(L, [(st.nabla_U, HALO)], self.group) if self.world > 1 else []
         for it in range(1, n_iters + 1):
             prev = slots[it - 1] if (it > 1 and can_converge) else None
             be.pass_a(st, self.w_reg, prev, self.thr)
             if self.world > 1:
-                exchange_halos(L, [(st.nabla_U, HALO)], self.group)
+                run_halo_ops(xch)
             be.pass_b(st, slots[it], self.taps, self.alpha, prev, self.thr)
             if self.world > 1 and can_converge:
                 dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
