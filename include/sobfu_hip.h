@@ -166,12 +166,14 @@ int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv
                                     int n_sweeps, void* stream);
 /* compact != 0: the field arguments are in the compact iteration format -- psi / nabla_U 12-byte xyz triples, phi_n o
  * psi / phi_global / phi_n tsdf-only floats (built with the conversion entry points below). */
+/* [z_begin, z_end): the planes this launch produces (the arrays are always the whole slab) -- lets the driver compute
+ * boundary planes first, start the halo exchange, and compute the interior while it is in flight. */
 int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
-                                      float* d_nabla_U, float w_reg, int X, int Y, int Lz, const uint32_t* d_prev_slots,
-                                      float max_update_norm, int compact, void* stream);
+                                      float* d_nabla_U, float w_reg, int X, int Y, int Lz, int z_begin, int z_end,
+                                      const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
 int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
                                        float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha,
-                                       int X, int Y, int Lz, int Zg, int z_own_lo, int z_own_hi,
+                                       int X, int Y, int Lz, int Zg, int z_own_lo, int z_own_hi, int z_begin, int z_end,
                                        const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
 /* Compact-format conversions (n = number of voxels): float4 <-> packed xyz (unpack leaves .w untouched), float2
  * {tsdf, weight} -> tsdf, and the tsdf-only warp of a slab (phi: whole (X, Y, Zg) tsdf-only volume). */

@@ -182,6 +182,7 @@ struct PassAArgs {
     Dims d;
     float w_reg;
     int zc;  // slices per workgroup
+    int z_lo, z_hi;  // planes [z_lo, z_hi) are produced by this launch (the whole volume, or a sub-range of a slab)
     const uint32_t* prev_slots;
     float max_update_norm;
 };
@@ -197,8 +198,8 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<true>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (d.z + a.zc - 1) / a.zc);
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = tid3.tz * a.zc, ze = min(zb + a.zc, d.z);
+    const TileId tid3 = tile_of_block<true>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (a.z_hi - a.z_lo + a.zc - 1) / a.zc);
+    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = a.z_lo + tid3.tz * a.zc, ze = min(zb + a.zc, a.z_hi);
     const int x = x0 + lx, xc = min(x, d.x - 1);
     const size_t plane = (size_t) d.x * d.y;
 
@@ -347,6 +348,7 @@ struct PassBArgs {
     Taps S;
     float alpha;
     int zc;
+    int z_lo, z_hi;  // planes produced by this launch
     const uint32_t* prev_slots;
     float max_update_norm;
     // multi-GPU slab tiles: the fields are local slabs (d) that carry halo planes, phi_n is the whole volume (pd);
@@ -367,8 +369,8 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<false>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (d.z + a.zc - 1) / a.zc);
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = tid3.tz * a.zc, ze = min(zb + a.zc, d.z);
+    const TileId tid3 = tile_of_block<false>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (a.z_hi - a.z_lo + a.zc - 1) / a.zc);
+    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = a.z_lo + tid3.tz * a.zc, ze = min(zb + a.zc, a.z_hi);
     const int x = x0 + lx, xc = min(x, d.x - 1);
     const size_t plane = (size_t) d.x * d.y;
 
@@ -561,11 +563,14 @@ int pick_zc(int X, int Y, int Z, int ty, int min_groups, const char* env) {
 }
 
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
-                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact) {
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo, int z_hi) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    if (zc <= 0) zc = pick_zc(X, Y, Z, TY, 1024, "SOBFU_ZC_A");  // pass A: short 3-plane pipeline, more groups win
-    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, prev_slots, max_update_norm};
-    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + zc - 1) / zc));
+    if (z_hi <= 0) { z_lo = 0; z_hi = Z; }
+    if (z_hi <= z_lo) return 0;
+    const int nz = z_hi - z_lo;
+    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 1024, "SOBFU_ZC_A");  // pass A: short 3-plane pipeline, more groups win
+    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, z_lo, z_hi, prev_slots, max_update_norm};
+    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((nz + zc - 1) / zc));
     if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
     else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
     return (int) hipGetLastError();
@@ -573,13 +578,17 @@ int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU
 
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact) {
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo,
+                  int z_hi) {
     if (phi_Z <= 0) { phi_Z = Z; own_lo = 0; own_hi = Z; }
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    if (zc <= 0) zc = pick_zc(X, Y, Z, TY, 512, "SOBFU_ZC_B");   // pass B: 7-plane pipeline refill favours long marches
-    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
+    if (z_hi <= 0) { z_lo = 0; z_hi = Z; }
+    if (z_hi <= z_lo) return 0;
+    const int nz = z_hi - z_lo;
+    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 512, "SOBFU_ZC_B");   // pass B: 7-plane pipeline refill favours long marches
+    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
-    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + zc - 1) / zc));
+    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((nz + zc - 1) / zc));
 #define SOBFU_LAUNCH_B(UPD, CMP) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP>), grid, dim3(TX, SOBFU_WY), 0, stream, a)
     if (updates && compact) SOBFU_LAUNCH_B(true, true);
@@ -649,7 +658,7 @@ int sobfu_hip_fused_potential_gradient(const float* d_phi_n_psi, const float* d_
                                        float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Z > 1);
     if ((size_t) X * Y * Z > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
-    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Z, nullptr, 0.f, 0, (hipStream_t) stream, false);
+    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Z, nullptr, 0.f, 0, (hipStream_t) stream, false, 0, 0);
 }
 
 int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
@@ -658,16 +667,18 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
     SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Z > 0);
     if ((size_t) X * Y * Z > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Z,
-                                    nullptr, 0.f, 0, (hipStream_t) stream, 0, 0, 0, false);
+                                    nullptr, 0.f, 0, (hipStream_t) stream, 0, 0, 0, false, 0, 0);
 }
 
 int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
-                                      float w_reg, int X, int Y, int Lz, const uint32_t* d_prev_slots, float max_update_norm,
-                                      int compact, void* stream) {
-    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Lz > 1);
+                                      float w_reg, int X, int Y, int Lz, int z_begin, int z_end, const uint32_t* d_prev_slots,
+                                      float max_update_norm, int compact, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Lz > 1 && z_begin >= 0 && z_begin <= z_end &&
+                     z_end <= Lz);
+    if (z_begin == z_end) return 0;
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Lz, d_prev_slots, max_update_norm, 0,
-                                    (hipStream_t) stream, compact != 0);
+                                    (hipStream_t) stream, compact != 0, z_begin, z_end);
 }
 
 int sobfu_hip_pack_vec3(const float* d_src4, float* d_dst3, size_t n, void* stream) {
@@ -689,13 +700,14 @@ int sobfu_hip_tile_apply_tsdf_only(const float* d_phi1, int Zg, float* d_out1, c
 
 int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
                                        float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha, int X, int Y,
-                                       int Lz, int Zg, int z_own_lo, int z_own_hi, const uint32_t* d_prev_slots,
-                                       float max_update_norm, int compact, void* stream) {
+                                       int Lz, int Zg, int z_own_lo, int z_own_hi, int z_begin, int z_end,
+                                       const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream) {
     SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Lz > 0 && Zg >= 1 &&
-                     z_own_lo >= 0 && z_own_lo <= z_own_hi && z_own_hi <= Lz);
+                     z_own_lo >= 0 && z_own_lo <= z_own_hi && z_own_hi <= Lz && z_begin >= 0 && z_begin <= z_end && z_end <= Lz);
+    if (z_begin == z_end) return 0;
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff || (size_t) X * Y * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Lz,
-                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, compact != 0);
+                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, compact != 0, z_begin, z_end);
 }
 
 }  // extern "C"

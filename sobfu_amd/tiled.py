@@ -7,16 +7,20 @@ planes: halo exchange is zero-copy `isend/irecv` straight out of / into the fiel
 Per rank:  psi, phi_n o psi, phi_global, nabla_U are LOCAL slabs (X, Y, Lz) = owned planes + HALO (=4) planes towards
 each neighbour; phi_n is replicated (the warp gathers at absolute coordinates anywhere in the volume).
 
-One iteration = ONE exchange (Option B of the survey, which in a 1-D decomposition needs no edge data):
-    A   nabla_U on the whole slab            exact on the OWNED planes (reads psi, phi_n o psi at owned +-1)
-    E   exchange nabla_U (4 planes / face)    -> nabla_U exact on owned +-4
-    B   psi -= alpha * (Sx+Sy+Sz) nabla_U, phi_n o psi on the whole slab: the radius-3 convolution is exact on
-        owned +-1, so psi and phi_n o psi stay exact on owned +-1 -- what the next pass A needs -- without ever being
-        exchanged (invariant; identity psi satisfies it at the start);  max ||u||^2 over OWNED planes only
-    R   all_reduce(MAX) of the 256 max-norm slots -- only when max_update_norm >= 0 (otherwise the test never fires)
-Values the kernels write further out in the halo are never read.  Clamp / mirror rules act at a slab's array edge,
-which is the volume boundary exactly where the slab has no halo, so the result equals the single-GPU run bit for bit
-(the max is order-independent).
+One iteration = ONE exchange (Option B of the survey, which in a 1-D decomposition needs no edge data), overlapped
+with the interior compute (the kernels take the range of planes a launch produces):
+    A_bnd  nabla_U on the 4 owned planes next to each interior face (reads psi, phi_n o psi at owned +-1)
+    E      start the exchange of those planes (one grouped RCCL send/recv on RCCL's stream) -> nabla_U exact on owned +-4
+    A_int  nabla_U on the remaining owned planes                       } run while E is in flight: they touch
+    B_int  psi, phi_n o psi on the planes whose +-3 taps are all owned } neither the planes being sent nor received
+    wait E
+    B_bnd  psi, phi_n o psi on the remaining planes out to owned +-1: the radius-3 convolution is exact there, so psi
+           and phi_n o psi stay exact on owned +-1 -- all the next pass A reads -- without ever being exchanged
+           (invariant; identity psi satisfies it at the start).  max ||u||^2 takes OWNED planes only.
+    R      all_reduce(MAX) of the 256 max-norm slots -- only when max_update_norm >= 0 (otherwise the test never fires)
+Halo planes further out are never read.  Clamp / mirror rules act at a slab's array edge, which is the volume
+boundary exactly where the slab has no halo, so the result equals the single-GPU run bit for bit (the max is
+order-independent).
 
 The kernel backend is pluggable: `HipBackend` (product; C ABI on torch CUDA tensors over RCCL) -- the CPU tests inject an
 oracle-backed backend over gloo to check the decomposition logic without a GPU.
@@ -80,10 +84,18 @@ def halo_ops(layout: SlabLayout, fields, group=None):
     return ops
 
 
+def start_halo_ops(ops):
+    """One grouped RCCL launch on RCCL's own stream, ordered after everything queued so far on the current stream."""
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def finish_halo_ops(works):
+    for w in works:  # for RCCL this only makes the current stream wait; the host does not block
+        w.wait()
+
+
 def run_halo_ops(ops):
-    if ops:
-        for r in dist.batch_isend_irecv(ops):  # one grouped RCCL launch; wait() only orders the current stream after it
-            r.wait()
+    finish_halo_ops(start_halo_ops(ops))
 
 
 def exchange_halos(layout: SlabLayout, fields, group=None):
@@ -153,20 +165,26 @@ class HipBackend:
         self._call("sobfu_hip_tile_apply_tsdf_only", self._p(st.c_n), Z, self._p(st.c_f), self._p(st.c_psi), X, Y, Lz)  # solver.cu:106
         return st
 
-    def pass_a(self, st, w_reg, prev_slots, thr):
+    def pass_a(self, st, z0, z1, w_reg, prev_slots, thr):
+        """nabla_U on local planes [z0, z1)"""
+        if z1 <= z0:
+            return
         L = st.layout
         X, Y, _ = L.dims
         prev = self._p(prev_slots) if prev_slots is not None else None
         self._call("sobfu_hip_tile_potential_gradient", self._p(st.c_f), self._p(st.c_g), self._p(st.c_psi), self._p(st.nabla_U),
-                   C.c_float(w_reg), X, Y, L.Lz, prev, C.c_float(thr), 1 if self.compact else 0)
+                   C.c_float(w_reg), X, Y, L.Lz, z0, z1, prev, C.c_float(thr), 1 if self.compact else 0)
 
-    def pass_b(self, st, slots, taps, alpha, prev_slots, thr):
+    def pass_b(self, st, z0, z1, slots, taps, alpha, prev_slots, thr):
+        """psi update + warp on local planes [z0, z1)"""
+        if z1 <= z0:
+            return
         L = st.layout
         X, Y, Z = L.dims
         prev = self._p(prev_slots) if prev_slots is not None else None
         self._call("sobfu_hip_tile_smooth_update_apply", self._p(st.nabla_U), self._p(st.c_psi), self._p(st.c_n), self._p(st.c_f), None,
                    self._p(slots), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), X, Y, L.Lz, Z, L.own_lo, L.own_hi,
-                   prev, C.c_float(thr), 1 if self.compact else 0)
+                   z0, z1, prev, C.c_float(thr), 1 if self.compact else 0)
 
     def end(self, st):
         if not self.compact:
@@ -223,12 +241,25 @@ class TiledSolver:
         slots = torch.zeros((n_iters + 1, SLOTS), dtype=torch.int32, device=be.device)
         self.slots = slots
         xch = halo_ops(L, [(st.nabla_U, HALO)], self.group) if self.world > 1 else []
+        lo, hi, H = L.own_lo, L.own_hi, HALO
+        # planes next to an interior face (sent to the neighbour) vs the rest; ranges are local plane indices
+        a_lo = min(lo + H, hi) if L.lo else lo          # [lo, a_lo)  : lower boundary planes of pass A
+        a_hi = max(hi - H, a_lo) if L.hi else hi        # [a_hi, hi)  : upper boundary planes of pass A
+        b_lo = min(lo + 3, hi) if L.lo else lo          # pass B planes >= b_lo have all -3 taps inside the owned range
+        b_hi = max(hi - 3, b_lo) if L.hi else hi
+        b_first = lo - 1 if L.lo else lo                # pass B also refreshes the first halo plane (owned +-1)
+        b_last = hi + 1 if L.hi else hi
         for it in range(1, n_iters + 1):
             prev = slots[it - 1] if (it > 1 and can_converge) else None
-            be.pass_a(st, self.w_reg, prev, self.thr)
-            if self.world > 1:
-                run_halo_ops(xch)
-            be.pass_b(st, slots[it], self.taps, self.alpha, prev, self.thr)
+            row = slots[it]
+            be.pass_a(st, lo, a_lo, self.w_reg, prev, self.thr)
+            be.pass_a(st, a_hi, hi, self.w_reg, prev, self.thr)
+            works = start_halo_ops(xch)
+            be.pass_a(st, a_lo, a_hi, self.w_reg, prev, self.thr)
+            be.pass_b(st, b_lo, b_hi, row, self.taps, self.alpha, prev, self.thr)
+            finish_halo_ops(works)
+            be.pass_b(st, b_first, b_lo, row, self.taps, self.alpha, prev, self.thr)
+            be.pass_b(st, b_hi, b_last, row, self.taps, self.alpha, prev, self.thr)
             if self.world > 1 and can_converge:
                 dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
         if self.world > 1 and not can_converge:

@@ -46,18 +46,20 @@ class OracleBackend:
             return False
         return tiled._sqrt_rd(int(prev.numpy().view(np.uint32).max())) <= thr
 
-    def pass_a(self, st, w_reg, prev, thr):
-        if self._gate(prev, thr):
+    def pass_a(self, st, z0, z1, w_reg, prev, thr):
+        """whole-slab oracle kernels, only planes [z0, z1) are committed (a launch of the HIP kernel produces exactly those)"""
+        if z1 <= z0 or self._gate(prev, thr):
             return
         L = st.layout
         dims = (L.dims[0], L.dims[1], L.Lz)
-        g, Lap = O.new_field(dims), O.new_field(dims)
+        g, Lap, out = O.new_field(dims), O.new_field(dims), O.new_field(dims)
         O.tsdf_gradient(st.pnp, g)
         O.laplacian(st.psi, Lap)
-        O.potential_gradient(st.pnp, st.pg, g, Lap, st.nabla_U.numpy(), w_reg)
+        O.potential_gradient(st.pnp, st.pg, g, Lap, out, w_reg)
+        st.nabla_U.numpy()[z0:z1] = out[z0:z1]
 
-    def pass_b(self, st, slots, taps, alpha, prev, thr):
-        if self._gate(prev, thr):
+    def pass_b(self, st, z0, z1, slots, taps, alpha, prev, thr):
+        if z1 <= z0 or self._gate(prev, thr):
             return
         L = st.layout
         dims = (L.dims[0], L.dims[1], L.Lz)
@@ -66,12 +68,18 @@ class OracleBackend:
         O.convolution_rows(nUS, nU, taps)
         O.convolution_columns(nUS, nU, taps)
         O.convolution_depth(nUS, nU, taps)
-        O.update_psi(st.psi, nUS, upd, alpha)
-        O.apply_tile(st.pn, st.pnp, st.psi)
-        u = upd[L.own_lo:L.own_hi]
-        sq = (u[..., 0] * u[..., 0] + u[..., 1] * u[..., 1]) + u[..., 2] * u[..., 2]
-        s = slots.numpy().view(np.uint32)
-        s[0] = max(s[0], np.float32(sq.max()).view(np.uint32))
+        psi_new = st.psi.copy()
+        O.update_psi(psi_new, nUS, upd, alpha)
+        st.psi[z0:z1] = psi_new[z0:z1]
+        warped = O.new_volume(dims)
+        O.apply_tile(st.pn, warped, psi_new)
+        st.pnp[z0:z1] = warped[z0:z1]
+        a, b = max(z0, L.own_lo), min(z1, L.own_hi)
+        if b > a:
+            u = upd[a:b]
+            sq = (u[..., 0] * u[..., 0] + u[..., 1] * u[..., 1]) + u[..., 2] * u[..., 2]
+            s = slots.numpy().view(np.uint32)
+            s[0] = max(s[0], np.float32(sq.max()).view(np.uint32))
 
     def end(self, st):
         pass

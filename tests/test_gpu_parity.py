@@ -452,12 +452,18 @@ def test_tile_kernels_match_full_volume(ops, oracle, world, compact):
         psi_l, pg_l = (L.take(t).clone().contiguous() for t in (dev(psi0), dev(pg)))
         pnp_l = torch.zeros(L.local_shape(2), device="cuda")
         st = be.begin(L, pg_l, pn_d, pnp_l, psi_l)
-        be.pass_a(st, w_reg, None, 0.0)
+        # split launches, as the overlapped schedule issues them
+        be.pass_a(st, L.own_lo, L.own_lo + 2, w_reg, None, 0.0)
+        be.pass_a(st, L.own_hi - 3, L.own_hi, w_reg, None, 0.0)
+        be.pass_a(st, L.own_lo + 2, L.own_hi - 3, w_reg, None, 0.0)
         nU_own = L.owned(st.nabla_U)[..., :3]
         assert torch.equal(nU_own.contiguous().view(torch.int32), nU_f[L.z0:L.z1][..., :3].contiguous().view(torch.int32))
         st.nabla_U[..., :3] = L.take(nU_f)[..., :3]  # the exchange: 4 halo planes of nabla_U from their owners
         slots = torch.zeros(256, dtype=torch.int32, device="cuda")
-        be.pass_b(st, slots, S, alpha, None, 0.0)
+        b_first, b_last = (L.own_lo - 1 if L.lo else L.own_lo), (L.own_hi + 1 if L.hi else L.own_hi)
+        mid = (b_first + b_last) // 2
+        be.pass_b(st, mid, b_last, slots, S, alpha, None, 0.0)
+        be.pass_b(st, b_first, mid, slots, S, alpha, None, 0.0)
         be.end(st)
         torch.cuda.synchronize()
         lo, hi = max(L.z0 - 1, 0), min(L.z1 + 1, Z)
