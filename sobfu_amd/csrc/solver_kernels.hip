@@ -19,6 +19,10 @@
 
 using namespace sobfu_hip;
 
+#ifndef SOBFU_SWIZZLE_B
+#define SOBFU_SWIZZLE_B false  // XCD-aware tile map for pass B (tuning knob; see tile_of_block)
+#endif
+
 namespace {
 
 struct Taps {
@@ -357,8 +361,11 @@ struct PassBArgs {
     int own_lo, own_hi;
 };
 
+#ifndef SOBFU_MINW_B
+#define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
+#endif
 template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT>
-__global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassBArgs a) {
+__global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
     constexpr int NXH = (2 * R * TY + 63) / 64;  // wave-tasks for the 2R x-halo columns
     constexpr int NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
@@ -369,7 +376,7 @@ __global__ void __launch_bounds__(TX* WY) fused_smooth_update_apply_kernel(PassB
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<false>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (a.z_hi - a.z_lo + a.zc - 1) / a.zc);
+    const TileId tid3 = tile_of_block<SOBFU_SWIZZLE_B>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (a.z_hi - a.z_lo + a.zc - 1) / a.zc);
     const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = a.z_lo + tid3.tz * a.zc, ze = min(zb + a.zc, a.z_hi);
     const int x = x0 + lx, xc = min(x, d.x - 1);
     const size_t plane = (size_t) d.x * d.y;
@@ -550,16 +557,30 @@ __global__ void __launch_bounds__(256) apply_tsdf_only_kernel(const float* __res
 
 namespace sobfu_hip {
 
-int pick_zc(int X, int Y, int Z, int ty, int min_groups, const char* env) {
+// z-chunk length of a fused pass.  A launch has tiles * ceil(nz / zc) workgroups; `capacity` of them are resident at
+// once on the chip (256 CUs x workgroups per CU allowed by VGPRs / LDS / waves).  Cost model: time ~ (1 + refill / zc)
+// / utilisation, where utilisation = groups / (ceil(groups / capacity) * capacity) penalises a ragged last wave of
+// workgroups (measured at 256^3, pass B: 768 groups = exactly 3 per CU: 166 us; 512 groups: 184 us; 1024: 195 us) and
+// refill = planes re-read when a march starts (2 for pass A, 6 for pass B).  Small grids end up with many short
+// marches, which is what the latency-bound regime wants (64^3: zc = 2 is 1.4x faster than zc = 8).
+int pick_zc(int X, int Y, int nz, int ty, int capacity, int refill, const char* env) {
     if (const char* e = getenv(env)) {  // tuning override
         int v = atoi(e);
-        if (v > 0) return v < Z ? v : Z;
+        if (v > 0) return v < nz ? v : nz;
     }
-    // enough workgroups to fill 256 CUs a few times over, but long z marches (less pipeline refill)
     const long tiles = (long) ((X + TX - 1) / TX) * ((Y + ty - 1) / ty);
-    int zc = Z;
-    while (zc > 2 && tiles * ((Z + zc - 1) / zc) < min_groups) zc = (zc + 1) / 2;  // small grids are latency-bound: many short marches
-    return zc;
+    int best_zc = nz;
+    double best = 1e30;
+    for (int c = 1; c <= nz; ++c) {
+        const int zc = (nz + c - 1) / c;
+        if (zc < 2 && nz >= 2) break;
+        const long groups = tiles * ((nz + zc - 1) / zc);
+        const long waves  = (groups + capacity - 1) / capacity;
+        const double util = (double) groups / (double) (waves * capacity);
+        const double cost = (1.0 + (double) refill / zc) / util;
+        if (cost < best - 1e-9) { best = cost; best_zc = zc; }
+    }
+    return best_zc;
 }
 
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
@@ -568,7 +589,7 @@ int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU
     if (z_hi <= 0) { z_lo = 0; z_hi = Z; }
     if (z_hi <= z_lo) return 0;
     const int nz = z_hi - z_lo;
-    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 1024, "SOBFU_ZC_A");  // pass A: short 3-plane pipeline, more groups win
+    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 256 * 4, 2, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
     PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, z_lo, z_hi, prev_slots, max_update_norm};
     dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((nz + zc - 1) / zc));
     if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
@@ -585,7 +606,7 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
     if (z_hi <= 0) { z_lo = 0; z_hi = Z; }
     if (z_hi <= z_lo) return 0;
     const int nz = z_hi - z_lo;
-    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 512, "SOBFU_ZC_B");   // pass B: 7-plane pipeline refill favours long marches
+    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 256 * 3, 6, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
     PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((nz + zc - 1) / zc));
