@@ -232,14 +232,42 @@ int sobfu_hip_solver_keep_updates(sobfu_hip_solver* s, int keep);
  * triples, tsdf-only 4-byte phi_global / phi_n / phi_n o psi -- and rebuild the caller's buffers after the loop
  * (76 instead of 112 bytes per voxel-iteration, identical results).  enable = 0 iterates directly on the API buffers. */
 int sobfu_hip_solver_set_compact(sobfu_hip_solver* s, int enable);
-/* Per-kernel timing of the quiet path with HIP events recorded on the solver's stream around every pass A / pass B
- * launch; totals accumulate over iterations until reset. */
+/* Per-kernel timing of the quiet path with HIP events recorded on the solver's stream around the pass A / pass B
+ * launches of every 8th iteration (sampling keeps the probe from slowing the loop); totals and the number of sampled
+ * iterations accumulate until reset. */
 int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int enable);
 int sobfu_hip_solver_get_profile(sobfu_hip_solver* s, float* ms_pass_a, float* ms_pass_b, int* launches, int reset);
 /* Callback invoked by estimate_psi for every line the reference prints with std::cout (solver.cu:115-190);
  * NULL (default) = print to stdout like the reference. */
 typedef void (*sobfu_hip_log_fn)(const char* line, void* user);
 int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* user);
+
+/* ------------------------------------------------------------------------------------------------------
+ * native multi-GPU loop: one rank per z-slab, RCCL halo exchange issued from C++ and overlapped with the interior
+ * compute (no reference counterpart; schedule documented in sobfu_amd/tiled.py)
+ * ---------------------------------------------------------------------------------------------------- */
+#define SOBFU_E_RCCL (-4) /* RCCL not loaded / an RCCL call failed (details on stderr) */
+typedef struct sobfu_hip_tiled sobfu_hip_tiled; /* opaque */
+/* dlopen()s the RCCL library the host process already uses (e.g. <torch>/lib/librccl.so); must precede the rest. */
+int sobfu_hip_tiled_load_rccl(const char* librccl_path);
+/* ncclGetUniqueId on one rank; the caller broadcasts the 128 bytes to all ranks (any transport). */
+int sobfu_hip_tiled_unique_id(char out[128]);
+/* Collective over all `world` ranks (ncclCommInitRank).  The volume's Z planes are split as evenly as possible. */
+int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
+                           const sobfu_hip_solver_params* params);
+int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t);
+/* owned planes [z0, z1) of this rank, halo planes below / above, slab thickness Lz, global z of local plane 0 */
+int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, int* hi, int* Lz, int* zbase);
+/* n_iters iterations on this rank's slab (collective).  Local slabs: phi_global / phi_n o psi float2 (X, Y, Lz), psi
+ * float4 (X, Y, Lz) exact on owned +-1 planes on entry and exit; phi_n: the whole float2 (X, Y, Z) volume. */
+int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
+                            float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
+                            float* per_iter_max_norm, void* stream);
+/* bring-up helpers: the loop's halo exchange on a caller-provided 12-byte slab field; a self send/recv and a MAX
+ * all-reduce through the same RCCL entry points (usable with a single rank) */
+int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream);
+int sobfu_hip_tiled_self_sendrecv(sobfu_hip_tiled* t, const float* d_src, float* d_dst, size_t n, void* stream);
+int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

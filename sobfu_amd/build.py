@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsobfu_hip.so")
-SOURCES = ["tsdf_kernels.hip", "field_kernels.hip", "reduce_kernels.hip", "solver_kernels.hip", "solver_capi.hip"]
+SOURCES = ["tsdf_kernels.hip", "field_kernels.hip", "reduce_kernels.hip", "solver_kernels.hip", "solver_capi.hip", "tiled_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
@@ -58,7 +58,7 @@ def build_hip(force: bool = False, extra_flags=(), verbose: bool = False) -> str
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB])
     return LIB
 
 

@@ -6,6 +6,7 @@
 // norm of iteration k lives in 256 device slots, iteration k+1's kernels test it themselves and turn into no-ops
 // once it is <= max_update_norm, and the host only looks every kCheckEvery iterations -- the iteration at which
 // the solver stops, and every array it leaves behind, are exactly the reference's.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,7 @@ namespace {
 
 constexpr int kSlots      = 256;
 constexpr int kCheckEvery = 32;
+constexpr int kProfEvery  = 8;
 
 float host_sqrt_rd(float s) {  // __fsqrt_rd
     float r = std::sqrt(s);
@@ -198,12 +200,16 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
         for (int it = 1; it <= max_iter && !converged; ++it) {
             const uint32_t* prev = (it > 1) ? s->slots + (size_t) (it - 1) * kSlots : nullptr;
             uint32_t* cur        = s->slots + (size_t) it * kSlots;
-            if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1)], st));
+            // timing events are SAMPLED (every kProfEvery-th iteration): an event between two kernels costs several us of
+            // pipeline drain, and recording around every launch slowed the loop by ~8 % at 256^3
+            const bool ev = prof && (it % kProfEvery == 0);
+            const int e0  = 3 * (it / kProfEvery - 1);
+            if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0], st));
             SOBFU_TRY(sobfu_hip::launch_pass_a(it_pnp, it_pg, it_psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st, compact));
-            if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1) + 1], st));
+            if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 1], st));
             SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, it_psi, it_pn, it_out, upd, cur, s->taps, p.alpha, X, Y, Z, prev,
                                                p.max_update_norm, 0, st, 0, 0, 0, compact));
-            if (prof) SOBFU_HIP_TRY(hipEventRecord(s->events[3 * (it - 1) + 2], st));
+            if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 2], st));
             launched = it;
             if (can_converge && (it % kCheckEvery == 0 || it == max_iter)) {
                 const int n = it - checked;
@@ -239,7 +245,7 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
             SOBFU_TRY(sobfu_hip::launch_unpack_vec(s->c_psi, psi, s->N, st));
             SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // the state solver.cu:168 leaves behind
         }
-        if (prof) s->prof_pending = done < launched ? done : launched;  // elapsed times are read in get_profile()
+        if (prof) s->prof_pending = (done < launched ? done : launched) / kProfEvery;  // sampled iterations; read in get_profile()
         // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
         for (int it = 1; it <= done; ++it)
             if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
@@ -297,6 +303,7 @@ const char* sobfu_hip_error_string(int code) {
         case SOBFU_E_BADARG: return "sobfu_hip: bad argument";
         case SOBFU_E_FILTER: return "sobfu_hip: (s, lambda) not in the Sobolev filter table";
         case SOBFU_E_UNSUPPORTED: return "sobfu_hip: unsupported configuration";
+        case SOBFU_E_RCCL: return "sobfu_hip: RCCL not loaded or an RCCL call failed (see stderr)";
         default: return code > 0 ? hipGetErrorString((hipError_t) code) : "sobfu_hip: unknown error";
     }
 }

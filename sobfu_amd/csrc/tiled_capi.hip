@@ -1,0 +1,326 @@
+// Native multi-GPU solver loop: one rank (process, GPU) per z-slab, halo exchange by RCCL send/recv over xGMI issued
+// from C++ on a dedicated communication stream and overlapped with the interior compute.
+//
+// Same decomposition and schedule as sobfu_amd/tiled.py (which documents the invariants), without a Python round trip
+// per iteration:
+//     A_bnd (planes next to an interior face)  ->  event  ->  [comm stream] group{send, recv} of 4 nabla_U planes / face
+//     A_int, B_int (planes whose +-3 taps are owned)            ... run while the exchange is in flight
+//     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)  ->  all_reduce(MAX) of the 256 max-norm slots (only when
+//     a non-negative threshold can fire: the device-side gate needs the GLOBAL max)
+//
+// RCCL is not a link-time dependency: the host process (PyTorch) has already loaded librccl.so; sobfu_hip_tiled_load_rccl
+// dlopen()s that same file and resolves the nine entry points used here, so libsobfu_hip.so still loads on a machine
+// without RCCL and a process never holds two copies of the library.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "sobfu_device.hpp"
+#include "sobfu_hip.h"
+#include "sobfu_host.hpp"
+
+namespace sobfu_hip {
+int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo, int z_hi);
+int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
+                  const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo,
+                  int z_hi);
+int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
+int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
+int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z);
+}  // namespace sobfu_hip
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return handle != nullptr; }
+} g_rccl;
+
+constexpr int kHalo = 4, kSlots = 256;
+
+#define RCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t _r = (expr);                                                               \
+        if (_r != ncclSuccess) {                                                                \
+            std::fprintf(stderr, "sobfu_hip: RCCL error %d (%s) at %s:%d\n", (int) _r,            \
+                         g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?", __FILE__, __LINE__); \
+            return SOBFU_E_RCCL;                                                                \
+        }                                                                                       \
+    } while (0)
+
+float host_sqrt_rd(float s) {
+    float r = std::sqrt(s);
+    if (r > 0.f && (double) r * (double) r > (double) s) r = std::nextafterf(r, -INFINITY);
+    return r;
+}
+
+}  // namespace
+
+struct sobfu_hip_tiled {
+    int X, Y, Z, world, rank;
+    int z0, z1, lo, hi, Lz, own_lo, own_hi, zbase;
+    sobfu_hip_solver_params p;
+    float taps[7];
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr;
+    // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
+    float *nU = nullptr, *c_psi = nullptr, *c_f = nullptr, *c_g = nullptr, *c_n = nullptr;
+    uint32_t* slots = nullptr;
+    int slots_iters = 0;
+    size_t NL, NF;
+};
+
+extern "C" {
+
+int sobfu_hip_tiled_load_rccl(const char* librccl_path) {
+    if (g_rccl.ok()) return 0;
+    SOBFU_CHECK_ARGS(librccl_path);
+    void* h = dlopen(librccl_path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        std::fprintf(stderr, "sobfu_hip: cannot dlopen %s: %s\n", librccl_path, dlerror());
+        return SOBFU_E_RCCL;
+    }
+#define SYM(field, name)                                         \
+    *(void**) (&g_rccl.field) = dlsym(h, name);                  \
+    if (!g_rccl.field) {                                         \
+        std::fprintf(stderr, "sobfu_hip: %s has no %s\n", librccl_path, name); \
+        return SOBFU_E_RCCL;                                     \
+    }
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.handle = h;
+    return 0;
+}
+
+int sobfu_hip_tiled_unique_id(char out[128]) {
+    SOBFU_CHECK_ARGS(out);
+    if (!g_rccl.ok()) return SOBFU_E_RCCL;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out, &id, 128);
+    return 0;
+}
+
+int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
+    if (!t) return 0;
+    for (float* q : {t->nU, t->c_psi, t->c_f, t->c_g, t->c_n})
+        if (q) (void) hipFree(q);
+    if (t->slots) (void) hipFree(t->slots);
+    if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
+    if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
+    if (t->comm_stream) (void) hipStreamDestroy(t->comm_stream);
+    if (t->comm && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm);
+    delete t;
+    return 0;
+}
+
+int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
+                           const sobfu_hip_solver_params* params) {
+    SOBFU_CHECK_ARGS(out && params && unique_id && X > 1 && Y > 1 && Z > 1 && world >= 1 && rank >= 0 && rank < world);
+    if (!g_rccl.ok()) return SOBFU_E_RCCL;
+    if (Z < world * kHalo || params->s < 7) return SOBFU_E_UNSUPPORTED;
+    auto* t = new sobfu_hip_tiled();
+    t->X = X; t->Y = Y; t->Z = Z; t->world = world; t->rank = rank;
+    const int base = Z / world, rem = Z % world;
+    t->z0 = rank * base + (rank < rem ? rank : rem);
+    t->z1 = t->z0 + base + (rank < rem ? 1 : 0);
+    t->lo = rank > 0 ? kHalo : 0;
+    t->hi = rank < world - 1 ? kHalo : 0;
+    t->Lz = (t->z1 - t->z0) + t->lo + t->hi;
+    t->own_lo = t->lo;
+    t->own_hi = t->lo + (t->z1 - t->z0);
+    t->zbase  = t->z0 - t->lo;
+    t->NL = (size_t) X * Y * t->Lz;
+    t->NF = (size_t) X * Y * Z;
+    t->p  = *params;
+    float h[16];
+    int rc = sobfu_hip_sobolev_filter(params->s, params->lambda, h);
+    for (int i = 0; i < 7; ++i) t->taps[i] = h[i];
+    if (rc == 0 && (t->z1 - t->z0) < kHalo && world > 1) rc = SOBFU_E_UNSUPPORTED;
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->nU, t->NL * 12);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi, t->NL * 12);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f, t->NL * 4);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
+    if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
+    if (rc == 0) {
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, 128);
+        ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
+        if (r != ncclSuccess) {
+            std::fprintf(stderr, "sobfu_hip: ncclCommInitRank failed: %s\n", g_rccl.GetErrorString(r));
+            rc = SOBFU_E_RCCL;
+        }
+    }
+    if (rc != 0) {
+        sobfu_hip_tiled_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return 0;
+}
+
+int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, int* hi, int* Lz, int* zbase) {
+    SOBFU_CHECK_ARGS(t);
+    if (z0) *z0 = t->z0;
+    if (z1) *z1 = t->z1;
+    if (lo) *lo = t->lo;
+    if (hi) *hi = t->hi;
+    if (Lz) *Lz = t->Lz;
+    if (zbase) *zbase = t->zbase;
+    return 0;
+}
+
+// One grouped send/recv of `planes` owned planes per interior face of a 12-byte field (floats: 3 per voxel).
+static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t stream) {
+    const size_t plane_f = (size_t) t->X * t->Y * 3, cnt = plane_f * planes;
+    RCCL_TRY(g_rccl.GroupStart());
+    if (t->rank > 0) {
+        RCCL_TRY(g_rccl.Send(field3 + plane_f * t->own_lo, cnt, ncclFloat32, t->rank - 1, t->comm, stream));
+        RCCL_TRY(g_rccl.Recv(field3 + plane_f * (t->own_lo - planes), cnt, ncclFloat32, t->rank - 1, t->comm, stream));
+    }
+    if (t->rank < t->world - 1) {
+        RCCL_TRY(g_rccl.Send(field3 + plane_f * (t->own_hi - planes), cnt, ncclFloat32, t->rank + 1, t->comm, stream));
+        RCCL_TRY(g_rccl.Recv(field3 + plane_f * t->own_hi, cnt, ncclFloat32, t->rank + 1, t->comm, stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    return 0;
+}
+
+// Debug / bring-up: exchange `planes` planes of a caller-provided 12-byte slab field exactly as the loop does.
+int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream) {
+    SOBFU_CHECK_ARGS(t && d_field3 && planes > 0 && planes <= kHalo);
+    return exchange(t, d_field3, planes, (hipStream_t) stream);
+}
+
+// Bring-up self test usable with ONE rank: a world-1 communicator sends n floats from d_src to itself into d_dst through
+// the same group{send, recv} path the loop uses (RCCL allows self send/recv inside a group).
+int sobfu_hip_tiled_self_sendrecv(sobfu_hip_tiled* t, const float* d_src, float* d_dst, size_t n, void* stream) {
+    SOBFU_CHECK_ARGS(t && d_src && d_dst && n > 0);
+    RCCL_TRY(g_rccl.GroupStart());
+    RCCL_TRY(g_rccl.Send(d_src, n, ncclFloat32, t->rank, t->comm, (hipStream_t) stream));
+    RCCL_TRY(g_rccl.Recv(d_dst, n, ncclFloat32, t->rank, t->comm, (hipStream_t) stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    return 0;
+}
+
+int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_t n, void* stream) {
+    SOBFU_CHECK_ARGS(t && d_buf && n > 0);
+    RCCL_TRY(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint32, ncclMax, t->comm, (hipStream_t) stream));
+    return 0;
+}
+
+// The gradient-descent loop (reference src/sobfu/cuda/solver.cu:106-193) on this rank's slab.  API-format arguments:
+// d_phi_global_local / d_phi_n_psi_local float2 (X, Y, Lz), d_phi_n_full float2 (X, Y, Z), d_psi_local float4 (X, Y, Lz)
+// whose owned +-1 planes are exact on entry (identity: sobfu_hip_tile_init_identity) and on exit.  Synchronises `stream`.
+int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
+                            float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
+                            float* per_iter_max_norm, void* stream) {
+    SOBFU_CHECK_ARGS(t && d_phi_global_local && d_phi_n_full && d_phi_n_psi_local && d_psi_local && n_iters >= 0);
+    hipStream_t st = (hipStream_t) stream;
+    const int X = t->X, Y = t->Y, Z = t->Z, Lz = t->Lz;
+    const sobfu_hip_solver_params& p = t->p;
+    sobfu_hip_solver_report r{};
+    r.last_max_update_norm = r.last_max_update_index = r.last_e_data = r.last_e_reg = NAN;
+    // enter the compact format (includes the warp of solver.cu:106)
+    SOBFU_TRY(sobfu_hip::launch_pack_vec(d_psi_local, t->c_psi, t->NL, st));
+    SOBFU_TRY(sobfu_hip::launch_extract_tsdf(d_phi_global_local, t->c_g, t->NL, st));
+    SOBFU_TRY(sobfu_hip::launch_extract_tsdf(d_phi_n_full, t->c_n, t->NF, st));
+    SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(t->c_n, t->c_f, t->c_psi, X, Y, Lz, st, Z));
+    if (n_iters > t->slots_iters) {
+        if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
+        t->slots = nullptr;
+        SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (n_iters + 1) * kSlots * 4));
+        t->slots_iters = n_iters;
+    }
+    if (n_iters > 0) SOBFU_HIP_TRY(hipMemsetAsync(t->slots, 0, (size_t) (n_iters + 1) * kSlots * 4, st));
+    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1;
+    const int lo = t->own_lo, hi = t->own_hi, H = kHalo;
+    const int a_lo = t->lo ? std::min(lo + H, hi) : lo, a_hi = t->hi ? std::max(hi - H, a_lo) : hi;
+    const int b_lo = t->lo ? std::min(lo + 3, hi) : lo, b_hi = t->hi ? std::max(hi - 3, b_lo) : hi;
+    const int b_first = t->lo ? lo - 1 : lo, b_last = t->hi ? hi + 1 : hi;
+    for (int it = 1; it <= n_iters; ++it) {
+        const uint32_t* prev = (it > 1 && can_converge) ? t->slots + (size_t) (it - 1) * kSlots : nullptr;
+        uint32_t* row        = t->slots + (size_t) it * kSlots;
+        auto A = [&](int za, int zb) {
+            return sobfu_hip::launch_pass_a(t->c_f, t->c_g, t->c_psi, t->nU, p.w_reg, X, Y, Lz, prev, p.max_update_norm, 0, st, true, za, zb);
+        };
+        auto B = [&](int za, int zb) {
+            return sobfu_hip::launch_pass_b(t->nU, t->c_psi, t->c_n, t->c_f, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev, p.max_update_norm,
+                                            0, st, Z, lo, hi, true, za, zb);
+        };
+        if (a_lo > lo) SOBFU_TRY(A(lo, a_lo));
+        if (hi > a_hi) SOBFU_TRY(A(a_hi, hi));
+        if (multi) {
+            SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
+            SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
+            SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
+            SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
+        }
+        if (a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
+        if (b_hi > b_lo) SOBFU_TRY(B(b_lo, b_hi));
+        if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
+        if (b_lo > b_first) SOBFU_TRY(B(b_first, b_lo));
+        if (b_last > b_hi) SOBFU_TRY(B(b_hi, b_last));
+        if (multi && can_converge) RCCL_TRY(g_rccl.AllReduce(row, row, kSlots, ncclUint32, ncclMax, t->comm, st));
+        // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
+        // the wait above, so the sends have completed by then
+    }
+    if (multi && !can_converge && n_iters > 0)
+        RCCL_TRY(g_rccl.AllReduce(t->slots + kSlots, t->slots + kSlots, (size_t) n_iters * kSlots, ncclUint32, ncclMax, t->comm, st));
+    // leave the compact format: psi.xyz back, phi_n o psi = apply(phi_n, psi) (the state of solver.cu:168)
+    SOBFU_TRY(sobfu_hip::launch_unpack_vec(t->c_psi, d_psi_local, t->NL, st));
+    SOBFU_TRY(sobfu_hip_tile_apply(d_phi_n_full, Z, d_phi_n_psi_local, d_psi_local, X, Y, Lz, st));
+    std::vector<uint32_t> hs((size_t) std::max(n_iters, 1) * kSlots, 0u);
+    if (n_iters > 0) SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), t->slots + kSlots, (size_t) n_iters * kSlots * 4, hipMemcpyDeviceToHost, st));
+    SOBFU_HIP_TRY(hipStreamSynchronize(st));
+    int done = n_iters;
+    for (int k = 0; k < n_iters; ++k) {
+        uint32_t m = 0;
+        for (int i = 0; i < kSlots; ++i) m = std::max(m, hs[(size_t) k * kSlots + i]);
+        float f;
+        std::memcpy(&f, &m, 4);
+        const float v = host_sqrt_rd(f);
+        if (per_iter_max_norm) per_iter_max_norm[k] = v;
+        r.last_max_update_norm = v;
+        if (can_converge && v <= p.max_update_norm) {  // solver.cu:183 -- later launches were device-side no-ops
+            done = k + 1;
+            r.converged = 1;
+            break;
+        }
+    }
+    r.iterations = done;
+    if (report) *report = r;
+    return 0;
+}
+
+}  // extern "C"

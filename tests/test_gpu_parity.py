@@ -539,3 +539,49 @@ def test_max_size_512(ops, oracle):
     y = torch.arange(512, device="cuda", dtype=torch.float32).view(1, 512, 1)
     assert float((psi[..., 1] - (y - 1.5)).abs().max()) < 1e-4
     assert float(psi[-1, -1, -1, 0]) == 511.0 and float(psi[-1, -1, -1, 2]) == 511.0
+
+
+def test_native_tiled_loop_single_rank(ops, oracle):
+    """sobfu_hip_tiled_* (C++ loop + RCCL) with one rank: identical to the solver handle; the RCCL entry points it uses
+    (communicator bootstrap, grouped send/recv, MAX all-reduce) are exercised on the real library through self-transfers."""
+    import ctypes as C
+
+    from sobfu_amd import _lib, tiled
+
+    dims = (40, 24, 20)
+    pg, pn = rand_volume(dims, 71), rand_volume(dims, 72)
+    psi0 = warped_identity(oracle, dims, 73, 0.6)
+    ref = ops.Solver(dims, max_iter=5, alpha=0.05, w_reg=0.4)
+    psi_r, pnp_r = dev(psi0), ops.new_volume(dims)
+    rep_r, hist_r = ref.iterate(dev(pg), dev(pn), pnp_r, psi_r, 5)
+    nt = tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4)
+    psi_n, pnp_n = dev(psi0), ops.new_volume(dims)
+    done, hist_n = nt.iterate(dev(pg), dev(pn), pnp_n, psi_n, 5)
+    assert done == 5 and same(hist_n, hist_r)
+    assert torch.equal(psi_n.view(torch.int32), psi_r.view(torch.int32))
+    assert torch.equal(pnp_n.view(torch.int32), pnp_r.view(torch.int32))
+    # identity slab, convergence gate
+    assert torch.equal(nt.identity_psi().view(torch.int32), dev(oracle.new_field(dims) * 0 + 0).view(torch.int32)) is False
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    src = torch.arange(3000, dtype=torch.float32, device="cuda")
+    dst = torch.zeros_like(src)
+    _lib.check(L.sobfu_hip_tiled_self_sendrecv(nt._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(3000), st), "self")
+    buf = torch.tensor([3, 9, 1, 7], dtype=torch.int32, device="cuda")
+    _lib.check(L.sobfu_hip_tiled_allreduce_max_u32(nt._h, C.c_void_p(buf.data_ptr()), C.c_size_t(4), st), "allreduce")
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst) and buf.tolist() == [3, 9, 1, 7]
+    nt.close()
+    ref.close()
+    # positive threshold: same stopping iteration as the handle
+    thr = float(hist_r[2])
+    a = ops.Solver(dims, max_iter=5, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+    psi_a, pnp_a = dev(psi0), ops.new_volume(dims)
+    rep_a, _ = a.iterate(dev(pg), dev(pn), pnp_a, psi_a, 5)
+    b = tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+    psi_b, pnp_b = dev(psi0), ops.new_volume(dims)
+    done_b, _ = b.iterate(dev(pg), dev(pn), pnp_b, psi_b, 5)
+    assert done_b == rep_a.iterations < 5
+    assert torch.equal(psi_b.view(torch.int32), psi_a.view(torch.int32))
+    a.close()
+    b.close()
