@@ -232,6 +232,9 @@ int sobfu_hip_solver_keep_updates(sobfu_hip_solver* s, int keep);
  * triples, tsdf-only 4-byte phi_global / phi_n / phi_n o psi -- and rebuild the caller's buffers after the loop
  * (76 instead of 112 bytes per voxel-iteration, identical results).  enable = 0 iterates directly on the API buffers. */
 int sobfu_hip_solver_set_compact(sobfu_hip_solver* s, int enable);
+/* Single-kernel iteration for quiet compact solves: nabla_U is recomputed per tile (3-cell halo) and never written to
+ * memory; psi / phi_n o psi are ping-ponged.  40 instead of 76 bytes per voxel-iteration, identical results. */
+int sobfu_hip_solver_set_fused(sobfu_hip_solver* s, int enable);
 /* Per-kernel timing of the quiet path with HIP events recorded on the solver's stream around the pass A / pass B
  * launches of every 8th iteration (sampling keeps the probe from slowing the loop); totals and the number of sampled
  * iterations accumulate until reset. */

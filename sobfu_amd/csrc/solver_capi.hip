@@ -25,6 +25,9 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
                   float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo = 0,
                   int z_hi = 0);
+int launch_fused_iteration(const float* psi_in3, const float* f_in, const float* g, const float* phi_n1, float* psi_out3, float* f_out,
+                           uint32_t* slots, const float taps[7], float alpha, float w_reg, int X, int Y, int Z, const uint32_t* prev_slots,
+                           float max_update_norm, hipStream_t stream);
 int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
 int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
 int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
@@ -68,6 +71,10 @@ struct sobfu_hip_solver {
     float* c_g   = nullptr;  //  4 B/voxel  phi_global.tsdf
     float* c_n   = nullptr;  //  4 B/voxel  phi_n.tsdf
     bool compact = true;
+    // single-kernel iteration (nabla_U never leaves the chip): needs psi / F ping-pong buffers
+    bool fused = false;
+    float* c_psi2 = nullptr;  // 12 B/voxel
+    float* c_f2   = nullptr;  //  4 B/voxel
     uint32_t* slots    = nullptr;  // (slots_iters + 1) x 256
     void* red_scratch  = nullptr;  // 65536 x 8 B block partials
     int slots_iters    = 0;
@@ -119,6 +126,14 @@ int ensure_compact(sobfu_hip_solver* s) {
     SOBFU_HIP_TRY(hipMalloc((void**) &s->c_g, s->N * 4));
     SOBFU_HIP_TRY(hipMalloc((void**) &s->c_n, s->N * 4));
     s->bytes += s->N * 24;
+    return 0;
+}
+
+int ensure_fused(sobfu_hip_solver* s) {
+    if (s->c_psi2) return 0;
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_psi2, s->N * 12));
+    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_f2, s->N * 4));
+    s->bytes += s->N * 16;
     return 0;
 }
 
@@ -192,6 +207,10 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
         SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(s->c_n, s->c_f, s->c_psi, X, Y, Z, st));  // solver.cu:106
         it_pnp = s->c_f; it_pg = s->c_g; it_pn = s->c_n; it_psi = s->c_psi; it_out = s->c_f;
     }
+    const bool fused = compact && s->fused && upd == nullptr;
+    if (fused) SOBFU_TRY(ensure_fused(s));
+    float* pp_psi[2] = {s->c_psi, s->c_psi2};
+    float* pp_f[2]   = {s->c_f, s->c_f2};
     const bool prof = s->profiling && !verbose;
     if (prof) SOBFU_TRY(ensure_events(s, (size_t) 3 * max_iter));
     int launched = 0;
@@ -205,10 +224,16 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
             const bool ev = prof && (it % kProfEvery == 0);
             const int e0  = 3 * (it / kProfEvery - 1);
             if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0], st));
+            if (fused) {  // iteration `it` reads buffer (it-1)&1 and writes buffer it&1
+                if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 1], st));
+                SOBFU_TRY(sobfu_hip::launch_fused_iteration(pp_psi[(it - 1) & 1], pp_f[(it - 1) & 1], s->c_g, s->c_n, pp_psi[it & 1], pp_f[it & 1], cur,
+                                                            s->taps, p.alpha, p.w_reg, X, Y, Z, prev, p.max_update_norm, st));
+            } else {
             SOBFU_TRY(sobfu_hip::launch_pass_a(it_pnp, it_pg, it_psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st, compact));
             if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 1], st));
             SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, it_psi, it_pn, it_out, upd, cur, s->taps, p.alpha, X, Y, Z, prev,
                                                p.max_update_norm, 0, st, 0, 0, 0, compact));
+            }
             if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 2], st));
             launched = it;
             if (can_converge && (it % kCheckEvery == 0 || it == max_iter)) {
@@ -242,7 +267,8 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
             done = max_iter;
         }
         if (compact) {
-            SOBFU_TRY(sobfu_hip::launch_unpack_vec(s->c_psi, psi, s->N, st));
+            // `done` iterations actually executed (later launches were no-ops): the state is in ping-pong buffer done&1
+            SOBFU_TRY(sobfu_hip::launch_unpack_vec(fused ? pp_psi[done & 1] : s->c_psi, psi, s->N, st));
             SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // the state solver.cu:168 leaves behind
         }
         if (prof) s->prof_pending = (done < launched ? done : launched) / kProfEvery;  // sampled iterations; read in get_profile()
@@ -344,6 +370,7 @@ int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const s
     s->X = X; s->Y = Y; s->Z = Z;
     s->N = (size_t) X * Y * Z;
     if (const char* e = getenv("SOBFU_COMPACT")) s->compact = atoi(e) != 0;  // tuning override
+    if (const char* e = getenv("SOBFU_FUSED")) s->fused = atoi(e) != 0;
     int rc = set_params(s, params);
     if (rc == 0) rc = (int) hipMalloc((void**) &s->nabla_U, s->N * 16);
     if (rc == 0) rc = (int) hipMalloc(&s->red_scratch, 65536 * 8);
@@ -365,7 +392,7 @@ int sobfu_hip_solver_destroy(sobfu_hip_solver* s) {
     if (s->updates) (void) hipFree(s->updates);
     if (s->slots) (void) hipFree(s->slots);
     if (s->red_scratch) (void) hipFree(s->red_scratch);
-    for (float* q : {s->c_psi, s->c_f, s->c_g, s->c_n})
+    for (float* q : {s->c_psi, s->c_f, s->c_g, s->c_n, s->c_psi2, s->c_f2})
         if (q) (void) hipFree(q);
     for (hipEvent_t e : s->events) (void) hipEventDestroy(e);
     delete s;
@@ -402,6 +429,12 @@ int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* 
 int sobfu_hip_solver_set_compact(sobfu_hip_solver* s, int enable) {
     SOBFU_CHECK_ARGS(s);
     s->compact = enable != 0;
+    return 0;
+}
+
+int sobfu_hip_solver_set_fused(sobfu_hip_solver* s, int enable) {
+    SOBFU_CHECK_ARGS(s);
+    s->fused = enable != 0;
     return 0;
 }
 

@@ -519,6 +519,245 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
     }
 }
 
+// ============================================================================================================
+// Part 3: single-kernel iteration (compact format only)
+// ============================================================================================================
+// One launch = one solver iteration: nabla_U is never written to memory.  A workgroup owns a 64x8 tile, marches along z
+// and, per plane, (re)computes nabla_U on the tile PLUS a 3-cell halo from psi / F = (phi_n o psi).tsdf staged with a
+// 4-cell halo in LDS (pass A's arithmetic), then smooths / updates / warps the tile exactly like pass B.  Halo cells of
+// nabla_U are recomputed by the workgroup that needs them (1.9x pass A's cheap math) instead of being round-tripped
+// through HBM: per voxel-iteration the kernel reads psi 12 + F 4 + G 4 (+ halo) + phi_n gather 4 and writes psi 12 + F 4
+// = 40 B instead of 76 B (two-pass compact) or 112 B (API format).  psi and F are ping-ponged (a tile's halo must see
+// the previous iteration's values while neighbours already write the next).  Same arithmetic, same order: bit-identical.
+//
+// Cell bookkeeping (E3 = tile +-3 = 70x14 cells holds nabla_U, E4 = tile +-4 = 72x16 holds psi/F):
+//   lane t owns its tile cell ("main") and, for t < 468, one cell of E3 \ tile ("extra"); lanes 468..511 refresh the
+//   172 cells of the ring E4 \ E3 (4 each).  Per owned cell: a 3-plane z window of psi/F (planes p-1, p, p+1 for the
+//   nabla_U plane p = z + 3 produced at step z); main cells feed the 7-plane nabla_U register pipeline, extra cells a
+//   4-plane delay line so that their value for plane z reaches the LDS nabla_U tile at step z.
+struct FusedArgs {
+    const void* psi_in;   // P3
+    const float* f_in;    // (phi_n o psi).tsdf
+    const float* g;       // phi_global.tsdf
+    const float* phi_n;   // phi_n.tsdf (whole volume)
+    void* psi_out;        // P3
+    float* f_out;
+    uint32_t* slots;
+    Dims d;
+    Taps S;
+    float alpha, w_reg;
+    int zc;
+    const uint32_t* prev_slots;
+    float max_update_norm;
+};
+
+constexpr int FY = 8, FE3X = TX + 6, FE3Y = FY + 6, FE4X = TX + 8, FE4Y = FY + 8;
+constexpr int FEXTRA = FE3X * FE3Y - TX * FY;  // 468
+constexpr int FRING  = FE4X * FE4Y - FE3X * FE3Y;  // 172
+
+// pass A's arithmetic for one cell (vector_fields.cu:157-208, 291-337; solver.cu:28-31).  c = {psi.xyz, F} of the cell;
+// xp/xm/yp/ym in-plane neighbours, zp/zm the cell's own window.
+SOBFU_DEV float4 nabla_u_cell(const float4& c, float4 xp, float4 xm, float4 yp, float4 ym, float4 zp, float4 zm, float g, float w_reg,
+                              bool xlo, bool xhi, bool ylo, bool yhi, bool zlo, bool zhi) {
+    float gx1 = xhi ? xm.w : xp.w, gx2 = xlo ? xp.w : xm.w;
+    float gy1 = yhi ? ym.w : yp.w, gy2 = ylo ? yp.w : ym.w;
+    float gz1 = zhi ? zm.w : zp.w, gz2 = zlo ? zp.w : zm.w;
+    float4 gr = f4((gx1 - gx2) / 2.f, (gy1 - gy2) / 2.f, (gz1 - gz2) / 2.f);
+    if (xlo || xhi) { xp = c; xm = c; }
+    if (ylo || yhi) { yp = c; ym = c; }
+    if (zlo || zhi) { zp = c; zm = c; }
+    float4 v = mul4(c, -6.f);
+    v = add4(v, xp);
+    v = add4(v, xm);
+    v = add4(v, yp);
+    v = add4(v, ym);
+    v = add4(v, zp);
+    v = add4(v, zm);
+    float4 L = mul4(v, -1.f);
+    return add4(mul4(gr, c.w - g), mul4(L, w_reg));
+}
+
+__global__ void __launch_bounds__(TX* FY, 4) fused_iteration_kernel(FusedArgs a) {
+    __shared__ float4 t_pf[2][FE4Y][FE4X];  // {psi.xyz, F} of plane z+3 on E4
+    __shared__ float4 t_nu[2][FE3Y][FE3X];  // nabla_U of plane z on E3
+    __shared__ uint32_t s_max[FY];
+
+    if (solver_converged(a.prev_slots, a.max_update_norm)) return;
+
+    const Dims d = a.d;
+    const int lx = threadIdx.x, wy = threadIdx.y, tid = wy * TX + lx;
+    const TileId tid3 = tile_of_block<false>((d.x + TX - 1) / TX, (d.y + FY - 1) / FY, (d.z + a.zc - 1) / a.zc);
+    const int x0 = tid3.tx * TX, y0 = tid3.ty * FY, zb = tid3.tz * a.zc, ze = min(zb + a.zc, d.z);
+    const size_t plane = (size_t) d.x * d.y;
+    auto clampx = [&](int v) { return min(max(v, 0), d.x - 1); };
+    auto clampy = [&](int v) { return min(max(v, 0), d.y - 1); };
+    auto clampz = [&](int v) { return min(max(v, 0), d.z - 1); };
+
+    // ---- main cell ------------------------------------------------------------------------------------------------
+    const int x = x0 + lx, y = y0 + wy;
+    const int mgx = clampx(x), mgy = clampy(y);
+    const size_t m_off = (size_t) mgx + (size_t) d.x * mgy;
+    const int mcx = mgx - (x0 - 4), mcy = mgy - (y0 - 4);  // E4 index of the (clamped) main cell
+    const bool m_in = x < d.x && y < d.y;
+    // ---- extra cell (E3 \ tile) -------------------------------------------------------------------------------------
+    const bool has_e = tid < FEXTRA;
+    int ex = 0, ey = 0;  // E3 coordinates
+    if (tid < 210) { ey = tid / FE3X; ex = tid % FE3X; }
+    else if (tid < 420) { ey = 11 + (tid - 210) / FE3X; ex = (tid - 210) % FE3X; }
+    else { const int e = tid - 420, c6 = e % 6; ey = 3 + e / 6; ex = c6 < 3 ? c6 : TX + c6; }
+    const int egx = clampx(x0 - 3 + ex), egy = clampy(y0 - 3 + ey);
+    const size_t e_off = (size_t) egx + (size_t) d.x * egy;
+    const int ecx = egx - (x0 - 4), ecy = egy - (y0 - 4);
+    // ---- ring cells (E4 \ E3), lanes 468..511, 4 each ---------------------------------------------------------------
+    const bool has_r = tid >= FEXTRA;
+    int r_cx[4], r_cy[4];
+    size_t r_off[4];
+    bool r_on[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (tid - FEXTRA) + (TX * FY - FEXTRA) * j;
+        r_on[j] = has_r && r < FRING;
+        int cx = 0, cy = 0;
+        if (r < FE4X) { cy = 0; cx = r; }
+        else if (r < 2 * FE4X) { cy = FE4Y - 1; cx = r - FE4X; }
+        else { const int q = r - 2 * FE4X; cy = 1 + q / 2; cx = (q & 1) ? FE4X - 1 : 0; }
+        r_cx[j] = cx;
+        r_cy[j] = cy;
+        r_off[j] = (size_t) clampx(x0 - 4 + cx) + (size_t) d.x * clampy(y0 - 4 + cy);
+    }
+
+    auto ld_pf = [&](size_t off, int zz) -> float4 {  // {psi.xyz, F} of voxel `off` in (clamped) plane zz
+        const size_t i = (size_t) clampz(zz) * plane + off;
+        float4 v = ldv<true>(a.psi_in, i);
+        v.w = a.f_in[i];
+        return v;
+    };
+
+    // producer state: psi/F z windows (planes p-1, p, p+1 for the nabla_U plane p = z+3 produced at step z)
+    const int z_start = max(zb - 6, -3);
+    float4 mw[3], ew[3], rr[4];
+    {
+        const int p = z_start + 3;
+        mw[0] = ld_pf(m_off, p - 1); mw[1] = ld_pf(m_off, p); mw[2] = ld_pf(m_off, p + 1);
+        if (has_e) { ew[0] = ld_pf(e_off, p - 1); ew[1] = ld_pf(e_off, p); ew[2] = ld_pf(e_off, p + 1); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r_on[j]) rr[j] = ld_pf(r_off[j], p);
+    }
+    float gm = a.g[(size_t) clampz(z_start + 3) * plane + m_off], ge = has_e ? a.g[(size_t) clampz(z_start + 3) * plane + e_off] : 0.f;
+    float4 q[7];   // nabla_U planes z-3 .. z+3 of the main cell
+    float4 dl[4];  // nabla_U planes z .. z+3 of the extra cell
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q[k] = f4(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dl[k] = f4(0.f, 0.f, 0.f);
+    float4 pin = ldv<true>(a.psi_in, (size_t) clampz(zb) * plane + m_off);  // psi_in of the plane being updated
+
+    const bool mxlo = mgx == 0, mxhi = mgx == d.x - 1, mylo = mgy == 0, myhi = mgy == d.y - 1;
+    const bool exlo = egx == 0, exhi = egx == d.x - 1, eylo = egy == 0, eyhi = egy == d.y - 1;
+
+    float msq = 0.f;
+    for (int z = z_start; z < ze; ++z) {
+        const int buf = (z - z_start) & 1, p = z + 3;
+        // (1) stage plane p of psi/F (E4) and plane z of nabla_U (E3)
+        t_pf[buf][mcy][mcx] = mw[1];
+        if (has_e) t_pf[buf][ecy][ecx] = ew[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r_on[j]) t_pf[buf][r_cy[j]][r_cx[j]] = rr[j];
+        t_nu[buf][wy + 3][lx + 3] = q[3];
+        if (has_e) t_nu[buf][ey][ex] = dl[0];
+        // NOTE: cells of the staged tiles are addressed by the CLAMPED position of their owner, so a tile row / column that
+        // lies outside the volume holds its clamped neighbour's value -- what clamp-to-edge taps expect.  The main / extra
+        // writes above use (mcx, mcy) / (ecx, ecy) for psi/F (neighbour look-ups are relative to the clamped cell) but the
+        // RAW E3 position for nabla_U (the convolution indexes by raw offset from the tile cell).
+        // (2) prefetch the next step's inputs
+        float4 nmw = ld_pf(m_off, p + 2), new_ = has_e ? ld_pf(e_off, p + 2) : f4(0.f, 0.f, 0.f), nrr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r_on[j]) nrr[j] = ld_pf(r_off[j], p + 1);
+        const float ngm = a.g[(size_t) clampz(p + 1) * plane + m_off], nge = has_e ? a.g[(size_t) clampz(p + 1) * plane + e_off] : 0.f;
+        const float4 npin = ldv<true>(a.psi_in, (size_t) clampz(z + 1) * plane + m_off);
+        __syncthreads();
+
+        // (3) produce nabla_U plane p (0 <= p <= Z-1 computed; p > Z-1 replicates the last plane; p < 0 is back-filled
+        //     with plane 0 when it is produced -- clamp-to-edge along z)
+        if (p >= 0 && p < d.z) {
+            const bool zlo = p == 0, zhi = p == d.z - 1;
+            q[6] = nabla_u_cell(mw[1], t_pf[buf][mcy][mcx + 1], t_pf[buf][mcy][mcx - 1], t_pf[buf][mcy + 1][mcx], t_pf[buf][mcy - 1][mcx], mw[2],
+                                mw[0], gm, a.w_reg, mxlo, mxhi, mylo, myhi, zlo, zhi);
+            if (has_e)
+                dl[3] = nabla_u_cell(ew[1], t_pf[buf][ecy][ecx + 1], t_pf[buf][ecy][ecx - 1], t_pf[buf][ecy + 1][ecx], t_pf[buf][ecy - 1][ecx],
+                                     ew[2], ew[0], ge, a.w_reg, exlo, exhi, eylo, eyhi, zlo, zhi);
+            if (p == 0) {
+#pragma unroll
+                for (int k = 3; k < 6; ++k) q[k] = q[6];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dl[k] = dl[3];
+            }
+        } else if (p >= d.z) {
+            q[6]  = q[5];
+            dl[3] = dl[2];
+        }
+
+        // (4) consume: smooth, update, warp plane z of the tile (pass B's arithmetic)
+        if (z >= zb) {
+            float sxx = 0.f, sxy = 0.f, sxz = 0.f, syx = 0.f, syy = 0.f, syz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
+#pragma unroll
+            for (int j = -3; j <= 3; ++j) {
+                const float s = a.S.s[3 - j];
+                const float4 vx = (j == 0) ? q[3] : t_nu[buf][wy + 3][lx + 3 + j];
+                sxx += vx.x * s;
+                sxy += vx.y * s;
+                sxz += vx.z * s;
+                const float4 vy = (j == 0) ? q[3] : t_nu[buf][wy + 3 + j][lx + 3];
+                syx += vy.x * s;
+                syy += vy.y * s;
+                syz += vy.z * s;
+                const float4 vz = q[3 + j];
+                szx += vz.x * s;
+                szy += vz.y * s;
+                szz += vz.z * s;
+            }
+            const float tx = (sxx + syx) + szx, ty = (sxy + syy) + szy, tz = (sxz + syz) + szz;
+            const float4 u = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
+            float4 pnew = pin;
+            pnew.x -= u.x;
+            pnew.y -= u.y;
+            pnew.z -= u.z;
+            if (m_in) {
+                msq = fmaxf(msq, norm_sq4(u));
+                const size_t i = (size_t) z * plane + (size_t) x + (size_t) d.x * y;
+                stv<true>(a.psi_out, i, pnew);
+                a.f_out[i] = interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z);
+            }
+        }
+        // (5) advance the pipelines
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = q[k + 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dl[k] = dl[k + 1];
+        mw[0] = mw[1]; mw[1] = mw[2]; mw[2] = nmw;
+        ew[0] = ew[1]; ew[1] = ew[2]; ew[2] = new_;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = nrr[j];
+        gm = ngm;
+        ge = nge;
+        if (z >= zb) pin = npin;
+    }
+
+    uint32_t m = __float_as_uint(msq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
+    if (lx == 0) s_max[wy] = m;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < FY; ++w) m = max(m, s_max[w]);
+        atomicMax(a.slots + (blockIdx.x & 255u), m);
+    }
+}
+
 // --- compact-format conversions (once per solve, not per iteration) ----------------------------------------------
 __global__ void __launch_bounds__(256) pack_vec_kernel(const float4* __restrict__ src, P3* __restrict__ dst, size_t N) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -617,6 +856,17 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
     else if (compact) SOBFU_LAUNCH_B(false, true);
     else SOBFU_LAUNCH_B(false, false);
 #undef SOBFU_LAUNCH_B
+    return (int) hipGetLastError();
+}
+
+int launch_fused_iteration(const float* psi_in3, const float* f_in, const float* g, const float* phi_n1, float* psi_out3, float* f_out,
+                           uint32_t* slots, const float taps[7], float alpha, float w_reg, int X, int Y, int Z, const uint32_t* prev_slots,
+                           float max_update_norm, hipStream_t stream) {
+    const int zc = pick_zc(X, Y, Z, FY, 256 * 2, 6, "SOBFU_ZC_F");  // 68 KB LDS, <= 128 VGPR: 2 workgroups per CU
+    FusedArgs a{psi_in3, f_in, g, phi_n1, psi_out3, f_out, slots, {X, Y, Z}, {}, alpha, w_reg, zc, prev_slots, max_update_norm};
+    for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
+    dim3 grid(((X + TX - 1) / TX) * ((Y + FY - 1) / FY) * ((Z + zc - 1) / zc));
+    hipLaunchKernelGGL(fused_iteration_kernel, grid, dim3(TX, FY), 0, stream, a);
     return (int) hipGetLastError();
 }
 

@@ -298,6 +298,9 @@ class Solver:
     def set_compact(self, enable=True):
         check(_lib.lib().sobfu_hip_solver_set_compact(self._h, C.c_int(1 if enable else 0)), "set_compact")
 
+    def set_fused(self, enable=True):
+        check(_lib.lib().sobfu_hip_solver_set_fused(self._h, C.c_int(1 if enable else 0)), "set_fused")
+
     def set_profiling(self, enable=True):
         check(_lib.lib().sobfu_hip_solver_set_profiling(self._h, C.c_int(1 if enable else 0)), "set_profiling")
 

@@ -585,3 +585,33 @@ def test_native_tiled_loop_single_rank(ops, oracle):
     assert torch.equal(psi_b.view(torch.int32), psi_a.view(torch.int32))
     a.close()
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-kernel iteration (nabla_U recomputed per tile, psi / F ping-pong): same bits as everything else
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", [(64, 64, 64), (40, 24, 20), (17, 9, 5), (70, 33, 19), (130, 37, 41), (2, 2, 2), (65, 9, 2), (5, 70, 3)])
+def test_fused_single_kernel_iteration(ops, oracle, dims):
+    pg, pn = rand_volume(dims, 81), rand_volume(dims, 82)
+    psi = warped_identity(oracle, dims, 83, 0.9)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=5, alpha=0.05, w_reg=0.4, inverse_iters=0, compute_jacobian=False)
+    sv = ops.Solver(dims, max_iter=5, alpha=0.05, w_reg=0.4)
+    sv.set_fused(True)
+    psi_d, pnp_d = dev(warped_identity(oracle, dims, 83, 0.9)), ops.new_volume(dims)
+    rep, hist = sv.iterate(dev(pg), dev(pn), pnp_d, psi_d, 5)
+    assert rep.iterations == 5
+    assert nmis(host(psi_d), psi) == 0
+    assert nmis(host(pnp_d), r["phi_n_psi"]) == 0
+    assert same(hist, r["trace"][:, 2])
+    # odd iteration count + convergence break (ping-pong parity must follow the EXECUTED iterations)
+    thr = float(r["trace"][2, 2])
+    psi2 = warped_identity(oracle, dims, 83, 0.9)
+    r2 = oracle.estimate_psi(pg, pn, psi2, max_iter=5, alpha=0.05, w_reg=0.4, max_update_norm=thr, inverse_iters=0, compute_jacobian=False)
+    sv2 = ops.Solver(dims, max_iter=5, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+    sv2.set_fused(True)
+    psi_d2, pnp_d2 = dev(warped_identity(oracle, dims, 83, 0.9)), ops.new_volume(dims)
+    rep2, _ = sv2.iterate(dev(pg), dev(pn), pnp_d2, psi_d2, 5)
+    assert rep2.iterations == r2["iters"]
+    assert nmis(host(psi_d2), psi2) == 0 and nmis(host(pnp_d2), r2["phi_n_psi"]) == 0
+    sv.close()
+    sv2.close()
