@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
                 szy += vz.y * s;
                 szz += vz.z * s;
             }
-            // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)
+            // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)  -- explicit v_pk_mul/add pairing of the
+            // taps was tried and is not faster (pass B 167 us either way), so the loop stays scalar
             float tx = (sxx + syx) + szx, ty = (sxy + syy) + szy, tz = (sxz + syz) + szz;
             // update_psi_kernel (solver.cu:64-67)
             float4 u = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
@@ -577,9 +578,16 @@ SOBFU_DEV float4 nabla_u_cell(const float4& c, float4 xp, float4 xm, float4 yp, 
     return add4(mul4(gr, c.w - g), mul4(L, w_reg));
 }
 
-__global__ void __launch_bounds__(TX* FY, 4) fused_iteration_kernel(FusedArgs a) {
-    __shared__ float4 t_pf[2][FE4Y][FE4X];  // {psi.xyz, F} of plane z+3 on E4
-    __shared__ float4 t_nu[2][FE3Y][FE3X];  // nabla_U of plane z on E3
+#ifndef SOBFU_MINW_F
+#define SOBFU_MINW_F 4
+#endif
+__global__ void __launch_bounds__(TX* FY, SOBFU_MINW_F) fused_iteration_kernel(FusedArgs a) {
+    // psi/F tile: E3 cells only -- the one neighbour an E3-perimeter cell needs outside E3 is fetched by that cell itself
+    // (register `on`); the plane below (p-1) of every cell is still in the other half of the double buffer.
+    // THREE psi/F buffers: a step reads plane p (this step's buffer) AND plane p-1 (the previous step's), so the next
+    // step must write a third one (one __syncthreads per step)
+    __shared__ float4 t_pf[3][FE3Y][FE3X];  // {psi.xyz, F} of planes z+2 / z+3 on E3, addressed by CLAMPED cell position
+    __shared__ float4 t_nu[2][FE3Y][FE3X];  // nabla_U of plane z on E3, addressed by RAW cell position
     __shared__ uint32_t s_max[FY];
 
     if (solver_converged(a.prev_slots, a.max_update_norm)) return;
@@ -588,107 +596,98 @@ __global__ void __launch_bounds__(TX* FY, 4) fused_iteration_kernel(FusedArgs a)
     const int lx = threadIdx.x, wy = threadIdx.y, tid = wy * TX + lx;
     const TileId tid3 = tile_of_block<false>((d.x + TX - 1) / TX, (d.y + FY - 1) / FY, (d.z + a.zc - 1) / a.zc);
     const int x0 = tid3.tx * TX, y0 = tid3.ty * FY, zb = tid3.tz * a.zc, ze = min(zb + a.zc, d.z);
-    const size_t plane = (size_t) d.x * d.y;
+    const uint32_t plane = (uint32_t) d.x * d.y;  // voxel indices fit 31 bits
     auto clampx = [&](int v) { return min(max(v, 0), d.x - 1); };
     auto clampy = [&](int v) { return min(max(v, 0), d.y - 1); };
-    auto clampz = [&](int v) { return min(max(v, 0), d.z - 1); };
+    auto clampz = [&](int v) { return (uint32_t) min(max(v, 0), d.z - 1); };
 
     // ---- main cell ------------------------------------------------------------------------------------------------
     const int x = x0 + lx, y = y0 + wy;
     const int mgx = clampx(x), mgy = clampy(y);
-    const size_t m_off = (size_t) mgx + (size_t) d.x * mgy;
-    const int mcx = mgx - (x0 - 4), mcy = mgy - (y0 - 4);  // E4 index of the (clamped) main cell
+    const uint32_t m_off = (uint32_t) mgx + (uint32_t) d.x * mgy;
+    const int mcx = mgx - (x0 - 3), mcy = mgy - (y0 - 3);  // E3 index of the (clamped) main cell
     const bool m_in = x < d.x && y < d.y;
     // ---- extra cell (E3 \ tile) -------------------------------------------------------------------------------------
     const bool has_e = tid < FEXTRA;
-    int ex = 0, ey = 0;  // E3 coordinates
+    int ex = 0, ey = 0;  // raw E3 coordinates
     if (tid < 210) { ey = tid / FE3X; ex = tid % FE3X; }
     else if (tid < 420) { ey = 11 + (tid - 210) / FE3X; ex = (tid - 210) % FE3X; }
     else { const int e = tid - 420, c6 = e % 6; ey = 3 + e / 6; ex = c6 < 3 ? c6 : TX + c6; }
     const int egx = clampx(x0 - 3 + ex), egy = clampy(y0 - 3 + ey);
-    const size_t e_off = (size_t) egx + (size_t) d.x * egy;
-    const int ecx = egx - (x0 - 4), ecy = egy - (y0 - 4);
-    // ---- ring cells (E4 \ E3), lanes 468..511, 4 each ---------------------------------------------------------------
-    const bool has_r = tid >= FEXTRA;
-    int r_cx[4], r_cy[4];
-    size_t r_off[4];
-    bool r_on[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (tid - FEXTRA) + (TX * FY - FEXTRA) * j;
-        r_on[j] = has_r && r < FRING;
-        int cx = 0, cy = 0;
-        if (r < FE4X) { cy = 0; cx = r; }
-        else if (r < 2 * FE4X) { cy = FE4Y - 1; cx = r - FE4X; }
-        else { const int q = r - 2 * FE4X; cy = 1 + q / 2; cx = (q & 1) ? FE4X - 1 : 0; }
-        r_cx[j] = cx;
-        r_cy[j] = cy;
-        r_off[j] = (size_t) clampx(x0 - 4 + cx) + (size_t) d.x * clampy(y0 - 4 + cy);
+    const uint32_t e_off = (uint32_t) egx + (uint32_t) d.x * egy;
+    const int ecx = egx - (x0 - 3), ecy = egy - (y0 - 3);
+    // the neighbour of a perimeter cell that lies outside E3 (corner cells of E3 are never read by the plus-shaped
+    // convolution, so one outward neighbour is enough).  o_dir: 0 none, 1 x-1, 2 x+1, 3 y-1, 4 y+1.
+    int o_dir = 0;
+    if (has_e) {
+        if (ex == 0) o_dir = 1; else if (ex == FE3X - 1) o_dir = 2; else if (ey == 0) o_dir = 3; else if (ey == FE3Y - 1) o_dir = 4;
     }
+    const uint32_t o_off = (uint32_t) clampx(egx + (o_dir == 1 ? -1 : o_dir == 2 ? 1 : 0)) +
+                           (uint32_t) d.x * clampy(egy + (o_dir == 3 ? -1 : o_dir == 4 ? 1 : 0));
 
-    auto ld_pf = [&](size_t off, int zz) -> float4 {  // {psi.xyz, F} of voxel `off` in (clamped) plane zz
-        const size_t i = (size_t) clampz(zz) * plane + off;
+    auto ld_pf = [&](uint32_t off, int zz) -> float4 {  // {psi.xyz, F} of voxel `off` in (clamped) plane zz
+        const uint32_t i = clampz(zz) * plane + off;
         float4 v = ldv<true>(a.psi_in, i);
         v.w = a.f_in[i];
         return v;
     };
 
-    // producer state: psi/F z windows (planes p-1, p, p+1 for the nabla_U plane p = z+3 produced at step z)
+    // producer state for the nabla_U plane p = z + 3 produced at step z: plane p (c) and p+1 (n) of the owned cells
     const int z_start = max(zb - 6, -3);
-    float4 mw[3], ew[3], rr[4];
+    float4 mc_, mn_, ec_, en_, on_ = f4(0.f, 0.f, 0.f);
     {
         const int p = z_start + 3;
-        mw[0] = ld_pf(m_off, p - 1); mw[1] = ld_pf(m_off, p); mw[2] = ld_pf(m_off, p + 1);
-        if (has_e) { ew[0] = ld_pf(e_off, p - 1); ew[1] = ld_pf(e_off, p); ew[2] = ld_pf(e_off, p + 1); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (r_on[j]) rr[j] = ld_pf(r_off[j], p);
+        mc_ = ld_pf(m_off, p);
+        mn_ = ld_pf(m_off, p + 1);
+        if (has_e) { ec_ = ld_pf(e_off, p); en_ = ld_pf(e_off, p + 1); }
+        if (o_dir) on_ = ld_pf(o_off, p);
+        // plane p-1 is read from the previous step's buffer: pre-stage it for the first step
+        t_pf[2][mcy][mcx] = ld_pf(m_off, p - 1);
+        if (has_e) t_pf[2][ecy][ecx] = ld_pf(e_off, p - 1);
     }
-    float gm = a.g[(size_t) clampz(z_start + 3) * plane + m_off], ge = has_e ? a.g[(size_t) clampz(z_start + 3) * plane + e_off] : 0.f;
+    float gm = a.g[clampz(z_start + 3) * plane + m_off], ge = has_e ? a.g[clampz(z_start + 3) * plane + e_off] : 0.f;
     float4 q[7];   // nabla_U planes z-3 .. z+3 of the main cell
     float4 dl[4];  // nabla_U planes z .. z+3 of the extra cell
 #pragma unroll
     for (int k = 0; k < 7; ++k) q[k] = f4(0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dl[k] = f4(0.f, 0.f, 0.f);
-    float4 pin = ldv<true>(a.psi_in, (size_t) clampz(zb) * plane + m_off);  // psi_in of the plane being updated
 
     const bool mxlo = mgx == 0, mxhi = mgx == d.x - 1, mylo = mgy == 0, myhi = mgy == d.y - 1;
     const bool exlo = egx == 0, exhi = egx == d.x - 1, eylo = egy == 0, eyhi = egy == d.y - 1;
 
     float msq = 0.f;
     for (int z = z_start; z < ze; ++z) {
-        const int buf = (z - z_start) & 1, p = z + 3;
-        // (1) stage plane p of psi/F (E4) and plane z of nabla_U (E3)
-        t_pf[buf][mcy][mcx] = mw[1];
-        if (has_e) t_pf[buf][ecy][ecx] = ew[1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (r_on[j]) t_pf[buf][r_cy[j]][r_cx[j]] = rr[j];
+        const int buf = (z - z_start) & 1, pb = (z - z_start) % 3, pbm = (pb + 2) % 3, p = z + 3;
+        // (1) stage plane p of psi/F and plane z of nabla_U
+        t_pf[pb][mcy][mcx] = mc_;
+        if (has_e) t_pf[pb][ecy][ecx] = ec_;
         t_nu[buf][wy + 3][lx + 3] = q[3];
         if (has_e) t_nu[buf][ey][ex] = dl[0];
-        // NOTE: cells of the staged tiles are addressed by the CLAMPED position of their owner, so a tile row / column that
-        // lies outside the volume holds its clamped neighbour's value -- what clamp-to-edge taps expect.  The main / extra
-        // writes above use (mcx, mcy) / (ecx, ecy) for psi/F (neighbour look-ups are relative to the clamped cell) but the
-        // RAW E3 position for nabla_U (the convolution indexes by raw offset from the tile cell).
-        // (2) prefetch the next step's inputs
-        float4 nmw = ld_pf(m_off, p + 2), new_ = has_e ? ld_pf(e_off, p + 2) : f4(0.f, 0.f, 0.f), nrr[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (r_on[j]) nrr[j] = ld_pf(r_off[j], p + 1);
-        const float ngm = a.g[(size_t) clampz(p + 1) * plane + m_off], nge = has_e ? a.g[(size_t) clampz(p + 1) * plane + e_off] : 0.f;
-        const float4 npin = ldv<true>(a.psi_in, (size_t) clampz(z + 1) * plane + m_off);
+        // (2) requests for the next step / this step's update
+        const float4 nmn = ld_pf(m_off, p + 2);
+        float4 nen = f4(0.f, 0.f, 0.f), non = f4(0.f, 0.f, 0.f);
+        if (has_e) nen = ld_pf(e_off, p + 2);
+        if (o_dir) non = ld_pf(o_off, p + 1);
+        const float ngm = a.g[clampz(p + 1) * plane + m_off], nge = has_e ? a.g[clampz(p + 1) * plane + e_off] : 0.f;
+        float4 pin = f4(0.f, 0.f, 0.f);
+        if (z >= zb) pin = ldv<true>(a.psi_in, (uint32_t) z * plane + m_off);
         __syncthreads();
 
-        // (3) produce nabla_U plane p (0 <= p <= Z-1 computed; p > Z-1 replicates the last plane; p < 0 is back-filled
-        //     with plane 0 when it is produced -- clamp-to-edge along z)
+        // (3) produce nabla_U plane p
         if (p >= 0 && p < d.z) {
             const bool zlo = p == 0, zhi = p == d.z - 1;
-            q[6] = nabla_u_cell(mw[1], t_pf[buf][mcy][mcx + 1], t_pf[buf][mcy][mcx - 1], t_pf[buf][mcy + 1][mcx], t_pf[buf][mcy - 1][mcx], mw[2],
-                                mw[0], gm, a.w_reg, mxlo, mxhi, mylo, myhi, zlo, zhi);
-            if (has_e)
-                dl[3] = nabla_u_cell(ew[1], t_pf[buf][ecy][ecx + 1], t_pf[buf][ecy][ecx - 1], t_pf[buf][ecy + 1][ecx], t_pf[buf][ecy - 1][ecx],
-                                     ew[2], ew[0], ge, a.w_reg, exlo, exhi, eylo, eyhi, zlo, zhi);
+            q[6] = nabla_u_cell(mc_, t_pf[pb][mcy][mcx + 1], t_pf[pb][mcy][mcx - 1], t_pf[pb][mcy + 1][mcx], t_pf[pb][mcy - 1][mcx], mn_,
+                                t_pf[pbm][mcy][mcx], gm, a.w_reg, mxlo, mxhi, mylo, myhi, zlo, zhi);
+            if (has_e) {
+                // in-plane neighbours: from the tile, except the outward one of a perimeter cell (register on_).  Index
+                // clamps keep the (unused) look-ups of corner cells inside the array.
+                const float4 xp = o_dir == 2 ? on_ : t_pf[pb][ecy][min(ecx + 1, FE3X - 1)];
+                const float4 xm = o_dir == 1 ? on_ : t_pf[pb][ecy][max(ecx - 1, 0)];
+                const float4 yp = o_dir == 4 ? on_ : t_pf[pb][min(ecy + 1, FE3Y - 1)][ecx];
+                const float4 ym = o_dir == 3 ? on_ : t_pf[pb][max(ecy - 1, 0)][ecx];
+                dl[3] = nabla_u_cell(ec_, xp, xm, yp, ym, en_, t_pf[pbm][ecy][ecx], ge, a.w_reg, exlo, exhi, eylo, eyhi, zlo, zhi);
+            }
             if (p == 0) {
 #pragma unroll
                 for (int k = 3; k < 6; ++k) q[k] = q[6];
@@ -727,7 +726,7 @@ __global__ void __launch_bounds__(TX* FY, 4) fused_iteration_kernel(FusedArgs a)
             pnew.z -= u.z;
             if (m_in) {
                 msq = fmaxf(msq, norm_sq4(u));
-                const size_t i = (size_t) z * plane + (size_t) x + (size_t) d.x * y;
+                const uint32_t i = (uint32_t) z * plane + (uint32_t) x + (uint32_t) d.x * y;
                 stv<true>(a.psi_out, i, pnew);
                 a.f_out[i] = interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z);
             }
@@ -737,13 +736,11 @@ __global__ void __launch_bounds__(TX* FY, 4) fused_iteration_kernel(FusedArgs a)
         for (int k = 0; k < 6; ++k) q[k] = q[k + 1];
 #pragma unroll
         for (int k = 0; k < 3; ++k) dl[k] = dl[k + 1];
-        mw[0] = mw[1]; mw[1] = mw[2]; mw[2] = nmw;
-        ew[0] = ew[1]; ew[1] = ew[2]; ew[2] = new_;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rr[j] = nrr[j];
+        mc_ = mn_; mn_ = nmn;
+        ec_ = en_; en_ = nen;
+        on_ = non;
         gm = ngm;
         ge = nge;
-        if (z >= zb) pin = npin;
     }
 
     uint32_t m = __float_as_uint(msq);
