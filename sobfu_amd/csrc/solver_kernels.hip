@@ -531,11 +531,12 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 // = 40 B instead of 76 B (two-pass compact) or 112 B (API format).  psi and F are ping-ponged (a tile's halo must see
 // the previous iteration's values while neighbours already write the next).  Same arithmetic, same order: bit-identical.
 //
-// Cell bookkeeping (E3 = tile +-3 = 70x14 cells holds nabla_U, E4 = tile +-4 = 72x16 holds psi/F):
-//   lane t owns its tile cell ("main") and, for t < 468, one cell of E3 \ tile ("extra"); lanes 468..511 refresh the
-//   172 cells of the ring E4 \ E3 (4 each).  Per owned cell: a 3-plane z window of psi/F (planes p-1, p, p+1 for the
-//   nabla_U plane p = z + 3 produced at step z); main cells feed the 7-plane nabla_U register pipeline, extra cells a
-//   4-plane delay line so that their value for plane z reaches the LDS nabla_U tile at step z.
+// Cell bookkeeping (E3 = tile +-3 = 70x14 cells; both LDS tiles cover E3):
+//   lane t owns its tile cell ("main") and, for t < 468, one cell of E3 \ tile ("extra").  Per owned cell, for the
+//   nabla_U plane p = z + 3 produced at step z: psi/F of planes p and p+1 in registers, plane p-1 from the previous
+//   step's LDS buffer, in-plane neighbours from this step's buffer (an E3-perimeter cell fetches its one neighbour outside
+//   E3 itself).  Main cells feed the 7-plane nabla_U register pipeline, extra cells a 4-plane delay line so that their
+//   value for plane z reaches the LDS nabla_U tile at step z.
 struct FusedArgs {
     const void* psi_in;   // P3
     const float* f_in;    // (phi_n o psi).tsdf
@@ -552,9 +553,8 @@ struct FusedArgs {
     float max_update_norm;
 };
 
-constexpr int FY = 8, FE3X = TX + 6, FE3Y = FY + 6, FE4X = TX + 8, FE4Y = FY + 8;
+constexpr int FY = 8, FE3X = TX + 6, FE3Y = FY + 6;
 constexpr int FEXTRA = FE3X * FE3Y - TX * FY;  // 468
-constexpr int FRING  = FE4X * FE4Y - FE3X * FE3Y;  // 172
 
 // pass A's arithmetic for one cell (vector_fields.cu:157-208, 291-337; solver.cu:28-31).  c = {psi.xyz, F} of the cell;
 // xp/xm/yp/ym in-plane neighbours, zp/zm the cell's own window.
@@ -594,7 +594,10 @@ __global__ void __launch_bounds__(TX* FY, SOBFU_MINW_F) fused_iteration_kernel(F
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y, tid = wy * TX + lx;
-    const TileId tid3 = tile_of_block<false>((d.x + TX - 1) / TX, (d.y + FY - 1) / FY, (d.z + a.zc - 1) / a.zc);
+#ifndef SOBFU_SWIZZLE_F
+#define SOBFU_SWIZZLE_F true  // XCD-aware tile map: halo re-reads hit the XCD's L2 (279 -> 271 us at 256^3)
+#endif
+    const TileId tid3 = tile_of_block<SOBFU_SWIZZLE_F>((d.x + TX - 1) / TX, (d.y + FY - 1) / FY, (d.z + a.zc - 1) / a.zc);
     const int x0 = tid3.tx * TX, y0 = tid3.ty * FY, zb = tid3.tz * a.zc, ze = min(zb + a.zc, d.z);
     const uint32_t plane = (uint32_t) d.x * d.y;  // voxel indices fit 31 bits
     auto clampx = [&](int v) { return min(max(v, 0), d.x - 1); };
