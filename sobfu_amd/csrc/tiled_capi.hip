@@ -5,8 +5,11 @@
 // per iteration:
 //     A_bnd (planes next to an interior face)  ->  event  ->  [comm stream] group{send, recv} of 4 nabla_U planes / face
 //     A_int, B_int (planes whose +-3 taps are owned)            ... run while the exchange is in flight
-//     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)  ->  all_reduce(MAX) of the 256 max-norm slots (only when
-//     a non-negative threshold can fire: the device-side gate needs the GLOBAL max)
+//     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)
+// When a non-negative threshold can fire, the device-side gate needs the GLOBAL max of the previous iteration's 256
+// max-norm slots.  Only pass B changes solver state, so pass A runs ungated and the all_reduce(MAX) of row it-1 is issued
+// on the comm stream ahead of iteration it's exchange; B_int waits for it.  The reduction's latency hides behind A_int
+// instead of ending every iteration (SOBFU_TILED_INLINE_REDUCE=1 restores the in-line variant for A/B runs).
 //
 // RCCL is not a link-time dependency: the host process (PyTorch) has already loaded librccl.so; sobfu_hip_tiled_load_rccl
 // dlopen()s that same file and resolves the nine entry points used here, so libsobfu_hip.so still loads on a machine
@@ -17,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -80,7 +84,7 @@ struct sobfu_hip_tiled {
     float taps[7];
     ncclComm_t comm = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_red = nullptr;
     // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
     float *nU = nullptr, *c_psi = nullptr, *c_f = nullptr, *c_g = nullptr, *c_n = nullptr;
     uint32_t* slots = nullptr;
@@ -135,6 +139,7 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (t->slots) (void) hipFree(t->slots);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
+    if (t->ev_red) (void) hipEventDestroy(t->ev_red);
     if (t->comm_stream) (void) hipStreamDestroy(t->comm_stream);
     if (t->comm && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm);
     delete t;
@@ -172,6 +177,7 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red, hipEventDisableTiming);
     if (rc == 0) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, 128);
@@ -263,19 +269,25 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         t->slots_iters = n_iters;
     }
     if (n_iters > 0) SOBFU_HIP_TRY(hipMemsetAsync(t->slots, 0, (size_t) (n_iters + 1) * kSlots * 4, st));
-    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1;
+    // SOBFU_TILED_FORCE_COMM=1 runs the communication choreography (streams, events, empty exchange group, world-1
+    // all-reduce) on a single rank too: bring-up / test hook for 1-GPU machines
+    const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
+    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
+    const char* inl = std::getenv("SOBFU_TILED_INLINE_REDUCE");  // A/B knob: all-reduce in line on the compute stream
+    const bool inline_reduce = inl && inl[0] == '1';
     const int lo = t->own_lo, hi = t->own_hi, H = kHalo;
     const int a_lo = t->lo ? std::min(lo + H, hi) : lo, a_hi = t->hi ? std::max(hi - H, a_lo) : hi;
     const int b_lo = t->lo ? std::min(lo + 3, hi) : lo, b_hi = t->hi ? std::max(hi - 3, b_lo) : hi;
     const int b_first = t->lo ? lo - 1 : lo, b_last = t->hi ? hi + 1 : hi;
     for (int it = 1; it <= n_iters; ++it) {
-        const uint32_t* prev = (it > 1 && can_converge) ? t->slots + (size_t) (it - 1) * kSlots : nullptr;
-        uint32_t* row        = t->slots + (size_t) it * kSlots;
+        const uint32_t* prev_b = (it > 1 && can_converge) ? t->slots + (size_t) (it - 1) * kSlots : nullptr;
+        const uint32_t* prev_a = (multi && !inline_reduce) ? nullptr : prev_b;  // pass A writes scratch only: no need to wait for the global max
+        uint32_t* row          = t->slots + (size_t) it * kSlots;
         auto A = [&](int za, int zb) {
-            return sobfu_hip::launch_pass_a(t->c_f, t->c_g, t->c_psi, t->nU, p.w_reg, X, Y, Lz, prev, p.max_update_norm, 0, st, true, za, zb);
+            return sobfu_hip::launch_pass_a(t->c_f, t->c_g, t->c_psi, t->nU, p.w_reg, X, Y, Lz, prev_a, p.max_update_norm, 0, st, true, za, zb);
         };
         auto B = [&](int za, int zb) {
-            return sobfu_hip::launch_pass_b(t->nU, t->c_psi, t->c_n, t->c_f, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev, p.max_update_norm,
+            return sobfu_hip::launch_pass_b(t->nU, t->c_psi, t->c_n, t->c_f, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev_b, p.max_update_norm,
                                             0, st, Z, lo, hi, true, za, zb);
         };
         if (a_lo > lo) SOBFU_TRY(A(lo, a_lo));
@@ -283,17 +295,24 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         if (multi) {
             SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
+            if (prev_b && !inline_reduce) {  // row it-1 is complete (B of it-1 precedes A_bnd on `st`): make it the global max
+                RCCL_TRY(g_rccl.AllReduce((void*) prev_b, (void*) prev_b, kSlots, ncclUint32, ncclMax, t->comm, t->comm_stream));
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
+            }
             SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
         }
         if (a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
+        if (multi && prev_b && !inline_reduce) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
         if (b_hi > b_lo) SOBFU_TRY(B(b_lo, b_hi));
         if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
         if (b_lo > b_first) SOBFU_TRY(B(b_first, b_lo));
         if (b_last > b_hi) SOBFU_TRY(B(b_hi, b_last));
-        if (multi && can_converge) RCCL_TRY(g_rccl.AllReduce(row, row, kSlots, ncclUint32, ncclMax, t->comm, st));
+        if (multi && can_converge && (inline_reduce || it == n_iters))
+            RCCL_TRY(g_rccl.AllReduce(row, row, kSlots, ncclUint32, ncclMax, t->comm, st));
         // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
-        // the wait above, so the sends have completed by then
+        // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
+        // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
     }
     if (multi && !can_converge && n_iters > 0)
         RCCL_TRY(g_rccl.AllReduce(t->slots + kSlots, t->slots + kSlots, (size_t) n_iters * kSlots, ncclUint32, ncclMax, t->comm, st));

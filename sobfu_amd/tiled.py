@@ -402,6 +402,27 @@ def bench_tiled(P, steps, warmup, rank, world):
     dist.barrier()
     dt = time.perf_counter() - t0
     assert done == steps and np.isfinite(norms).all() and float(norms.max()) > 0
-    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None,
+    # self-check, outside the timed region: every rank repeats the WHOLE solve on its own GPU with the single-GPU solver
+    # handle and compares its owned planes and the max-norm history bit for bit (tiling must not change a single bit)
+    parity = None
+    if os.environ.get("SOBFU_TILED_SELFCHECK", "1") == "1":
+        pg_full = ops.new_volume(dims)
+        ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
+        psi_full, pnp_full = ops.new_field(dims), ops.new_volume(dims)
+        ops.init_identity(psi_full)
+        one = ops.Solver(dims, max_iter=max(steps, warmup, 1), **kw)
+        if warmup > 0:
+            one.iterate(pg_full, pn_full, pnp_full, psi_full, warmup)
+        _, norms_one = one.iterate(pg_full, pn_full, pnp_full, psi_full, steps)
+        one.close()
+        same = (np.array_equal(np.asarray(norms_one, np.float32).view(np.uint32), np.asarray(norms, np.float32).view(np.uint32))
+                and torch.equal(L.owned(L.take(psi_full))[..., :3].contiguous().view(torch.int32), L.owned(psi)[..., :3].contiguous().view(torch.int32))
+                and torch.equal(L.owned(L.take(pnp_full)).contiguous().view(torch.int32), L.owned(pnp).contiguous().view(torch.int32)))
+        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        parity = bool(int(ok.item()))
+        if not parity:
+            print(f"[rank {rank}] tiled self-check: slab differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
+    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
                 parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange, "
                             + ("native C++ loop" if native else "torch.distributed loop"))

@@ -587,6 +587,36 @@ def test_native_tiled_loop_single_rank(ops, oracle):
     b.close()
 
 
+def test_native_tiled_loop_comm_choreography_on_one_rank(ops, oracle, monkeypatch):
+    """SOBFU_TILED_FORCE_COMM=1: the multi-rank stream/event schedule (comm stream, exchange group, all-reduce overlapped with
+    the next iteration's ungated pass A) on a world of one -- results must not change, with and without a live threshold."""
+    from sobfu_amd import tiled
+
+    dims = (40, 24, 20)
+    pg, pn = rand_volume(dims, 71), rand_volume(dims, 72)
+    psi0 = warped_identity(oracle, dims, 73, 0.6)
+    ref = ops.Solver(dims, max_iter=6, alpha=0.05, w_reg=0.4)
+    psi_r, pnp_r = dev(psi0), ops.new_volume(dims)
+    _, hist_r = ref.iterate(dev(pg), dev(pn), pnp_r, psi_r, 6)
+    ref.close()
+    monkeypatch.setenv("SOBFU_TILED_FORCE_COMM", "1")
+    for thr, expect in ((-1.0, 6), (1e-10, 6), (float(hist_r[2]), 3)):
+        nt = tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+        psi_n, pnp_n = dev(psi0), ops.new_volume(dims)
+        done, hist_n = nt.iterate(dev(pg), dev(pn), pnp_n, psi_n, 6)
+        assert done == expect and same(hist_n[:done], hist_r[:done])
+        if expect == 6:
+            assert torch.equal(psi_n.view(torch.int32), psi_r.view(torch.int32))
+            assert torch.equal(pnp_n.view(torch.int32), pnp_r.view(torch.int32))
+        else:
+            a = ops.Solver(dims, max_iter=6, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+            psi_a, pnp_a = dev(psi0), ops.new_volume(dims)
+            a.iterate(dev(pg), dev(pn), pnp_a, psi_a, 6)
+            assert torch.equal(psi_n.view(torch.int32), psi_a.view(torch.int32))
+            a.close()
+        nt.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 # single-kernel iteration (nabla_U recomputed per tile, psi / F ping-pong): same bits as everything else
 # ---------------------------------------------------------------------------------------------------
