@@ -255,7 +255,9 @@ typedef struct sobfu_hip_tiled sobfu_hip_tiled; /* opaque */
 int sobfu_hip_tiled_load_rccl(const char* librccl_path);
 /* ncclGetUniqueId on one rank; the caller broadcasts the 128 bytes to all ranks (any transport). */
 int sobfu_hip_tiled_unique_id(char out[128]);
-/* Collective over all `world` ranks (ncclCommInitRank).  The volume's Z planes are split as evenly as possible. */
+/* Collective over all `world` ranks (ncclCommInitRank).  The volume's Z planes are split as evenly as possible.
+ * An all-zero unique_id creates a communicator-less handle (no collective): the slab layout and launch schedule of
+ * (world, rank) with the transport left to sobfu_hip_tiled_set_transport -- or to nobody, for compute-only timing. */
 int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
                            const sobfu_hip_solver_params* params);
 int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t);
@@ -266,6 +268,15 @@ int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, 
 int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
                             float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
                             float* per_iter_max_norm, void* stream);
+/* Pluggable transport for communicator-less handles (MPI, an in-process loopback for tests, ...).  `exchange` must make
+ * planes [own_lo - planes, own_lo) / [own_hi, own_hi + planes) of the 12-byte slab field equal to the neighbours'
+ * [own_hi - planes, own_hi) / [own_lo, own_lo + planes) (local plane indices of each rank); `allreduce_max` must leave the
+ * element-wise maximum over all ranks in d_buf.  Both are called on the host in launch order and must order their work
+ * after everything already enqueued on `stream` and before anything enqueued on it later. */
+typedef int (*sobfu_hip_tiled_exchange_fn)(void* ctx, int rank, float* d_field3, int planes, void* stream);
+typedef int (*sobfu_hip_tiled_allreduce_fn)(void* ctx, int rank, uint32_t* d_buf, size_t n, void* stream);
+int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_fn exchange, sobfu_hip_tiled_allreduce_fn allreduce_max,
+                                  void* ctx);
 /* bring-up helpers: the loop's halo exchange on a caller-provided 12-byte slab field; a self send/recv and a MAX
  * all-reduce through the same RCCL entry points (usable with a single rank) */
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream);

@@ -1,0 +1,25 @@
+// Internal launchers shared by solver_capi.hip / tiled_capi.hip (defined in solver_kernels.hip).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace sobfu_hip {
+// Pass A / pass B over planes [z_lo, z_hi) (z_hi <= 0: the whole grid) and, optionally, a second range [z_lo2, z_hi2)
+// in the same launch (both boundary regions of a multi-GPU slab).  zc <= 0: z-chunk chosen by the cost model.
+int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo = 0, int z_hi = 0,
+                  int z_lo2 = 0, int z_hi2 = 0);
+int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
+                  const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
+                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo = 0,
+                  int z_hi = 0, int z_lo2 = 0, int z_hi2 = 0);
+int launch_fused_iteration(const float* psi_in3, const float* f_in, const float* g, const float* phi_n1, float* psi_out3, float* f_out,
+                           uint32_t* slots, const float taps[7], float alpha, float w_reg, int X, int Y, int Z, const uint32_t* prev_slots,
+                           float max_update_norm, hipStream_t stream);
+int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
+int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
+int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z = 0);
+}  // namespace sobfu_hip

@@ -17,22 +17,8 @@
 #include "sobfu_device.hpp"
 #include "sobfu_hip.h"
 #include "sobfu_host.hpp"
+#include "sobfu_launch.hpp"
 
-namespace sobfu_hip {
-int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
-                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo = 0, int z_hi = 0);
-int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
-                  const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo = 0,
-                  int z_hi = 0);
-int launch_fused_iteration(const float* psi_in3, const float* f_in, const float* g, const float* phi_n1, float* psi_out3, float* f_out,
-                           uint32_t* slots, const float taps[7], float alpha, float w_reg, int X, int Y, int Z, const uint32_t* prev_slots,
-                           float max_update_norm, hipStream_t stream);
-int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
-int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
-int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
-int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z = 0);
-}  // namespace sobfu_hip
 
 namespace {
 

@@ -11,16 +11,18 @@
 //           456 B/voxel.
 //
 // Arithmetic is op-for-op the reference's (see sobfu_device.hpp): results are bit-identical to Part 1.
+#include <algorithm>
 #include <cstdlib>
 
 #include "sobfu_device.hpp"
 #include "sobfu_hip.h"
 #include "sobfu_host.hpp"
+#include "sobfu_launch.hpp"
 
 using namespace sobfu_hip;
 
 #ifndef SOBFU_SWIZZLE_B
-#define SOBFU_SWIZZLE_B false  // XCD-aware tile map for pass B (tuning knob; see tile_of_block)
+#define SOBFU_SWIZZLE_B true  // XCD-aware tile map for pass B (see tile_of_block)
 #endif
 
 namespace {
@@ -159,6 +161,15 @@ SOBFU_DEV TileId tile_of_block(int ntx, int nty, int ntz) {
     return r;
 }
 
+// z-chunk -> plane range of a launch that covers [z_lo, z_hi) and, optionally, [z_lo2, z_hi2)
+SOBFU_DEV int z_chunks(int z_lo, int z_hi, int zc) { return z_hi > z_lo ? (z_hi - z_lo + zc - 1) / zc : 0; }
+SOBFU_DEV void chunk_range(int tz, int zc, int z_lo, int z_hi, int z_lo2, int z_hi2, int& zb, int& ze) {
+    const int n1 = z_chunks(z_lo, z_hi, zc);
+    const bool second = tz >= n1;
+    zb = second ? z_lo2 + (tz - n1) * zc : z_lo + tz * zc;
+    ze = min(zb + zc, second ? z_hi2 : z_hi);
+}
+
 // --- convergence gate ----------------------------------------------------------------------------------------
 // Pass B folds max ||u||^2 of iteration k into 256 uint32 slots (non-negative floats order like their bit
 // patterns).  A kernel of iteration k+1 receives the slots of iteration k and returns immediately when
@@ -187,6 +198,7 @@ struct PassAArgs {
     float w_reg;
     int zc;  // slices per workgroup
     int z_lo, z_hi;  // planes [z_lo, z_hi) are produced by this launch (the whole volume, or a sub-range of a slab)
+    int z_lo2, z_hi2;  // optional second range (both boundary regions of a slab in ONE launch); empty when z_hi2 <= z_lo2
     const uint32_t* prev_slots;
     float max_update_norm;
 };
@@ -202,8 +214,10 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<true>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (a.z_hi - a.z_lo + a.zc - 1) / a.zc);
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = a.z_lo + tid3.tz * a.zc, ze = min(zb + a.zc, a.z_hi);
+    const TileId tid3 = tile_of_block<true>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, z_chunks(a.z_lo, a.z_hi, a.zc) + z_chunks(a.z_lo2, a.z_hi2, a.zc));
+    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY;
+    int zb, ze;
+    chunk_range(tid3.tz, a.zc, a.z_lo, a.z_hi, a.z_lo2, a.z_hi2, zb, ze);
     const int x = x0 + lx, xc = min(x, d.x - 1);
     const size_t plane = (size_t) d.x * d.y;
 
@@ -353,6 +367,7 @@ struct PassBArgs {
     float alpha;
     int zc;
     int z_lo, z_hi;  // planes produced by this launch
+    int z_lo2, z_hi2;  // optional second range (see PassAArgs)
     const uint32_t* prev_slots;
     float max_update_norm;
     // multi-GPU slab tiles: the fields are local slabs (d) that carry halo planes, phi_n is the whole volume (pd);
@@ -376,8 +391,10 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<SOBFU_SWIZZLE_B>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, (a.z_hi - a.z_lo + a.zc - 1) / a.zc);
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY, zb = a.z_lo + tid3.tz * a.zc, ze = min(zb + a.zc, a.z_hi);
+    const TileId tid3 = tile_of_block<SOBFU_SWIZZLE_B>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, z_chunks(a.z_lo, a.z_hi, a.zc) + z_chunks(a.z_lo2, a.z_hi2, a.zc));
+    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY;
+    int zb, ze;
+    chunk_range(tid3.tz, a.zc, a.z_lo, a.z_hi, a.z_lo2, a.z_hi2, zb, ze);
     const int x = x0 + lx, xc = min(x, d.x - 1);
     const size_t plane = (size_t) d.x * d.y;
 
@@ -823,14 +840,18 @@ int pick_zc(int X, int Y, int nz, int ty, int capacity, int refill, const char* 
 }
 
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
-                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo, int z_hi) {
+                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo, int z_hi,
+                  int z_lo2, int z_hi2) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    if (z_hi <= 0) { z_lo = 0; z_hi = Z; }
+    if (z_hi <= 0 && z_hi2 <= z_lo2) { z_lo = 0; z_hi = Z; }  // no range given: the whole grid
+    if (z_hi <= z_lo) { z_lo = z_lo2; z_hi = z_hi2; z_lo2 = z_hi2 = 0; }
     if (z_hi <= z_lo) return 0;
-    const int nz = z_hi - z_lo;
-    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 256 * 4, 2, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
-    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, z_lo, z_hi, prev_slots, max_update_norm};
-    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((nz + zc - 1) / zc));
+    const bool two = z_hi2 > z_lo2;
+    const int nz = std::max(z_hi - z_lo, two ? z_hi2 - z_lo2 : 0);  // the longer range sets the march length
+    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, (256 * 4) / (two ? 2 : 1), 2, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
+    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, z_lo, z_hi, z_lo2, z_hi2, prev_slots, max_update_norm};
+    const int nchunks = (z_hi - z_lo + zc - 1) / zc + (two ? (z_hi2 - z_lo2 + zc - 1) / zc : 0);
+    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * nchunks);
     if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
     else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
     return (int) hipGetLastError();
@@ -839,16 +860,19 @@ int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
                   float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo,
-                  int z_hi) {
+                  int z_hi, int z_lo2, int z_hi2) {
     if (phi_Z <= 0) { phi_Z = Z; own_lo = 0; own_hi = Z; }
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    if (z_hi <= 0) { z_lo = 0; z_hi = Z; }
+    if (z_hi <= 0 && z_hi2 <= z_lo2) { z_lo = 0; z_hi = Z; }  // no range given: the whole grid
+    if (z_hi <= z_lo) { z_lo = z_lo2; z_hi = z_hi2; z_lo2 = z_hi2 = 0; }
     if (z_hi <= z_lo) return 0;
-    const int nz = z_hi - z_lo;
-    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, 256 * 3, 6, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
-    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
+    const bool two = z_hi2 > z_lo2;
+    const int nz = std::max(z_hi - z_lo, two ? z_hi2 - z_lo2 : 0);
+    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, (256 * 3) / (two ? 2 : 1), 6, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
+    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, z_lo2, z_hi2, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
-    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((nz + zc - 1) / zc));
+    const int nchunks = (z_hi - z_lo + zc - 1) / zc + (two ? (z_hi2 - z_lo2 + zc - 1) / zc : 0);
+    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * nchunks);
 #define SOBFU_LAUNCH_B(UPD, CMP) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP>), grid, dim3(TX, SOBFU_WY), 0, stream, a)
     if (updates && compact) SOBFU_LAUNCH_B(true, true);

@@ -27,19 +27,8 @@
 #include "sobfu_device.hpp"
 #include "sobfu_hip.h"
 #include "sobfu_host.hpp"
+#include "sobfu_launch.hpp"
 
-namespace sobfu_hip {
-int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
-                  const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo, int z_hi);
-int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
-                  const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
-                  float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo,
-                  int z_hi);
-int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
-int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
-int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
-int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z);
-}  // namespace sobfu_hip
 
 namespace {
 
@@ -58,6 +47,7 @@ struct Rccl {
 } g_rccl;
 
 constexpr int kHalo = 4, kSlots = 256;
+constexpr int kSplitAMinPlanes = 48;  // interior planes below which pass A stays one launch (tools/slab_time_native.py)
 
 #define RCCL_TRY(expr)                                                                          \
     do {                                                                                        \
@@ -83,6 +73,9 @@ struct sobfu_hip_tiled {
     sobfu_hip_solver_params p;
     float taps[7];
     ncclComm_t comm = nullptr;
+    sobfu_hip_tiled_exchange_fn xfn = nullptr;    // transport of a communicator-less handle
+    sobfu_hip_tiled_allreduce_fn rfn = nullptr;
+    void* tctx = nullptr;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_red = nullptr;
     // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
@@ -149,7 +142,9 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
 int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
                            const sobfu_hip_solver_params* params) {
     SOBFU_CHECK_ARGS(out && params && unique_id && X > 1 && Y > 1 && Z > 1 && world >= 1 && rank >= 0 && rank < world);
-    if (!g_rccl.ok()) return SOBFU_E_RCCL;
+    bool dry = true;  // an all-zero id asks for a communicator-less handle: slab layout, kernels and stream choreography of
+    for (int i = 0; i < 128; ++i) dry = dry && unique_id[i] == 0;  // (world, rank); transport: sobfu_hip_tiled_set_transport
+    if (!dry && !g_rccl.ok()) return SOBFU_E_RCCL;
     if (Z < world * kHalo || params->s < 7) return SOBFU_E_UNSUPPORTED;
     auto* t = new sobfu_hip_tiled();
     t->X = X; t->Y = Y; t->Z = Z; t->world = world; t->rank = rank;
@@ -178,7 +173,7 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red, hipEventDisableTiming);
-    if (rc == 0) {
+    if (rc == 0 && !dry) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, 128);
         ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
@@ -192,6 +187,15 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
         return rc;
     }
     *out = t;
+    return 0;
+}
+
+int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_fn exchange_fn, sobfu_hip_tiled_allreduce_fn allreduce_fn,
+                                  void* ctx) {
+    SOBFU_CHECK_ARGS(t && !t->comm);
+    t->xfn = exchange_fn;
+    t->rfn = allreduce_fn;
+    t->tctx = ctx;
     return 0;
 }
 
@@ -209,6 +213,7 @@ int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, 
 // One grouped send/recv of `planes` owned planes per interior face of a 12-byte field (floats: 3 per voxel).
 static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t stream) {
     const size_t plane_f = (size_t) t->X * t->Y * 3, cnt = plane_f * planes;
+    if (!t->comm) return t->xfn ? t->xfn(t->tctx, t->rank, field3, planes, (void*) stream) : 0;  // user transport / dry handle
     RCCL_TRY(g_rccl.GroupStart());
     if (t->rank > 0) {
         RCCL_TRY(g_rccl.Send(field3 + plane_f * t->own_lo, cnt, ncclFloat32, t->rank - 1, t->comm, stream));
@@ -222,6 +227,12 @@ static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t s
     return 0;
 }
 
+static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_t stream) {
+    if (!t->comm) return t->rfn ? t->rfn(t->tctx, t->rank, buf, n, (void*) stream) : 0;
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, n, ncclUint32, ncclMax, t->comm, stream));
+    return 0;
+}
+
 // Debug / bring-up: exchange `planes` planes of a caller-provided 12-byte slab field exactly as the loop does.
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream) {
     SOBFU_CHECK_ARGS(t && d_field3 && planes > 0 && planes <= kHalo);
@@ -231,7 +242,7 @@ int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, vo
 // Bring-up self test usable with ONE rank: a world-1 communicator sends n floats from d_src to itself into d_dst through
 // the same group{send, recv} path the loop uses (RCCL allows self send/recv inside a group).
 int sobfu_hip_tiled_self_sendrecv(sobfu_hip_tiled* t, const float* d_src, float* d_dst, size_t n, void* stream) {
-    SOBFU_CHECK_ARGS(t && d_src && d_dst && n > 0);
+    SOBFU_CHECK_ARGS(t && t->comm && d_src && d_dst && n > 0);
     RCCL_TRY(g_rccl.GroupStart());
     RCCL_TRY(g_rccl.Send(d_src, n, ncclFloat32, t->rank, t->comm, (hipStream_t) stream));
     RCCL_TRY(g_rccl.Recv(d_dst, n, ncclFloat32, t->rank, t->comm, (hipStream_t) stream));
@@ -240,7 +251,7 @@ int sobfu_hip_tiled_self_sendrecv(sobfu_hip_tiled* t, const float* d_src, float*
 }
 
 int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_t n, void* stream) {
-    SOBFU_CHECK_ARGS(t && d_buf && n > 0);
+    SOBFU_CHECK_ARGS(t && t->comm && d_buf && n > 0);
     RCCL_TRY(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint32, ncclMax, t->comm, (hipStream_t) stream));
     return 0;
 }
@@ -279,43 +290,45 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const int a_lo = t->lo ? std::min(lo + H, hi) : lo, a_hi = t->hi ? std::max(hi - H, a_lo) : hi;
     const int b_lo = t->lo ? std::min(lo + 3, hi) : lo, b_hi = t->hi ? std::max(hi - 3, b_lo) : hi;
     const int b_first = t->lo ? lo - 1 : lo, b_last = t->hi ? hi + 1 : hi;
+    // pass A split into boundary + interior launches only when the interior is worth a launch of its own
+    const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
+    const bool split_a = (t->lo || t->hi) && a_hi > a_lo && (sa ? sa[0] == '1' : (a_hi - a_lo) >= kSplitAMinPlanes);
     for (int it = 1; it <= n_iters; ++it) {
         const uint32_t* prev_b = (it > 1 && can_converge) ? t->slots + (size_t) (it - 1) * kSlots : nullptr;
         const uint32_t* prev_a = (multi && !inline_reduce) ? nullptr : prev_b;  // pass A writes scratch only: no need to wait for the global max
         uint32_t* row          = t->slots + (size_t) it * kSlots;
-        auto A = [&](int za, int zb) {
-            return sobfu_hip::launch_pass_a(t->c_f, t->c_g, t->c_psi, t->nU, p.w_reg, X, Y, Lz, prev_a, p.max_update_norm, 0, st, true, za, zb);
+        auto A = [&](int za, int zb, int za2 = 0, int zb2 = 0) {
+            return sobfu_hip::launch_pass_a(t->c_f, t->c_g, t->c_psi, t->nU, p.w_reg, X, Y, Lz, prev_a, p.max_update_norm, 0, st, true, za, zb, za2, zb2);
         };
-        auto B = [&](int za, int zb) {
+        auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0) {
             return sobfu_hip::launch_pass_b(t->nU, t->c_psi, t->c_n, t->c_f, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev_b, p.max_update_norm,
-                                            0, st, Z, lo, hi, true, za, zb);
+                                            0, st, Z, lo, hi, true, za, zb, za2, zb2);
         };
-        if (a_lo > lo) SOBFU_TRY(A(lo, a_lo));
-        if (hi > a_hi) SOBFU_TRY(A(a_hi, hi));
+        // both boundary regions of a pass go out as ONE launch (two plane ranges); thin slabs skip the A split entirely
+        // (one pass A launch, the exchange then overlaps pass B's interior only)
+        if (split_a) SOBFU_TRY(A(lo, a_lo, a_hi, hi));
+        else SOBFU_TRY(A(lo, hi));
         if (multi) {
             SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
             if (prev_b && !inline_reduce) {  // row it-1 is complete (B of it-1 precedes A_bnd on `st`): make it the global max
-                RCCL_TRY(g_rccl.AllReduce((void*) prev_b, (void*) prev_b, kSlots, ncclUint32, ncclMax, t->comm, t->comm_stream));
+                SOBFU_TRY(allreduce_max(t, const_cast<uint32_t*>(prev_b), kSlots, t->comm_stream));
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
             }
             SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
         }
-        if (a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
+        if (split_a && a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
         if (multi && prev_b && !inline_reduce) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
         if (b_hi > b_lo) SOBFU_TRY(B(b_lo, b_hi));
         if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
-        if (b_lo > b_first) SOBFU_TRY(B(b_first, b_lo));
-        if (b_last > b_hi) SOBFU_TRY(B(b_hi, b_last));
-        if (multi && can_converge && (inline_reduce || it == n_iters))
-            RCCL_TRY(g_rccl.AllReduce(row, row, kSlots, ncclUint32, ncclMax, t->comm, st));
+        if (b_lo > b_first || b_last > b_hi) SOBFU_TRY(B(b_first, b_lo, b_hi, b_last));
+        if (multi && can_converge && (inline_reduce || it == n_iters)) SOBFU_TRY(allreduce_max(t, row, kSlots, st));
         // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
     }
-    if (multi && !can_converge && n_iters > 0)
-        RCCL_TRY(g_rccl.AllReduce(t->slots + kSlots, t->slots + kSlots, (size_t) n_iters * kSlots, ncclUint32, ncclMax, t->comm, st));
+    if (multi && !can_converge && n_iters > 0) SOBFU_TRY(allreduce_max(t, t->slots + kSlots, (size_t) n_iters * kSlots, st));
     // leave the compact format: psi.xyz back, phi_n o psi = apply(phi_n, psi) (the state of solver.cu:168)
     SOBFU_TRY(sobfu_hip::launch_unpack_vec(t->c_psi, d_psi_local, t->NL, st));
     SOBFU_TRY(sobfu_hip_tile_apply(d_phi_n_full, Z, d_phi_n_psi_local, d_psi_local, X, Y, Lz, st));

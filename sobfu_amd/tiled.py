@@ -294,7 +294,9 @@ class NativeTiledSolver:
     a dedicated communication stream, overlapped with the interior compute, no Python per iteration.  torch.distributed is
     used once, to hand the RCCL unique id to every rank."""
 
-    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, group=None):
+    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, group=None, dry=None):
+        """dry=(world, rank): a communicator-less handle with that slab layout -- every launch and stream dependency of the
+        rank's schedule without peers (halos are stale, so only its TIMING means anything; tools/slab_time_native.py)."""
         import os
 
         from . import _lib
@@ -307,9 +309,11 @@ class NativeTiledSolver:
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         _lib.check(L.sobfu_hip_tiled_load_rccl(path.encode()), "tiled_load_rccl")
         uid = (C.c_char * 128)()
-        if self.rank == 0:
+        if dry is not None:
+            self.world, self.rank = dry
+        elif self.rank == 0:
             _lib.check(L.sobfu_hip_tiled_unique_id(uid), "tiled_unique_id")
-        if self.world > 1:
+        if self.world > 1 and dry is None:
             box = [bytes(uid)]
             dist.broadcast_object_list(box, src=0, group=group)
             uid = (C.c_char * 128).from_buffer_copy(box[0])
@@ -323,6 +327,15 @@ class NativeTiledSolver:
         got = tuple(x.value for x in v)
         want = (self.layout.z0, self.layout.z1, self.layout.lo, self.layout.hi, self.layout.Lz, self.layout.zbase)
         assert got == want, (got, want)
+
+    EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+    ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+    def set_transport(self, exchange, allreduce_max):
+        """communicator-less (dry) handles only: callables (rank, field_ptr, planes, stream) / (rank, buf_ptr, n, stream) -> 0"""
+        self._cb = (self.EXCHANGE_FN(lambda ctx, r, f, p, st: exchange(r, f, p, st)),
+                    self.ALLREDUCE_FN(lambda ctx, r, b, n, st: allreduce_max(r, b, n, st)))
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_set_transport(self._h, self._cb[0], self._cb[1], None), "tiled_set_transport")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,142 @@
+"""N ranks of the NATIVE tiled loop (sobfu_hip_tiled_iterate) on ONE GPU: communicator-less handles, one host thread per
+rank, and an in-process loopback transport (device-to-device copies between the ranks' slabs + a host max) plugged in
+through sobfu_hip_tiled_set_transport.  Everything but RCCL itself -- slab layout, boundary / interior plane ranges, the
+two-range boundary launches, halo widths, ungated pass A, stream and event order -- runs exactly as on N GPUs, and the
+gathered result must equal the single-GPU solve bit for bit."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Loopback:
+    def __init__(self, solvers, X, Y):
+        self.sv, self.N, self.pb = solvers, len(solvers), X * Y * 12
+        self.bar = threading.Barrier(self.N)
+        self.ptr, self.host = [None] * self.N, [None] * self.N
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def _ok(self, rc):
+        if rc != 0:
+            self.bar.abort()
+            raise RuntimeError(f"hip call failed: {rc}")
+
+    def exchange(self, rank, field, planes, stream):
+        try:
+            self._ok(self.hip.hipStreamSynchronize(stream))  # this rank's boundary planes are final
+            self.ptr[rank] = field
+            self.bar.wait(timeout=60)
+            L, n = self.sv[rank].layout, planes * self.pb
+            if rank > 0:
+                Lp = self.sv[rank - 1].layout
+                self._ok(self.hip.hipMemcpy(field + (L.own_lo - planes) * self.pb, self.ptr[rank - 1] + (Lp.own_hi - planes) * self.pb, n, 3))
+            if rank < self.N - 1:
+                Ln = self.sv[rank + 1].layout
+                self._ok(self.hip.hipMemcpy(field + L.own_hi * self.pb, self.ptr[rank + 1] + Ln.own_lo * self.pb, n, 3))
+            self._ok(self.hip.hipDeviceSynchronize())
+            self.bar.wait(timeout=60)  # nobody overwrites planes a peer is still copying
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("loopback exchange failed:", e, flush=True)
+            return -1
+
+    def allreduce(self, rank, buf, n, stream):
+        try:
+            self._ok(self.hip.hipStreamSynchronize(stream))
+            h = np.empty(n, np.uint32)
+            self._ok(self.hip.hipMemcpy(h.ctypes.data, buf, 4 * n, 2))
+            self.host[rank] = h
+            self.bar.wait(timeout=60)
+            m = np.maximum.reduce([x for x in self.host])
+            self.bar.wait(timeout=60)
+            self._ok(self.hip.hipMemcpy(buf, m.ctypes.data, 4 * n, 1))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("loopback allreduce failed:", e, flush=True)
+            return -1
+
+
+def run_world(dims, world, psi0, pg, pn, n_iters, thr):
+    import torch
+
+    from sobfu_amd import tiled
+
+    X, Y, Z = dims
+    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr, dry=(world, r)) for r in range(world)]
+    lb = Loopback(solvers, X, Y)
+    for s in solvers:
+        s.set_transport(lb.exchange, lb.allreduce)
+    pn_d = torch.from_numpy(pn).cuda()
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            s = solvers[r]
+            L = s.layout
+            with torch.cuda.stream(torch.cuda.Stream()):
+                pg_l = torch.from_numpy(np.ascontiguousarray(L.take(pg))).cuda()
+                psi_l = torch.from_numpy(np.ascontiguousarray(L.take(psi0))).cuda()
+                pnp_l = s.new_local(2)
+                done, hist = s.iterate(pg_l, pn_d, pnp_l, psi_l, n_iters)
+                torch.cuda.current_stream().synchronize()
+            out[r] = (done, hist, L.owned(psi_l).cpu().numpy(), L.owned(pnp_l).cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+            lb.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    for s in solvers:
+        s.close()
+    return out
+
+
+@pytest.mark.parametrize("dims,world,split", [((40, 24, 36), 3, None), ((40, 24, 36), 3, "1"), ((33, 17, 16), 4, None), ((20, 12, 120), 2, None),
+                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0")])
+def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
+    import torch
+
+    import oracle
+    from sobfu_amd import ops
+
+    if split is not None:
+        monkeypatch.setenv("SOBFU_TILED_SPLIT_A", split)
+    rng = np.random.default_rng(5)
+    X, Y, Z = dims
+    pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    psi0 = oracle.new_field(dims)
+    oracle.init_identity(psi0)
+    psi0[..., :3] += rng.uniform(-0.7, 0.7, psi0[..., :3].shape).astype(np.float32)
+    n_iters = 6
+    ref = ops.Solver(dims, max_iter=n_iters, alpha=0.05, w_reg=0.4)
+    psi_r, pnp_r = torch.from_numpy(psi0.copy()).cuda(), ops.new_volume(dims)
+    _, hist_r = ref.iterate(torch.from_numpy(pg).cuda(), torch.from_numpy(pn).cuda(), pnp_r, psi_r, n_iters)
+    ref.close()
+    for thr, expect in ((-1.0, n_iters), (1e-10, n_iters), (float(hist_r[2]), 3)):
+        if expect < n_iters:
+            a = ops.Solver(dims, max_iter=n_iters, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+            psi_e, pnp_e = torch.from_numpy(psi0.copy()).cuda(), ops.new_volume(dims)
+            rep, _ = a.iterate(torch.from_numpy(pg).cuda(), torch.from_numpy(pn).cuda(), pnp_e, psi_e, n_iters)
+            a.close()
+            assert rep.iterations == expect
+        else:
+            psi_e, pnp_e = psi_r, pnp_r
+        out = run_world(dims, world, psi0, pg, pn, n_iters, thr)
+        psi_t = np.concatenate([o[2] for o in out], 0)
+        pnp_t = np.concatenate([o[3] for o in out], 0)
+        for done, hist, _, _ in out:
+            assert done == expect
+            assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), np.asarray(hist_r[:expect], np.float32).view(np.uint32))
+        assert np.array_equal(psi_t[..., :3].view(np.uint32), psi_e.cpu().numpy()[..., :3].view(np.uint32))
+        assert np.array_equal(pnp_t.view(np.uint32), pnp_e.cpu().numpy().view(np.uint32))
