@@ -77,7 +77,7 @@ struct sobfu_hip_tiled {
     sobfu_hip_tiled_allreduce_fn rfn = nullptr;
     void* tctx = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_red = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_row = nullptr, ev_red = nullptr;
     // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
     float *nU = nullptr, *c_psi = nullptr, *c_f = nullptr, *c_g = nullptr, *c_n = nullptr;
     uint32_t* slots = nullptr;
@@ -133,6 +133,7 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
     if (t->ev_red) (void) hipEventDestroy(t->ev_red);
+    if (t->ev_row) (void) hipEventDestroy(t->ev_row);
     if (t->comm_stream) (void) hipStreamDestroy(t->comm_stream);
     if (t->comm && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm);
     delete t;
@@ -173,6 +174,7 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red, hipEventDisableTiming);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_row, hipEventDisableTiming);
     if (rc == 0 && !dry) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, 128);
@@ -311,7 +313,7 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         if (multi) {
             SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
-            if (prev_b && !inline_reduce) {  // row it-1 is complete (B of it-1 precedes A_bnd on `st`): make it the global max
+            if (prev_b && !inline_reduce && split_a) {  // row it-1 is complete (B of it-1 precedes A_bnd on `st`): make it the global max
                 SOBFU_TRY(allreduce_max(t, const_cast<uint32_t*>(prev_b), kSlots, t->comm_stream));
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
             }
@@ -323,7 +325,16 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         if (b_hi > b_lo) SOBFU_TRY(B(b_lo, b_hi));
         if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
         if (b_lo > b_first || b_last > b_hi) SOBFU_TRY(B(b_first, b_lo, b_hi, b_last));
-        if (multi && can_converge && (inline_reduce || it == n_iters)) SOBFU_TRY(allreduce_max(t, row, kSlots, st));
+        if (multi && can_converge && (inline_reduce || it == n_iters)) {
+            SOBFU_TRY(allreduce_max(t, row, kSlots, st));
+        } else if (multi && can_converge && !split_a) {
+            // unsplit pass A (thin slabs): there is no A_int to hide a comm-stream round trip behind, so the reduction of THIS
+            // row starts now and runs beside the whole of the next pass A
+            SOBFU_HIP_TRY(hipEventRecord(t->ev_row, st));
+            SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_row, 0));
+            SOBFU_TRY(allreduce_max(t, row, kSlots, t->comm_stream));
+            SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
+        }
         // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd

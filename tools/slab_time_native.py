@@ -10,7 +10,7 @@ P = bench.boxing_params(256); dims = P["dims"]; X, Y, Z = dims
 c0, c1, r = bench.sphere_pair(P)
 pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
 ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r); ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("SLAB_WORLDS", "1,2,4,8").split(",")]:
     for thr in (-1.0, 1e-10):
         sv = tiled.NativeTiledSolver(dims, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=thr, dry=(world, world // 2))
         L = sv.layout
