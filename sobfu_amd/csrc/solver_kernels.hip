@@ -123,6 +123,32 @@ SOBFU_DEV void stv(void* base, size_t i, const float4& v) {
         ((float4*) base)[i] = v;
     }
 }
+// streaming variants (nontemporal hint) for data a launch touches exactly once: they should not displace the lines that
+// neighbouring workgroups re-read from the XCD's L2 (nabla_U halo rows, phi_n corners)
+#ifndef SOBFU_NT
+#define SOBFU_NT 3  // 1 = pass B stores of psi / phi_n o psi, 2 = + pass B load of psi, 3 = + pass A load of phi_global (4: + nabla_U store, 5: + pass A inner rows: A slower, B faster, no net gain)
+#endif
+template <bool C>
+SOBFU_DEV float4 ldv_nt(const void* base, size_t i) {
+    if (C) {
+        v3f v = __builtin_nontemporal_load((const v3f_u*) ((const float*) base + 3 * i));
+        return make_float4(v.x, v.y, v.z, 0.f);
+    }
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f v = __builtin_nontemporal_load((const v4f*) base + i);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool C>
+SOBFU_DEV void stv_nt(void* base, size_t i, const float4& v) {
+    if (C) {
+        v3f o = {v.x, v.y, v.z};
+        __builtin_nontemporal_store(o, (v3f_u*) ((float*) base + 3 * i));
+    } else {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f o = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(o, (v4f*) base + i);
+    }
+}
 template <bool C>
 SOBFU_DEV float ldt(const void* base, size_t i) {  // tsdf of voxel i
     return C ? ((const float*) base)[i] : ((const float2*) base)[i].x;
@@ -288,9 +314,14 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
         float bg[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            pn[r] = ldv<COMPACT>(a.psi, zn + off[r]);
-            fn[r] = ldt<COMPACT>(a.pnp, zn + off[r]);
-            bg[r] = ldt<COMPACT>(a.pg, zcur + off[r]);
+            if (SOBFU_NT >= 5 && COMPACT && RPT == 1 && wy > 0 && wy < WY - 1) {  // rows no y-neighbour tile re-reads
+                pn[r] = ldv_nt<COMPACT>(a.psi, zn + off[r]);
+                fn[r] = __builtin_nontemporal_load((const float*) a.pnp + zn + off[r]);
+            } else {
+                pn[r] = ldv<COMPACT>(a.psi, zn + off[r]);
+                fn[r] = ldt<COMPACT>(a.pnp, zn + off[r]);
+            }
+            bg[r] = (SOBFU_NT >= 3 && COMPACT) ? __builtin_nontemporal_load((const float*) a.pg + zcur + off[r]) : ldt<COMPACT>(a.pg, zcur + off[r]);
         }
         if (z + 1 < ze) {
 #pragma unroll
@@ -341,7 +372,10 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
             // calculate_potential_gradient_kernel (solver.cu:28-31)
             float diff = fc[r] - bg[r];
             float4 o   = add4(mul4(g, diff), mul4(L, a.w_reg));
-            if (x < d.x && y < d.y) stv<COMPACT>(a.nU, zcur + (size_t) x + (size_t) d.x * y, o);
+            if (x < d.x && y < d.y) {
+                if (SOBFU_NT >= 4) stv_nt<COMPACT>(a.nU, zcur + (size_t) x + (size_t) d.x * y, o);
+                else stv<COMPACT>(a.nU, zcur + (size_t) x + (size_t) d.x * y, o);
+            }
         }
         // shift the z pipeline
 #pragma unroll
@@ -451,7 +485,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         const size_t zcur = (size_t) z * plane;
         float4 pv[RPT], nq[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) pv[r] = ldv<COMPACT>(a.psi, zcur + off[r]);
+        for (int r = 0; r < RPT; ++r) pv[r] = SOBFU_NT >= 2 ? ldv_nt<COMPACT>(a.psi, zcur + off[r]) : ldv<COMPACT>(a.psi, zcur + off[r]);
         if (z + 1 < ze) {
             const size_t z4 = (size_t) min(z + 4, d.z - 1) * plane, z1 = (size_t) (z + 1) * plane;
 #pragma unroll
@@ -504,10 +538,12 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             if (x < d.x && y < d.y) {
                 if (z >= a.own_lo && z < a.own_hi) msq = fmaxf(msq, norm_sq4(u));
                 const size_t i = zcur + (size_t) x + (size_t) d.x * y;
-                stv<COMPACT>(a.psi, i, p);
+                if (SOBFU_NT >= 1) stv_nt<COMPACT>(a.psi, i, p);
+                else stv<COMPACT>(a.psi, i, p);
                 if (WRITE_UPDATES) a.updates[i] = u;
                 // apply_kernel (vector_fields.cu:95-98)
-                if (COMPACT) ((float*) a.pnp)[i] = interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
+                if (COMPACT && SOBFU_NT >= 1) __builtin_nontemporal_store(interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z), (float*) a.pnp + i);
+                else if (COMPACT) ((float*) a.pnp)[i] = interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
                 else ((float2*) a.pnp)[i] = interp_tsdf((const float2*) a.phi_n, a.pd, p.x, p.y, p.z);
             }
         }
