@@ -1,7 +1,8 @@
 // sobfu_headless -- headless counterpart of the reference app's frame loop (src/apps/demo.cpp:285-340) on the MI355X
 // shells: reads a params .ini, feeds depth frames to SobFusion::operator(), prints per-frame volume statistics and can
-// dump the fields.  No OpenCV / PCL / VTK: depth frames are binary 16-bit PGM ("P5", maxval 65535, big-endian) or raw
-// little-endian uint16 files of rows*cols pixels, or a built-in synthetic translating sphere.
+// dump the fields.  No OpenCV / PCL / VTK: depth frames are 16-bit grayscale PNG (what the reference's datasets ship),
+// binary 16-bit PGM or raw little-endian uint16 files of rows*cols pixels (sobfu_amd/depth_io.hpp), or a built-in
+// synthetic translating sphere.  --dump DIR writes psi, psi_inv and the four TSDF volumes as .npy (float32).
 //
 //   sobfu_headless <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR]
 //                  (--synthetic FRAMES [--shift DX] | frame0.pgm frame1.pgm ...)
@@ -11,29 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <sobfu_amd/depth_io.hpp>
 #include <sobfu_amd/sobfu.hpp>
-
-static bool load_depth(const std::string& path, int rows, int cols, std::vector<uint16_t>& out) {
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    out.assign((size_t) rows * cols, 0);
-    char magic[3] = {0, 0, 0};
-    bool ok = false;
-    if (std::fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && magic[1] == '5') {
-        int w = 0, h = 0, maxv = 0;
-        if (std::fscanf(f, "%d %d %d", &w, &h, &maxv) == 3 && w == cols && h == rows && maxv > 255) {
-            std::fgetc(f);
-            std::vector<unsigned char> b((size_t) rows * cols * 2);
-            ok = std::fread(b.data(), 1, b.size(), f) == b.size();
-            for (size_t i = 0; ok && i < out.size(); ++i) out[i] = (uint16_t) ((b[2 * i] << 8) | b[2 * i + 1]);
-        }
-    } else {
-        std::rewind(f);
-        ok = std::fread(out.data(), 2, out.size(), f) == out.size();
-    }
-    std::fclose(f);
-    return ok;
-}
 
 // uint16 mm depth of a sphere, same convention as sobfu_amd/synthetic.py::render_sphere_depth (float64, rint)
 static void render_sphere(double cx, double cy, double cz, double r, const kfusion::Intr& in, int rows, int cols, std::vector<uint16_t>& out) {
@@ -96,11 +76,21 @@ int main(int argc, char** argv) {
     const int nframes = synthetic > 0 ? synthetic : (int) files.size();
     std::vector<uint16_t> img;
     kfusion::cuda::Depth depth;
+    double time_ms = 0.0;
     for (int n = 0; n < nframes; ++n) {
         if (synthetic > 0) render_sphere(shift * n, 0.0, 0.75, 0.1, p.intr, p.rows, p.cols, img);
-        else if (!load_depth(files[n], p.rows, p.cols, img)) { std::printf("cannot read depth frame %s\n", files[n].c_str()); return 2; }
+        else {
+            std::string why;
+            if (!sobfu_amd::read_depth(files[n], p.rows, p.cols, img, &why)) {
+                std::printf("cannot read depth frame %s: %s\n", files[n].c_str(), why.c_str());
+                return 2;
+            }
+        }
         depth.upload(img.data(), (size_t) p.cols * sizeof(uint16_t), p.rows, p.cols);  // demo.cpp:327-329
-        fusion(depth);
+        {
+            kfusion::SampledScopeTime fps(time_ms);  // demo.cpp:331 -- "avg. frame time" every 34 frames
+            fusion(depth);
+        }
         stats("phi_global", *fusion.phi_global);
         if (n > 0) {
             stats("phi_n", *fusion.phi_n);
@@ -112,17 +102,25 @@ int main(int argc, char** argv) {
             }
         }
     }
-    if (!dump.empty() && fusion.psi) {  // raw little-endian float32 dumps (replaces the reference's commented-out .vti writer)
+    if (!dump.empty() && fusion.psi) {  // .npy dumps (replace the reference's commented-out .vti writer, demo.cpp:252-283)
         cv::Vec3i d = p.volume_dims;
-        size_t n = (size_t) d[0] * d[1] * d[2];
+        const size_t n = (size_t) d[0] * d[1] * d[2], Z = (size_t) d[2], Y = (size_t) d[1], X = (size_t) d[0];
         std::vector<float4> h(n);
-        fusion.psi->get_data().download(h.data());
-        FILE* f = std::fopen((dump + "/psi.f32").c_str(), "wb");
-        if (f) { std::fwrite(h.data(), sizeof(float4), n, f); std::fclose(f); }
         std::vector<float2> t(n);
-        fusion.phi_global->data().download(t.data());
-        f = std::fopen((dump + "/phi_global.f32").c_str(), "wb");
-        if (f) { std::fwrite(t.data(), sizeof(float2), n, f); std::fclose(f); }
+        auto field = [&](const char* name, sobfu::cuda::DeformationField& f) {
+            f.get_data().download(h.data());
+            if (!sobfu_amd::write_npy(dump + "/" + name + ".npy", (const float*) h.data(), {Z, Y, X, 4})) std::printf("cannot write %s\n", name);
+        };
+        auto volume = [&](const char* name, kfusion::cuda::TsdfVolume& v) {
+            v.data().download(t.data());
+            if (!sobfu_amd::write_npy(dump + "/" + name + ".npy", (const float*) t.data(), {Z, Y, X, 2})) std::printf("cannot write %s\n", name);
+        };
+        field("psi", *fusion.psi);
+        if (fusion.psi_inv) field("psi_inv", *fusion.psi_inv);
+        volume("phi_global", *fusion.phi_global);
+        if (fusion.phi_n) volume("phi_n", *fusion.phi_n);
+        if (fusion.phi_n_psi) volume("phi_n_psi", *fusion.phi_n_psi);
+        if (fusion.phi_global_psi_inv) volume("phi_global_psi_inv", *fusion.phi_global_psi_inv);
     }
     return 0;
 }

@@ -24,9 +24,11 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -141,6 +143,40 @@ struct Params {
 };
 
 namespace kfusion {
+
+// ---- ScopeTime / SampledScopeTime (include/kfusion/types.hpp:101-122, src/kfusion/core.cpp:214-234) ---------------
+// Same console lines as the reference ("Time(name) = X ms", and every 34th sampled scope "avg. frame time = ...ms
+// (...fps)"); the tick source is std::chrono::steady_clock instead of cv::getTickCount.
+struct ScopeTime {
+    const char* name;
+    double start;
+    static double now_ms() {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    explicit ScopeTime(const char* name_) : name(name_), start(now_ms()) {}
+    ~ScopeTime() { std::cout << "Time(" << name << ") = " << now_ms() - start << "ms" << std::endl; }
+};
+
+struct SampledScopeTime {
+    enum { EACH = 34 };
+    explicit SampledScopeTime(double& time_ms) : time_ms_(time_ms), start(ScopeTime::now_ms()) {}
+    ~SampledScopeTime() {
+        static int scopes = 0;  // one counter for the process, like the reference's function-local static
+        time_ms_ += ScopeTime::now_ms() - start;
+        if (scopes % EACH == 0 && scopes) {
+            std::cout << "avg. frame time = " << time_ms_ / EACH << "ms (" << 1000.f * EACH / time_ms_ << "fps)" << std::endl;
+            time_ms_ = 0.0;
+        }
+        ++scopes;
+    }
+    SampledScopeTime(const SampledScopeTime&) = delete;
+    SampledScopeTime& operator=(const SampledScopeTime&) = delete;
+
+private:
+    double& time_ms_;
+    double start;
+};
+
 namespace cuda {
 
 inline void setDevice(int device) { sobfuSafeCall(hipSetDevice(device)); }
@@ -149,6 +185,24 @@ inline void printShortCudaDeviceInfo(int device) {
     hipDeviceProp_t p;
     sobfuSafeCall(hipGetDeviceProperties(&p, device));
     std::printf("[%s] %d CUs, %.1f GB\n", p.name, p.multiProcessorCount, p.totalGlobalMem / 1e9);
+}
+// remaining device queries of include/kfusion/kinfu.hpp:25-30, answered by the HIP runtime
+inline int getCudaEnabledDeviceCount() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+inline std::string getDeviceName(int device) {
+    hipDeviceProp_t p;
+    sobfuSafeCall(hipGetDeviceProperties(&p, device));
+    return p.name;
+}
+inline bool checkIfPreFermiGPU(int) { return false; }  // the demo's "GPU too old" gate (demo.cpp:575): never true on CDNA
+inline void printCudaDeviceInfo(int device) {
+    hipDeviceProp_t p;
+    sobfuSafeCall(hipGetDeviceProperties(&p, device));
+    std::printf("Device %d: \"%s\" (%s)\n  compute units %d, wavefront %d, clock %.0f MHz\n  global memory %.1f GB, L2 %d KB, LDS per workgroup %zu KB\n",
+                device, p.name, p.gcnArchName, p.multiProcessorCount, p.warpSize, p.clockRate / 1e3, p.totalGlobalMem / 1e9,
+                p.l2CacheSize / 1024, p.sharedMemPerBlock / 1024);
 }
 
 // ---- DeviceMemory: ref-counted hipMalloc blob (include/kfusion/cuda/device_memory.hpp:20-102) -------------------

@@ -647,6 +647,9 @@ __global__ void __launch_bounds__(TX* FY, SOBFU_MINW_F) fused_iteration_kernel(F
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y, tid = wy * TX + lx;
+#ifndef SOBFU_NT_F
+#define SOBFU_NT_F 1  // streaming stores of psi_out / f_out (the next iteration reads them; this one never does)
+#endif
 #ifndef SOBFU_SWIZZLE_F
 #define SOBFU_SWIZZLE_F true  // XCD-aware tile map: halo re-reads hit the XCD's L2 (279 -> 271 us at 256^3)
 #endif
@@ -783,8 +786,13 @@ __global__ void __launch_bounds__(TX* FY, SOBFU_MINW_F) fused_iteration_kernel(F
             if (m_in) {
                 msq = fmaxf(msq, norm_sq4(u));
                 const uint32_t i = (uint32_t) z * plane + (uint32_t) x + (uint32_t) d.x * y;
-                stv<true>(a.psi_out, i, pnew);
-                a.f_out[i] = interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z);
+                if (SOBFU_NT_F) {
+                    stv_nt<true>(a.psi_out, i, pnew);
+                    __builtin_nontemporal_store(interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z), a.f_out + i);
+                } else {
+                    stv<true>(a.psi_out, i, pnew);
+                    a.f_out[i] = interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z);
+                }
             }
         }
         // (5) advance the pipelines

@@ -63,3 +63,37 @@ def test_start_frame_gating_and_unknown_keys(tmp_path):
     assert out.count("solver: iterations=3") == 1          # only frame 2 runs the solver
     pg = _stats(out, "phi_global")
     assert pg[1][1] > pg[0][1] and pg[2][1] > pg[1][1]     # weights accumulate on every frame
+
+
+def test_png_frames_and_npy_dumps(tmp_path):
+    """The same two frames as 16-bit PNG files (what the reference's datasets ship): identical output to the built-in renderer;
+    --dump writes loadable .npy fields whose statistics match the printed ones."""
+    import numpy as np
+
+    from sobfu_amd import synthetic
+    from test_depth_io import png_bytes
+
+    ini = os.path.join(ROOT, "params", "config1_sphere_64.ini")
+    ref = _run(ini, "--synthetic", "2", "--max-iter", "4")
+    intr = (570.342, 570.342, 320.0, 240.0)
+    files = []
+    for n in range(2):
+        d = synthetic.render_sphere_depth((0.005 * n, 0.0, 0.75), 0.1, intr, 480, 640)
+        p = tmp_path / f"frame{n}.png"
+        p.write_bytes(png_bytes(d, [4, 1, 2] if n else [0]))
+        files.append(str(p))
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    out = _run(ini, "--max-iter", "4", "--dump", str(dump), *files)
+    strip = lambda s: [l for l in s.splitlines() if l.startswith(("phi_", "solver:"))]  # noqa: E731
+    assert strip(out) == strip(ref)
+    psi, psi_inv = np.load(dump / "psi.npy"), np.load(dump / "psi_inv.npy")
+    assert psi.shape == (64, 64, 64, 4) and psi_inv.shape == psi.shape and psi.dtype == np.float32
+    z, y, x = np.meshgrid(np.arange(64), np.arange(64), np.arange(64), indexing="ij")
+    assert float(np.abs(psi[..., 0] - x).max()) < 2.0 and float(np.abs(psi[..., 0] - x).max()) > 1e-3
+    assert float(np.abs(psi[..., 3]).max()) == 0.0
+    pg = np.load(dump / "phi_global.npy")
+    s = _stats(out, "phi_global")[-1]
+    assert pg.shape == (64, 64, 64, 2) and abs(float(pg[..., 0].astype(np.float64).sum()) - s[0]) < 1e-2 and float(pg[..., 1].sum()) == s[1]
+    for name in ("phi_n", "phi_n_psi", "phi_global_psi_inv"):
+        assert np.load(dump / f"{name}.npy").shape == (64, 64, 64, 2)
