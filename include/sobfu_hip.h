@@ -246,6 +246,23 @@ typedef void (*sobfu_hip_log_fn)(const char* line, void* user);
 int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* user);
 
 /* ------------------------------------------------------------------------------------------------------
+ * marching cubes -- include/kfusion/internal.hpp:213-225, src/kfusion/cuda/marching_cubes.cu
+ * `occupied`: 3 rows of `stride` ints on the device -- voxel index, vertex count, vertex offset (the reference's
+ * DeviceArray2D<int>(3, cols)).  Unlike the reference (atomic append, run-dependent order) cells come out in ascending
+ * voxel-index order.  Vertices / normals are float4 (x, -y, -z, 1), three per triangle, one normal per triangle.
+ * ---------------------------------------------------------------------------------------------------- */
+/* getOccupiedVoxels (marching_cubes.cu:143-163): rows 0 and 1; *h_count = min(active cells, max_size).  Synchronises. */
+int sobfu_hip_mc_occupied_voxels(void* stream, const float* d_vol, int X, int Y, int Z, int* d_occupied, int stride, int max_size,
+                                 int* h_count);
+/* computeOffsetsAndTotalVertices (marching_cubes.cu:165-181): row 2 = exclusive scan of row 1.  Synchronises. */
+int sobfu_hip_mc_offsets(void* stream, int* d_occupied, int stride, int count, int* h_total_vertices);
+/* generateTriangles (marching_cubes.cu:275-313); pose = volume -> world (R row-major, t).  Triangles that would end beyond
+ * max_vertices are dropped (the reference does not check). */
+int sobfu_hip_mc_generate_triangles(void* stream, const float* d_vol, int X, int Y, int Z, const int* d_occupied, int stride, int count,
+                                    float size_x, float size_y, float size_z, const float R[9], const float t[3], float* d_vertices,
+                                    float* d_normals, int max_vertices);
+
+/* ------------------------------------------------------------------------------------------------------
  * native multi-GPU loop: one rank per z-slab, RCCL halo exchange issued from C++ and overlapped with the interior
  * compute (no reference counterpart; schedule documented in sobfu_amd/tiled.py)
  * ---------------------------------------------------------------------------------------------------- */

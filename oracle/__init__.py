@@ -281,3 +281,44 @@ def num_threads():
 
 def set_num_threads(n):
     lib().so_set_num_threads(C.c_int(n))
+
+
+# ---- marching cubes (parity unpinned; see the block comment in sobfu_oracle.c) -------------------------------------
+def mc_num_verts(cube):
+    lib().so_mc_num_verts.restype = C.c_int
+    return int(lib().so_mc_num_verts(C.c_int(int(cube))))
+
+
+def mc_occupied_voxels(vol, max_size):
+    """-> (occupied int32 (3, max_size): voxel index / vertex count / vertex offset rows, count)"""
+    occ = np.zeros((3, int(max_size)), np.int32)
+    lib().so_mc_occupied_voxels.restype = C.c_int
+    n = lib().so_mc_occupied_voxels(_p(vol), *_dims(vol), _p(occ), C.c_int(occ.shape[1]), C.c_int(int(max_size)))
+    return occ, int(n)
+
+
+def mc_offsets(occ, count):
+    lib().so_mc_offsets.restype = C.c_int
+    return int(lib().so_mc_offsets(_p(occ), C.c_int(occ.shape[1]), C.c_int(int(count))))
+
+
+def mc_generate_triangles(vol, occ, count, volume_size, R, t, max_vertices):
+    """-> (vertices, normals) float32 (max_vertices, 4); rows past the total stay zero"""
+    v, n = np.zeros((int(max_vertices), 4), np.float32), np.zeros((int(max_vertices), 4), np.float32)
+    R = np.ascontiguousarray(R, np.float32).reshape(9)
+    t = np.ascontiguousarray(t, np.float32).reshape(3)
+    lib().so_mc_generate_triangles(_p(vol), *_dims(vol), _p(occ), C.c_int(occ.shape[1]), C.c_int(int(count)), _f(volume_size[0]),
+                                   _f(volume_size[1]), _f(volume_size[2]), _p(R), _p(t), _p(v), _p(n), C.c_int(int(max_vertices)))
+    return v, n
+
+
+def marching_cubes(vol, volume_size, R=np.eye(3), t=(0, 0, 0), max_voxels=None, max_vertices=None):
+    """kfusion::cuda::MarchingCubes::run (src/kfusion/marching_cubes.cpp:23-79) -> (vertices (n, 4), normals (n, 4))"""
+    max_voxels = max_voxels or 2_000_000
+    max_vertices = max_vertices or 3 * max_voxels
+    occ, count = mc_occupied_voxels(vol, max_voxels)
+    if count == 0:
+        return np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)
+    total = min(mc_offsets(occ, count), max_vertices // 3 * 3)  # whole triangles only
+    v, n = mc_generate_triangles(vol, occ, count, volume_size, R, t, max_vertices)
+    return v[:total], n[:total]

@@ -709,3 +709,113 @@ void so_set_num_threads(int n) {
     (void) n;
 #endif
 }
+
+/* ================================================================================================
+ * marching cubes -- src/kfusion/cuda/marching_cubes.cu, src/kfusion/marching_cubes.cpp
+ *
+ * PARITY UNPINNED for this block: the reference's tests and SURVEY Appendix B hold no marching-cubes numbers.  Arithmetic
+ * follows the oracle conventions of the rest of this file (IEEE / and sqrt, rsqrt(x) = 1/sqrt(x), no contraction of
+ * plain a*b+c, explicit fma only where the reference writes one: dot(), Aff3f * v).
+ * The case table is the Lorensen-Cline / Bourke table (mc_table.inc, see tools/pack_mc_table.py).
+ * ============================================================================================== */
+static const uint64_t MC_TRI[256] = {
+#include "mc_table.inc"
+};
+static inline int mc_edge(int cube, int k) { return (int) ((MC_TRI[cube] >> (4 * k)) & 15u); } /* triTable[cube][k]; 15 = -1 */
+int so_mc_num_verts(int cube) { /* numVertsTable, marching_cubes.cpp:358 = entries before the first -1 */
+    int n = 0;
+    while (n < 16 && mc_edge(cube, n) != 15) ++n;
+    return n;
+}
+
+/* CubeIndexEstimator::computeCubeIndex -- marching_cubes.cu:38-79 (isoValue = 0, internal.hpp:95) */
+static int mc_cube_index(const f2 *vol, int X, int Y, int Z, int x, int y, int z, float f[8]) {
+    (void) Z;
+    static const int dx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, dy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, dz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    for (int c = 0; c < 8; ++c) {
+        f2 v = vol[IDX(x + dx[c], y + dy[c], z + dz[c])];
+        f[c] = v.x;
+        if (v.y == 0.f) return 0;
+    }
+    int cube = 0;
+    for (int c = 0; c < 8; ++c) cube += (f[c] < 0.f) << c;
+    return cube;
+}
+
+/* getOccupiedVoxels -- marching_cubes.cu:81-163.  occupied: 3 rows of `stride` ints (voxel index, vertex count, vertex
+ * offset).  The reference appends in warp-arrival order (atomicAdd on a global counter), i.e. every run is some
+ * permutation; this restatement and the HIP path emit the canonical member of that family, ascending voxel index (which
+ * a run whose warps advance in lockstep produces), and cap at max_size in that order.  Returns min(found, max_size). */
+int so_mc_occupied_voxels(const f2 *vol, int X, int Y, int Z, int *occupied, int stride, int max_size) {
+    int count = 0;
+    for (int z = 0; z < Z - 1; ++z) /* :94 */
+        for (int y = 0; y + 1 < Y; ++y)
+            for (int x = 0; x + 1 < X; ++x) { /* :97 */
+                float f[8];
+                int cube = mc_cube_index(vol, X, Y, Z, x, y, z, f);
+                int nv   = (cube == 0 || cube == 255) ? 0 : so_mc_num_verts(cube); /* :102 */
+                if (nv > 0) {
+                    if (count < max_size) { /* :119-122 */
+                        occupied[count]          = X * Y * z + X * y + x;
+                        occupied[stride + count] = nv;
+                    }
+                    ++count;
+                }
+            }
+    return count < max_size ? count : max_size; /* :148 */
+}
+
+/* computeOffsetsAndTotalVertices -- marching_cubes.cu:165-181: exclusive scan of row 1 into row 2 */
+int so_mc_offsets(int *occupied, int stride, int count) {
+    int run = 0;
+    for (int i = 0; i < count; ++i) {
+        occupied[2 * stride + i] = run;
+        run += occupied[stride + i];
+    }
+    return run;
+}
+
+static inline void mc_interp(const float p0[3], const float p1[3], float f0, float f1, float out[3]) { /* :193-199 */
+    float t = (0.f - f0) / (f1 - f0 + 1e-15f);
+    for (int k = 0; k < 3; ++k) out[k] = p0[k] + t * (p1[k] - p0[k]);
+}
+
+/* generateTriangles -- marching_cubes.cu:201-313.  pose: R (9, row major), t (3).  Vertices / normals are float4
+ * (x, -y, -z, 1) (store_point :270-273).  Triangles whose three vertices do not fit below max_vertices are dropped (the
+ * reference does not check its 6M-vertex buffer). */
+void so_mc_generate_triangles(const f2 *vol, int X, int Y, int Z, const int *occupied, int stride, int count, float sx,
+                              float sy, float sz, const float *R, const float *t, f4 *out_v, f4 *out_n, int max_vertices) {
+    static const int dx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, dy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, dz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    static const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7}; /* :232-243 */
+    const float cs[3] = {sx / X, sy / Y, sz / Z}; /* :292-294 */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < count; ++idx) {
+        int voxel = occupied[idx];
+        int z = voxel / (X * Y), y = (voxel - z * X * Y) / X, x = (voxel - z * X * Y) - y * X; /* :210-212 */
+        float f[8] = {0}, v[8][3], vl[12][3];
+        int cube = mc_cube_index(vol, X, Y, Z, x, y, z, f);
+        for (int c = 0; c < 8; ++c) { /* get_node_coo :183-191 */
+            v[c][0] = ((float) (x + dx[c]) + 0.5f) * cs[0];
+            v[c][1] = ((float) (y + dy[c]) + 0.5f) * cs[1];
+            v[c][2] = ((float) (z + dz[c]) + 0.5f) * cs[2];
+        }
+        for (int e = 0; e < 12; ++e) mc_interp(v[ea[e]], v[eb[e]], f[ea[e]], f[eb[e]], vl[e]);
+        int nv = so_mc_num_verts(cube); /* :247 */
+        for (int i = 0; i < nv; i += 3) {
+            int index = occupied[2 * stride + idx] + i;
+            if (index + 3 > max_vertices) break;
+            const float *p1 = vl[mc_edge(cube, i)], *p2 = vl[mc_edge(cube, i + 1)], *p3 = vl[mc_edge(cube, i + 2)];
+            float a[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]}, b[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+            float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; /* cross, temp_utils.hpp:92 */
+            float inv = 1.f / sqrtf(dot3(c, c[0], c[1], c[2]));                                          /* normalized :90 */
+            f4 n = {c[0] * inv, -(c[1] * inv), -(c[2] * inv), 1.f};
+            const float *p[3] = {p1, p2, p3};
+            for (int k = 0; k < 3; ++k) { /* pose * vertex (device.hpp:57-61), store_point */
+                float wx = dot3(R + 0, p[k][0], p[k][1], p[k][2]) + t[0], wy = dot3(R + 3, p[k][0], p[k][1], p[k][2]) + t[1],
+                      wz = dot3(R + 6, p[k][0], p[k][1], p[k][2]) + t[2];
+                out_v[index + k] = (f4){wx, -wy, -wz, 1.f};
+                out_n[index + k] = n;
+            }
+        }
+    }
+}

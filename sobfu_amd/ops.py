@@ -341,3 +341,45 @@ class Solver:
         check(_lib.lib().sobfu_hip_solver_iterate(self._h, _ptr(phi_global), _ptr(phi_n), _ptr(phi_n_psi), _ptr(psi),
                                                   C.c_int(n_iters), C.byref(rep), hist, _stream()), "solver_iterate")
         return rep, np.array(hist[:rep.iterations], np.float32)
+
+
+# ---- marching cubes (include/kfusion/internal.hpp:213-225) ---------------------------------------------------------------
+def mc_occupied_voxels(vol, max_size):
+    """getOccupiedVoxels -> (occupied int32 (3, max_size) on the GPU: voxel index / vertex count / vertex offset rows, count)"""
+    occ = torch.zeros((3, int(max_size)), dtype=torch.int32, device=vol.device)
+    n = C.c_int(0)
+    check(_lib.lib().sobfu_hip_mc_occupied_voxels(_stream(), _ptr(vol), *_xyz(vol), _ptr(occ, torch.int32), C.c_int(occ.shape[1]),
+                                                  C.c_int(int(max_size)), C.byref(n)), "mc_occupied_voxels")
+    return occ, n.value
+
+
+def mc_offsets(occ, count):
+    """computeOffsetsAndTotalVertices: row 2 = exclusive scan of row 1 -> total vertices"""
+    total = C.c_int(0)
+    check(_lib.lib().sobfu_hip_mc_offsets(_stream(), _ptr(occ, torch.int32), C.c_int(occ.shape[1]), C.c_int(int(count)), C.byref(total)),
+          "mc_offsets")
+    return total.value
+
+
+def mc_generate_triangles(vol, occ, count, volume_size, R, t, vertices, normals):
+    """generateTriangles into float4 buffers (n, 4)"""
+    Rm = _F9(*[float(v) for v in np.asarray(R, np.float32).reshape(9)])
+    tv = _F3(*[float(v) for v in np.asarray(t, np.float32).reshape(3)])
+    assert vertices.shape == normals.shape and vertices.shape[1] == 4
+    check(_lib.lib().sobfu_hip_mc_generate_triangles(_stream(), _ptr(vol), *_xyz(vol), _ptr(occ, torch.int32), C.c_int(occ.shape[1]),
+                                                     C.c_int(int(count)), _f(volume_size[0]), _f(volume_size[1]), _f(volume_size[2]), Rm, tv,
+                                                     _ptr(vertices), _ptr(normals), C.c_int(vertices.shape[0])), "mc_generate_triangles")
+
+
+def marching_cubes(vol, volume_size, R=np.eye(3), t=(0, 0, 0), max_voxels=2_000_000, max_vertices=None):
+    """kfusion::cuda::MarchingCubes::run (src/kfusion/marching_cubes.cpp:23-79) -> (vertices (n, 4), normals (n, 4)) GPU tensors"""
+    max_vertices = max_vertices or 3 * max_voxels
+    occ, count = mc_occupied_voxels(vol, max_voxels)
+    if count == 0:
+        e = torch.zeros((0, 4), dtype=torch.float32, device=vol.device)
+        return e, e.clone()
+    total = min(mc_offsets(occ, count), max_vertices // 3 * 3)  # whole triangles only
+    v = torch.zeros((max_vertices, 4), dtype=torch.float32, device=vol.device)
+    n = torch.zeros_like(v)
+    mc_generate_triangles(vol, occ, count, volume_size, R, t, v, n)
+    return v[:total], n[:total]
