@@ -2,9 +2,10 @@
 // shells: reads a params .ini, feeds depth frames to SobFusion::operator(), prints per-frame volume statistics and can
 // dump the fields.  No OpenCV / PCL / VTK: depth frames are 16-bit grayscale PNG (what the reference's datasets ship),
 // binary 16-bit PGM or raw little-endian uint16 files of rows*cols pixels (sobfu_amd/depth_io.hpp), or a built-in
-// synthetic translating sphere.  --dump DIR writes psi, psi_inv and the four TSDF volumes as .npy (float32).
+// synthetic translating sphere.  --dump DIR writes psi, psi_inv and the four TSDF volumes as .npy (float32); --mesh DIR
+// writes marching-cubes meshes of the volumes per frame as legacy-ASCII .vtk polydata (the reference: demo.cpp:236-246).
 //
-//   sobfu_headless <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR]
+//   sobfu_headless <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR] [--mesh DIR]
 //                  (--synthetic FRAMES [--shift DX] | frame0.pgm frame1.pgm ...)
 #include <cmath>
 #include <cstdint>
@@ -39,7 +40,7 @@ static void stats(const char* name, kfusion::cuda::TsdfVolume& v) {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::printf("usage: %s <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR] (--synthetic FRAMES [--shift DX] | depth files...)\n", argv[0]);
+        std::printf("usage: %s <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR] [--mesh DIR] (--synthetic FRAMES [--shift DX] | depth files...)\n", argv[0]);
         return 2;
     }
     Params p;
@@ -49,7 +50,7 @@ int main(int argc, char** argv) {
     }
     int synthetic = 0;
     double shift = 0.005;
-    std::string dump;
+    std::string dump, mesh_dir;
     std::vector<std::string> files;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
@@ -60,6 +61,7 @@ int main(int argc, char** argv) {
         else if (a == "--synthetic" && i + 1 < argc) synthetic = std::atoi(argv[++i]);
         else if (a == "--shift" && i + 1 < argc) shift = std::atof(argv[++i]);
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
+        else if (a == "--mesh" && i + 1 < argc) mesh_dir = argv[++i];
         else files.push_back(a);
     }
     if (argc > 2) {  // --dims changes the voxel size: re-derive the voxel-unit parameters
@@ -92,6 +94,20 @@ int main(int argc, char** argv) {
             fusion(depth);
         }
         stats("phi_global", *fusion.phi_global);
+        auto save_mesh = [&](const char* name, const sobfu_amd::TriangleMesh& m) {  // demo.cpp:236-246 (name_frame.vtk)
+            if (m.empty()) return;
+            const std::string path = mesh_dir + "/" + name + "_" + std::to_string(n) + ".vtk";
+            if (sobfu_amd::write_vtk(path, m)) std::printf("mesh %s: %zu triangles\n", name, m.triangles());
+            else std::printf("cannot write %s\n", path.c_str());
+        };
+        if (!mesh_dir.empty()) {
+            save_mesh("phi_global", fusion.get_phi_global_mesh());
+            if (n > 0) save_mesh("phi_n", fusion.get_phi_n_mesh());
+            if (n > 0 && n >= p.start_frame) {
+                save_mesh("phi_n_psi", fusion.get_phi_n_psi_mesh());
+                save_mesh("phi_global_psi_inv", fusion.get_phi_global_psi_inv_mesh());
+            }
+        }
         if (n > 0) {
             stats("phi_n", *fusion.phi_n);
             if (n >= p.start_frame) {

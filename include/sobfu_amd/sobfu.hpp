@@ -31,7 +31,9 @@
 #include <iostream>
 #include <memory>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "sobfu_hip.h"
 
@@ -291,6 +293,32 @@ private:
 typedef DeviceArray2D<unsigned short> Depth;
 typedef DeviceArray2D<float> Dists;
 
+// ---- DeviceArray<T>: typed 1-D view of a DeviceMemory blob (include/kfusion/cuda/device_array.hpp:20-90) --------
+template <class T>
+class DeviceArray : public DeviceMemory {
+public:
+    DeviceArray() {}
+    explicit DeviceArray(size_t n) : DeviceMemory(n * sizeof(T)) {}
+    DeviceArray(T* p, size_t n) : DeviceMemory(p, n * sizeof(T)) {}  // user buffer
+    void create(size_t n) { DeviceMemory::create(n * sizeof(T)); }
+    void upload(const T* host, size_t n) { DeviceMemory::upload(host, n * sizeof(T)); }
+    void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
+    void download(T* host) const { DeviceMemory::download(host); }
+    void download(std::vector<T>& v) const { v.resize(size()); if (!v.empty()) download(v.data()); }
+    T* ptr() { return DeviceMemory::ptr<T>(); }
+    const T* ptr() const { return DeviceMemory::ptr<T>(); }
+    size_t size() const { return sizeBytes() / sizeof(T); }
+};
+
+// point / normal element of the mesh buffers: the reference aliases pcl::PointXYZ / pcl::Normal onto float4
+// (marching_cubes.cpp:63-65, kfusion::device::PointType)
+typedef float4 Point;
+typedef float4 Normal;
+struct Surface {  // include/kfusion/types.hpp:85-88
+    DeviceArray<Point> vertices;
+    DeviceArray<Normal> normals;
+};
+
 // ---- image pre-steps (include/kfusion/cuda/imgproc.hpp:11-28, src/kfusion/imgproc.cpp:3-41) ---------------------
 inline void depthBilateralFilter(const Depth& in, Depth& out, int kernel_size, float sigma_spatial, float sigma_depth) {
     out.create(in.rows(), in.cols());
@@ -440,7 +468,92 @@ private:
     float gradient_delta_factor_, raycast_step_factor_;
 };
 }  // namespace cuda
+
+namespace device {
+// ---- marching cubes launchers (include/kfusion/internal.hpp:213-225) ---------------------------------------------
+typedef float4 PointType;
+inline void bindTextures(const int*, const int*, const int*) {}  // the case table lives in the library's constant data
+inline void unbindTextures() {}
+// occupied_voxels: 3 x cols ints (voxel index / vertex count / vertex offset); row stride in ints = step() / 4
+inline int getOccupiedVoxels(const TsdfVolume& v, cuda::DeviceArray2D<int>& occupied_voxels) {
+    int n = 0;
+    sobfuSafeCall(sobfu_hip_mc_occupied_voxels(nullptr, (const float*) v.data, v.dims.x, v.dims.y, v.dims.z, occupied_voxels.ptr(),
+                                               (int) (occupied_voxels.step() / sizeof(int)), occupied_voxels.cols(), &n));
+    return n;
+}
+inline int computeOffsetsAndTotalVertices(cuda::DeviceArray2D<int>& occupied_voxels, int active_voxels) {
+    int total = 0;
+    sobfuSafeCall(sobfu_hip_mc_offsets(nullptr, occupied_voxels.ptr(), (int) (occupied_voxels.step() / sizeof(int)), active_voxels, &total));
+    return total;
+}
+inline void generateTriangles(const TsdfVolume& v, const cuda::DeviceArray2D<int>& occupied_voxels, int active_voxels, const float3& volume_size,
+                              const Aff3f& pose, cuda::DeviceArray<PointType>& out_vertices, cuda::DeviceArray<PointType>& out_normals) {
+    const float R[9] = {pose.R.data[0].x, pose.R.data[0].y, pose.R.data[0].z, pose.R.data[1].x, pose.R.data[1].y, pose.R.data[1].z,
+                        pose.R.data[2].x, pose.R.data[2].y, pose.R.data[2].z};
+    const float t[3] = {pose.t.x, pose.t.y, pose.t.z};
+    sobfuSafeCall(sobfu_hip_mc_generate_triangles(nullptr, (const float*) v.data, v.dims.x, v.dims.y, v.dims.z, occupied_voxels.ptr(),
+                                                  (int) (occupied_voxels.step() / sizeof(int)), active_voxels, volume_size.x, volume_size.y,
+                                                  volume_size.z, R, t, (float*) out_vertices.ptr(), (float*) out_normals.ptr(),
+                                                  (int) std::min(out_vertices.size(), out_normals.size())));
+    sobfuSafeCall(hipDeviceSynchronize());  // marching_cubes.cu:312
+}
+}  // namespace device
+
+namespace cuda {
+// ---- MarchingCubes (include/kfusion/cuda/marching_cubes.hpp:17-61, src/kfusion/marching_cubes.cpp:14-79) ------------
+class MarchingCubes {
+public:
+    enum { POINTS_PER_TRIANGLE = 3, DEFAULT_TRIANGLES_BUFFER_SIZE = 2 * 1000 * 1000 * POINTS_PER_TRIANGLE };
+    typedef std::shared_ptr<MarchingCubes> Ptr;
+    MarchingCubes() : pose(Affine3f::Identity()) {}
+    void setPose(const Affine3f& pose_) { pose = pose_; }
+    Surface run(const TsdfVolume& volume, DeviceArray<Point>& vertices_buffer, DeviceArray<Normal>& normals_buffer) {
+        if (vertices_buffer.empty()) vertices_buffer.create(DEFAULT_TRIANGLES_BUFFER_SIZE);
+        if (normals_buffer.empty()) normals_buffer.create(DEFAULT_TRIANGLES_BUFFER_SIZE);
+        occupied_voxels_buffer_.create(3, (int) (vertices_buffer.size() / 3));
+        device::TsdfVolume vol = const_cast<TsdfVolume&>(volume).pod();
+        const int active_voxels = device::getOccupiedVoxels(vol, occupied_voxels_buffer_);
+        std::cout << "no. of active voxels: " << active_voxels << std::endl;  // marching_cubes.cpp:49
+        if (!active_voxels) return Surface();
+        int total_vertices = device::computeOffsetsAndTotalVertices(occupied_voxels_buffer_, active_voxels);
+        const int cap = (int) (std::min(vertices_buffer.size(), normals_buffer.size()) / 3 * 3);  // whole triangles that fit
+        if (total_vertices > cap) total_vertices = cap;
+        device::generateTriangles(vol, occupied_voxels_buffer_, active_voxels, device_cast<float3>(volume.getSize()),
+                                  device_cast<device::Aff3f>(pose), vertices_buffer, normals_buffer);
+        Surface s;
+        s.vertices = DeviceArray<Point>(vertices_buffer.ptr(), (size_t) total_vertices);
+        s.normals  = DeviceArray<Normal>(normals_buffer.ptr(), (size_t) total_vertices);
+        return s;
+    }
+
+private:
+    DeviceArray2D<int> occupied_voxels_buffer_;
+    Affine3f pose;
+};
+}  // namespace cuda
 }  // namespace kfusion
+
+namespace sobfu_amd {
+// Host triangle soup standing in for pcl::PolygonMesh (three consecutive vertices per polygon, sob_fusion.cpp:160-183)
+struct TriangleMesh {
+    std::vector<float4> vertices;
+    size_t triangles() const { return vertices.size() / 3; }
+    bool empty() const { return vertices.empty(); }
+};
+// Legacy-ASCII VTK polydata, the sections pcl::io::saveVTKFile writes for a PolygonMesh (demo.cpp:244): POINTS, VERTICES, POLYGONS
+inline bool write_vtk(const std::string& path, const TriangleMesh& m) {
+    FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) return false;
+    const size_t n = m.vertices.size(), nt = m.triangles();
+    std::fprintf(f, "# vtk DataFile Version 3.0\nvtk output\nASCII\nDATASET POLYDATA\nPOINTS %zu float\n", n);
+    for (const float4& v : m.vertices) std::fprintf(f, "%.9g %.9g %.9g\n", v.x, v.y, v.z);
+    std::fprintf(f, "\nVERTICES %zu %zu\n", n, 2 * n);
+    for (size_t i = 0; i < n; ++i) std::fprintf(f, "1 %zu\n", i);
+    std::fprintf(f, "\nPOLYGONS %zu %zu\n", nt, 4 * nt);
+    for (size_t i = 0; i < nt; ++i) std::fprintf(f, "3 %zu %zu %zu\n", 3 * i, 3 * i + 1, 3 * i + 2);
+    return std::fclose(f) == 0;
+}
+}  // namespace sobfu_amd
 
 // ================================================================================================================
 // sobfu
@@ -702,6 +815,8 @@ class SobFusion {
 public:
     explicit SobFusion(const Params& p) : frame_counter_(0), params(p), camera_pose_(cv::Affine3f::Identity()) {
         dists_.create(params.rows, params.cols);
+        mc = std::make_shared<kfusion::cuda::MarchingCubes>();  // sob_fusion.cpp:35-36
+        mc->setPose(params.volume_pose);
     }
     Params& getParams() { return params; }
     bool operator()(const kfusion::cuda::Depth& depth) {
@@ -732,6 +847,24 @@ public:
         return ++frame_counter_, true;
     }
     std::shared_ptr<sobfu::cuda::DeformationField> getDeformationField() { return psi; }
+    // meshes of the four volumes (sob_fusion.cpp:147-183); a host triangle soup replaces pcl::PolygonMesh
+    sobfu_amd::TriangleMesh get_phi_global_mesh() { return get_mesh(phi_global); }
+    sobfu_amd::TriangleMesh get_phi_global_psi_inv_mesh() { return get_mesh(phi_global_psi_inv); }
+    sobfu_amd::TriangleMesh get_phi_n_mesh() { return get_mesh(phi_n); }
+    sobfu_amd::TriangleMesh get_phi_n_psi_mesh() { return get_mesh(phi_n_psi); }
+    sobfu_amd::TriangleMesh get_mesh(cv::Ptr<kfusion::cuda::TsdfVolume> vol) {
+        kfusion::cuda::DeviceArray<kfusion::cuda::Point> vertices_buffer;
+        kfusion::cuda::DeviceArray<kfusion::cuda::Normal> normals_buffer;
+        kfusion::cuda::Surface model = mc->run(*vol, vertices_buffer, normals_buffer);
+        kfusion::cuda::waitAllDefaultStream();
+        return convert_to_mesh(model.vertices);
+    }
+    static sobfu_amd::TriangleMesh convert_to_mesh(const kfusion::cuda::DeviceArray<kfusion::cuda::Point>& triangles) {
+        sobfu_amd::TriangleMesh m;
+        if (!triangles.empty()) triangles.download(m.vertices);
+        return m;
+    }
+    std::shared_ptr<kfusion::cuda::MarchingCubes> mc;
 
     cv::Ptr<kfusion::cuda::TsdfVolume> phi_global, phi_global_psi_inv, phi_n, phi_n_psi;
     std::shared_ptr<sobfu::cuda::DeformationField> psi, psi_inv;

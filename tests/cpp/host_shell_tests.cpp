@@ -251,6 +251,49 @@ static void test_depth_integration() {
     CHECK(h[32 + 64 * (32 + 64 * (size_t) (zc - 2))].x > 0.f && h[32 + 64 * (32 + 64 * (size_t) (zc + 2))].x < 0.f);
 }
 
+static void test_marching_cubes() {
+    // kfusion::cuda::MarchingCubes on an analytic sphere: closed surface (zero total area vector), vertices on the sphere,
+    // enclosed volume; the pose translates the mesh; an unobserved volume gives an empty Surface
+    Params p;
+    p.volume_dims = cv::Vec3i::all(64);
+    p.volume_size = cv::Vec3f::all(0.5f);
+    p.tsdf_trunc_dist = 5.f * 0.5f / 64.f;
+    p.eta = 2.f * 0.5f / 64.f;
+    p.tsdf_max_weight = 128.f;
+    TsdfVolume vol(p);
+    kfusion::cuda::MarchingCubes mc;
+    kfusion::cuda::DeviceArray<kfusion::cuda::Point> vb;
+    kfusion::cuda::DeviceArray<kfusion::cuda::Normal> nb;
+    CHECK(mc.run(vol, vb, nb).vertices.empty());
+    const float cx = 0.25f, cy = 0.26f, cz = 0.24f, r = 0.1f;
+    float3 c; c.x = cx; c.y = cy; c.z = cz;
+    vol.initSphere(c, r);
+    mc.setPose(cv::Affine3f().translate(cv::Vec3f(1.f, 2.f, 3.f)));
+    kfusion::cuda::Surface s = mc.run(vol, vb, nb);
+    std::vector<float4> v, n;
+    s.vertices.download(v);
+    s.normals.download(n);
+    CHECK(v.size() == n.size() && v.size() % 3 == 0 && v.size() > 10000);
+    double ax = 0, ay = 0, az = 0, volume = 0, rmin = 1e9, rmax = 0;
+    for (size_t i = 0; i < v.size(); i += 3) {
+        double q[3][3];
+        for (int k = 0; k < 3; ++k) {  // undo store_point's flip and the pose translation
+            q[k][0] = v[i + k].x - 1.0; q[k][1] = -v[i + k].y - 2.0; q[k][2] = -v[i + k].z - 3.0;
+            double d = std::sqrt((q[k][0] - cx) * (q[k][0] - cx) + (q[k][1] - cy) * (q[k][1] - cy) + (q[k][2] - cz) * (q[k][2] - cz));
+            rmin = std::min(rmin, d); rmax = std::max(rmax, d);
+        }
+        double e1[3] = {q[1][0] - q[0][0], q[1][1] - q[0][1], q[1][2] - q[0][2]}, e2[3] = {q[2][0] - q[0][0], q[2][1] - q[0][1], q[2][2] - q[0][2]};
+        ax += 0.5 * (e1[1] * e2[2] - e1[2] * e2[1]); ay += 0.5 * (e1[2] * e2[0] - e1[0] * e2[2]); az += 0.5 * (e1[0] * e2[1] - e1[1] * e2[0]);
+        volume += (q[0][0] * (q[1][1] * q[2][2] - q[1][2] * q[2][1]) - q[0][1] * (q[1][0] * q[2][2] - q[1][2] * q[2][0]) +
+                   q[0][2] * (q[1][0] * q[2][1] - q[1][1] * q[2][0])) / 6.0;
+    }
+    const double vs = 0.5 / 64.0;
+    CHECK(rmin > r - 0.05 * vs && rmax < r + 0.05 * vs);
+    CHECK(std::fabs(ax) < 1e-7 && std::fabs(ay) < 1e-7 && std::fabs(az) < 1e-7);
+    CHECK(std::fabs(std::fabs(volume) / (4.0 / 3.0 * 3.14159265358979 * r * r * r) - 1.0) < 5e-3);
+    CHECK(v[0].w == 1.f && n[0].w == 1.f && std::fabs(n[0].x * n[0].x + n[0].y * n[0].y + n[0].z * n[0].z - 1.f) < 1e-5f);
+}
+
 int main() {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -264,6 +307,7 @@ int main() {
     test_data_term();
     test_solver_alignment();
     test_depth_integration();
+    test_marching_cubes();
     std::printf("host_shell_tests: %d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }

@@ -97,3 +97,39 @@ def test_png_frames_and_npy_dumps(tmp_path):
     assert pg.shape == (64, 64, 64, 2) and abs(float(pg[..., 0].astype(np.float64).sum()) - s[0]) < 1e-2 and float(pg[..., 1].sum()) == s[1]
     for name in ("phi_n", "phi_n_psi", "phi_global_psi_inv"):
         assert np.load(dump / f"{name}.npy").shape == (64, 64, 64, 2)
+
+
+def _read_vtk(path):
+    import numpy as np
+
+    lines = open(path).read().split("\n")
+    assert lines[0].startswith("# vtk DataFile") and lines[2] == "ASCII" and lines[3] == "DATASET POLYDATA"
+    n = int(lines[4].split()[1])
+    pts = np.array([[float(v) for v in l.split()] for l in lines[5:5 + n]], np.float32)
+    i = next(k for k, l in enumerate(lines) if l.startswith("POLYGONS"))
+    nt = int(lines[i].split()[1])
+    polys = np.array([[int(v) for v in l.split()] for l in lines[i + 1:i + 1 + nt]])
+    return pts, polys
+
+
+def test_mesh_files_match_oracle_marching_cubes(tmp_path):
+    """--mesh: the .vtk polydata of phi_global after frame 1 = the oracle's marching cubes of the dumped volume, vertex for vertex."""
+    import numpy as np
+
+    import oracle
+
+    ini = os.path.join(ROOT, "params", "config1_sphere_64.ini")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    out = _run(ini, "--synthetic", "2", "--max-iter", "4", "--mesh", str(out_dir), "--dump", str(out_dir))
+    assert "no. of active voxels:" in out and "mesh phi_global:" in out and "mesh phi_global_psi_inv:" in out
+    for name in ("phi_global_0", "phi_global_1", "phi_n_1", "phi_n_psi_1", "phi_global_psi_inv_1"):
+        assert (out_dir / f"{name}.vtk").exists(), name
+    pts, polys = _read_vtk(out_dir / "phi_global_1.vtk")
+    assert len(pts) == 3 * len(polys) and np.array_equal(polys[:, 0], np.full(len(polys), 3))
+    assert np.array_equal(polys[:, 1:].ravel(), np.arange(len(pts)))
+    vol = np.load(out_dir / "phi_global.npy")
+    # params: VOL_SIZE 0.5, volume pose = translate(-0.25, -0.25, VOL_POSE_T_Z = 0.5) (demo.cpp:73-74)
+    v, _ = oracle.marching_cubes(vol, (0.5, 0.5, 0.5), np.eye(3, dtype=np.float32), (-0.25, -0.25, 0.5))
+    assert len(v) == len(pts) > 3000
+    assert np.array_equal(v[:, :3].view(np.uint32), pts.view(np.uint32))  # %.9g text round-trips float32 exactly
