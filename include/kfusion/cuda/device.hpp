@@ -1,0 +1,3 @@
+// Forwarding header: the reference include path <kfusion/cuda/device.hpp> resolves to the MI355X shells.
+#pragma once
+#include <sobfu_amd/sobfu.hpp>
