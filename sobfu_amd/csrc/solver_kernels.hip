@@ -200,15 +200,25 @@ SOBFU_DEV void chunk_range(int tz, int zc, int z_lo, int z_hi, int z_lo2, int z_
 // Pass B folds max ||u||^2 of iteration k into 256 uint32 slots (non-negative floats order like their bit
 // patterns).  A kernel of iteration k+1 receives the slots of iteration k and returns immediately when
 // sqrt_rd(max) <= max_update_norm -- the reference's `break` (solver.cu:183) without a host round trip.
-SOBFU_DEV bool solver_converged(const uint32_t* __restrict__ prev_slots, float max_update_norm) {
+//
+// prev_rows = 2 (native tiled loop, late gate): the gate is true when the row at prev_slots OR the row before it says
+// "converged".  That loop gates iteration j on row j-2, runs iteration k+1 speculatively after the threshold fired at k, and
+// a gated launch leaves its own row at the all-zero (= converged) state it was cleared to -- looking at rows j-2 and j-3
+// makes the stop sticky for both parities whatever the speculative row k+1 holds.
+SOBFU_DEV bool solver_converged(const uint32_t* __restrict__ prev_slots, float max_update_norm, int prev_rows = 1) {
     if (prev_slots == nullptr) return false;
     __shared__ int s_flag;
     const int tid = threadIdx.x + blockDim.x * threadIdx.y;
     if (tid < 64) {
-        uint32_t m = max(max(prev_slots[tid], prev_slots[tid + 64]), max(prev_slots[tid + 128], prev_slots[tid + 192]));
+        bool conv = false;
+        for (int r = 0; r < prev_rows; ++r) {
+            const uint32_t* row = prev_slots - (size_t) r * 256;
+            uint32_t m = max(max(row[tid], row[tid + 64]), max(row[tid + 128], row[tid + 192]));
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
-        if (tid == 0) s_flag = sqrt_rd(__uint_as_float(m)) <= max_update_norm ? 1 : 0;
+            for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
+            conv = conv || sqrt_rd(__uint_as_float(m)) <= max_update_norm;
+        }
+        if (tid == 0) s_flag = conv ? 1 : 0;
     }
     __syncthreads();
     return s_flag != 0;
@@ -408,6 +418,8 @@ struct PassBArgs {
     // only planes [own_lo, own_hi) are owned by this rank and enter the max-norm.  Single GPU: pd == d, [0, d.z).
     Dims pd;
     int own_lo, own_hi;
+    int prev_rows;  // rows the gate looks at (see solver_converged)
+    void* psi_out;  // where the updated psi goes: == psi (in place) or the other half of a ping-pong pair (native tiled loop)
 };
 
 #ifndef SOBFU_MINW_B
@@ -421,7 +433,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
     __shared__ float4 tile[2][LH][LW + 2];
     __shared__ uint32_t s_max[WY];
 
-    if (solver_converged(a.prev_slots, a.max_update_norm)) return;
+    if (solver_converged(a.prev_slots, a.max_update_norm, a.prev_rows)) return;
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
@@ -538,8 +550,8 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             if (x < d.x && y < d.y) {
                 if (z >= a.own_lo && z < a.own_hi) msq = fmaxf(msq, norm_sq4(u));
                 const size_t i = zcur + (size_t) x + (size_t) d.x * y;
-                if (SOBFU_NT >= 1) stv_nt<COMPACT>(a.psi, i, p);
-                else stv<COMPACT>(a.psi, i, p);
+                if (SOBFU_NT >= 1) stv_nt<COMPACT>(a.psi_out, i, p);
+                else stv<COMPACT>(a.psi_out, i, p);
                 if (WRITE_UPDATES) a.updates[i] = u;
                 // apply_kernel (vector_fields.cu:95-98)
                 if (COMPACT && SOBFU_NT >= 1) __builtin_nontemporal_store(interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z), (float*) a.pnp + i);
@@ -904,7 +916,7 @@ int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
                   const float taps[7], float alpha, int X, int Y, int Z, const uint32_t* prev_slots,
                   float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo,
-                  int z_hi, int z_lo2, int z_hi2) {
+                  int z_hi, int z_lo2, int z_hi2, float* psi_out, int prev_rows) {
     if (phi_Z <= 0) { phi_Z = Z; own_lo = 0; own_hi = Z; }
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
     if (z_hi <= 0 && z_hi2 <= z_lo2) { z_lo = 0; z_hi = Z; }  // no range given: the whole grid
@@ -913,7 +925,7 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
     const bool two = z_hi2 > z_lo2;
     const int nz = std::max(z_hi - z_lo, two ? z_hi2 - z_lo2 : 0);
     if (zc <= 0) zc = pick_zc(X, Y, nz, TY, (256 * 3) / (two ? 2 : 1), 6, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
-    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, z_lo2, z_hi2, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi};
+    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, z_lo2, z_hi2, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi, prev_rows, psi_out ? psi_out : psi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     const int nchunks = (z_hi - z_lo + zc - 1) / zc + (two ? (z_hi2 - z_lo2 + zc - 1) / zc : 0);
     dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * nchunks);

@@ -6,10 +6,9 @@
 //     A_bnd (planes next to an interior face)  ->  event  ->  [comm stream] group{send, recv} of 4 nabla_U planes / face
 //     A_int, B_int (planes whose +-3 taps are owned)            ... run while the exchange is in flight
 //     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)
-// When a non-negative threshold can fire, the device-side gate needs the GLOBAL max of the previous iteration's 256
-// max-norm slots.  Only pass B changes solver state, so pass A runs ungated and the all_reduce(MAX) of row it-1 is issued
-// on the comm stream ahead of iteration it's exchange; B_int waits for it.  The reduction's latency hides behind A_int
-// instead of ending every iteration (SOBFU_TILED_INLINE_REDUCE=1 restores the in-line variant for A/B runs).
+// (both boundary regions of a pass are ONE two-range launch; thin slabs keep pass A unsplit).  When a non-negative threshold
+// can fire the device-side gate needs the GLOBAL max-norm: see sobfu_hip_tiled_iterate for the ping-pong / late-gate scheme
+// that keeps that all-reduce off the critical path.
 //
 // RCCL is not a link-time dependency: the host process (PyTorch) has already loaded librccl.so; sobfu_hip_tiled_load_rccl
 // dlopen()s that same file and resolves the nine entry points used here, so libsobfu_hip.so still loads on a machine
@@ -47,7 +46,7 @@ struct Rccl {
 } g_rccl;
 
 constexpr int kHalo = 4, kSlots = 256;
-constexpr int kSplitAMinPlanes = 48;  // interior planes below which pass A stays one launch (tools/slab_time_native.py)
+constexpr int kSplitAMaxPlanes = 48;  // owned planes up to which pass A is split into boundary + interior launches
 
 #define RCCL_TRY(expr)                                                                          \
     do {                                                                                        \
@@ -77,9 +76,9 @@ struct sobfu_hip_tiled {
     sobfu_hip_tiled_allreduce_fn rfn = nullptr;
     void* tctx = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_row = nullptr, ev_red = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_red = nullptr;
     // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
-    float *nU = nullptr, *c_psi = nullptr, *c_f = nullptr, *c_g = nullptr, *c_n = nullptr;
+    float *nU = nullptr, *c_psi = nullptr, *c_psi2 = nullptr, *c_f = nullptr, *c_f2 = nullptr, *c_g = nullptr, *c_n = nullptr;
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
@@ -127,13 +126,12 @@ int sobfu_hip_tiled_unique_id(char out[128]) {
 
 int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (!t) return 0;
-    for (float* q : {t->nU, t->c_psi, t->c_f, t->c_g, t->c_n})
+    for (float* q : {t->nU, t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
         if (q) (void) hipFree(q);
     if (t->slots) (void) hipFree(t->slots);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
     if (t->ev_red) (void) hipEventDestroy(t->ev_red);
-    if (t->ev_row) (void) hipEventDestroy(t->ev_row);
     if (t->comm_stream) (void) hipStreamDestroy(t->comm_stream);
     if (t->comm && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm);
     delete t;
@@ -168,13 +166,14 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipMalloc((void**) &t->nU, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f, t->NL * 4);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi2, t->NL * 12);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
     if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red, hipEventDisableTiming);
-    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_row, hipEventDisableTiming);
     if (rc == 0 && !dry) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, 128);
@@ -261,6 +260,14 @@ int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_
 // The gradient-descent loop (reference src/sobfu/cuda/solver.cu:106-193) on this rank's slab.  API-format arguments:
 // d_phi_global_local / d_phi_n_psi_local float2 (X, Y, Lz), d_phi_n_full float2 (X, Y, Z), d_psi_local float4 (X, Y, Lz)
 // whose owned +-1 planes are exact on entry (identity: sobfu_hip_tile_init_identity) and on exit.  Synchronises `stream`.
+//
+// Convergence without a stall: psi and F = (phi_n o psi).tsdf are PING-PONGED (iteration k reads buffer (k-1)&1 and writes
+// buffer k&1), and the device-side gate of iteration k looks at the max-norm row of iteration k-2.  When the threshold fires
+// at iteration k, iteration k+1 has already run speculatively -- into the OTHER buffer -- every later launch is a no-op,
+// and the state the reference's `break` (solver.cu:183) leaves is intact in buffer k&1.  The all-reduce that makes row k
+// global therefore has a whole iteration to complete and is issued on the comm stream behind the exchange: nothing in the
+// loop ever waits for a reduction that is still in flight (a same-iteration gate costs an exposed collective or a
+// stream round trip per iteration: 67 vs 55 us per iteration in the N = 8 compute-side timing).
 int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
                             float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
                             float* per_iter_max_norm, void* stream) {
@@ -270,11 +277,16 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const sobfu_hip_solver_params& p = t->p;
     sobfu_hip_solver_report r{};
     r.last_max_update_norm = r.last_max_update_index = r.last_e_data = r.last_e_reg = NAN;
-    // enter the compact format (includes the warp of solver.cu:106)
-    SOBFU_TRY(sobfu_hip::launch_pack_vec(d_psi_local, t->c_psi, t->NL, st));
+    float* P[2] = {t->c_psi, t->c_psi2};
+    float* F[2] = {t->c_f, t->c_f2};
+    // enter the compact format (includes the warp of solver.cu:106); both halves start equal so that planes no launch
+    // writes (beyond owned +-1) hold the caller's values whichever half the loop ends in
+    SOBFU_TRY(sobfu_hip::launch_pack_vec(d_psi_local, P[0], t->NL, st));
     SOBFU_TRY(sobfu_hip::launch_extract_tsdf(d_phi_global_local, t->c_g, t->NL, st));
     SOBFU_TRY(sobfu_hip::launch_extract_tsdf(d_phi_n_full, t->c_n, t->NF, st));
-    SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(t->c_n, t->c_f, t->c_psi, X, Y, Lz, st, Z));
+    SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(t->c_n, F[0], P[0], X, Y, Lz, st, Z));
+    SOBFU_HIP_TRY(hipMemcpyAsync(P[1], P[0], t->NL * 12, hipMemcpyDeviceToDevice, st));
+    SOBFU_HIP_TRY(hipMemcpyAsync(F[1], F[0], t->NL * 4, hipMemcpyDeviceToDevice, st));
     if (n_iters > t->slots_iters) {
         if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
         t->slots = nullptr;
@@ -286,63 +298,59 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     // all-reduce) on a single rank too: bring-up / test hook for 1-GPU machines
     const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
     const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
-    const char* inl = std::getenv("SOBFU_TILED_INLINE_REDUCE");  // A/B knob: all-reduce in line on the compute stream
-    const bool inline_reduce = inl && inl[0] == '1';
     const int lo = t->own_lo, hi = t->own_hi, H = kHalo;
     const int a_lo = t->lo ? std::min(lo + H, hi) : lo, a_hi = t->hi ? std::max(hi - H, a_lo) : hi;
     const int b_lo = t->lo ? std::min(lo + 3, hi) : lo, b_hi = t->hi ? std::max(hi - 3, b_lo) : hi;
     const int b_first = t->lo ? lo - 1 : lo, b_last = t->hi ? hi + 1 : hi;
-    // pass A split into boundary + interior launches only when the interior is worth a launch of its own
+    // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
+    // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
+    // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N = 8 at 256^3)
     const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
-    const bool split_a = (t->lo || t->hi) && a_hi > a_lo && (sa ? sa[0] == '1' : (a_hi - a_lo) >= kSplitAMinPlanes);
+    const bool split_a = (t->lo || t->hi) && a_hi > a_lo && (sa ? sa[0] == '1' : (hi - lo) <= kSplitAMaxPlanes);
+    bool red_pending = false;  // an all-reduce has been issued on the comm stream and ev_red recorded behind it
     for (int it = 1; it <= n_iters; ++it) {
-        const uint32_t* prev_b = (it > 1 && can_converge) ? t->slots + (size_t) (it - 1) * kSlots : nullptr;
-        const uint32_t* prev_a = (multi && !inline_reduce) ? nullptr : prev_b;  // pass A writes scratch only: no need to wait for the global max
-        uint32_t* row          = t->slots + (size_t) it * kSlots;
-        auto A = [&](int za, int zb, int za2 = 0, int zb2 = 0) {
-            return sobfu_hip::launch_pass_a(t->c_f, t->c_g, t->c_psi, t->nU, p.w_reg, X, Y, Lz, prev_a, p.max_update_norm, 0, st, true, za, zb, za2, zb2);
+        const float *psi_in = P[(it - 1) & 1], *f_in = F[(it - 1) & 1];
+        float *psi_out = P[it & 1], *f_out = F[it & 1];
+        const uint32_t* prev = (it > 2 && can_converge) ? t->slots + (size_t) (it - 2) * kSlots : nullptr;  // the late gate
+        uint32_t* row        = t->slots + (size_t) it * kSlots;
+        auto A = [&](int za, int zb, int za2 = 0, int zb2 = 0) {  // pass A writes scratch only: never gated
+            return sobfu_hip::launch_pass_a(f_in, t->c_g, psi_in, t->nU, p.w_reg, X, Y, Lz, nullptr, 0.f, 0, st, true, za, zb, za2, zb2);
         };
         auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0) {
-            return sobfu_hip::launch_pass_b(t->nU, t->c_psi, t->c_n, t->c_f, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev_b, p.max_update_norm,
-                                            0, st, Z, lo, hi, true, za, zb, za2, zb2);
+            return sobfu_hip::launch_pass_b(t->nU, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev,
+                                            p.max_update_norm, 0, st, Z, lo, hi, true, za, zb, za2, zb2, psi_out, it > 3 ? 2 : 1);
         };
-        // both boundary regions of a pass go out as ONE launch (two plane ranges); thin slabs skip the A split entirely
-        // (one pass A launch, the exchange then overlaps pass B's interior only)
+        // both boundary regions of a pass go out as ONE launch (two plane ranges)
         if (split_a) SOBFU_TRY(A(lo, a_lo, a_hi, hi));
         else SOBFU_TRY(A(lo, hi));
         if (multi) {
             SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
-            if (prev_b && !inline_reduce && split_a) {  // row it-1 is complete (B of it-1 precedes A_bnd on `st`): make it the global max
-                SOBFU_TRY(allreduce_max(t, const_cast<uint32_t*>(prev_b), kSlots, t->comm_stream));
-                SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
-            }
             SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
         }
         if (split_a && a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
-        if (multi && prev_b && !inline_reduce) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
+        // the gate row (iteration it-2) was reduced behind the PREVIOUS iteration's exchange: long done, the wait is free
+        if (multi && prev && red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
         if (b_hi > b_lo) SOBFU_TRY(B(b_lo, b_hi));
         if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
         if (b_lo > b_first || b_last > b_hi) SOBFU_TRY(B(b_first, b_lo, b_hi, b_last));
-        if (multi && can_converge && (inline_reduce || it == n_iters)) {
-            SOBFU_TRY(allreduce_max(t, row, kSlots, st));
-        } else if (multi && can_converge && !split_a) {
-            // unsplit pass A (thin slabs): there is no A_int to hide a comm-stream round trip behind, so the reduction of THIS
-            // row starts now and runs beside the whole of the next pass A
-            SOBFU_HIP_TRY(hipEventRecord(t->ev_row, st));
-            SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_row, 0));
-            SOBFU_TRY(allreduce_max(t, row, kSlots, t->comm_stream));
+        if (multi && can_converge && it >= 2 && it < n_iters) {
+            // row it-1 is complete (its pass B precedes this iteration's ev_bnd, which the comm stream has waited for) and is
+            // the gate of iteration it+1: reduce it now, behind this iteration's exchange
+            SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
+            red_pending = true;
         }
         // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
     }
-    if (multi && !can_converge && n_iters > 0) SOBFU_TRY(allreduce_max(t, t->slots + kSlots, (size_t) n_iters * kSlots, st));
-    // leave the compact format: psi.xyz back, phi_n o psi = apply(phi_n, psi) (the state of solver.cu:168)
-    SOBFU_TRY(sobfu_hip::launch_unpack_vec(t->c_psi, d_psi_local, t->NL, st));
-    SOBFU_TRY(sobfu_hip_tile_apply(d_phi_n_full, Z, d_phi_n_psi_local, d_psi_local, X, Y, Lz, st));
+    if (multi && n_iters > 0) {  // rows the loop has not reduced yet: all of them without a threshold, the tail otherwise
+        if (red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
+        const int first = can_converge ? std::max(1, n_iters - 1) : 1;  // rows 1 .. n_iters-2 went through the comm stream
+        SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (n_iters - first + 1) * kSlots, st));
+    }
     std::vector<uint32_t> hs((size_t) std::max(n_iters, 1) * kSlots, 0u);
     if (n_iters > 0) SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), t->slots + kSlots, (size_t) n_iters * kSlots * 4, hipMemcpyDeviceToHost, st));
     SOBFU_HIP_TRY(hipStreamSynchronize(st));
@@ -355,13 +363,18 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         const float v = host_sqrt_rd(f);
         if (per_iter_max_norm) per_iter_max_norm[k] = v;
         r.last_max_update_norm = v;
-        if (can_converge && v <= p.max_update_norm) {  // solver.cu:183 -- later launches were device-side no-ops
+        if (can_converge && v <= p.max_update_norm) {  // solver.cu:183 -- iteration k+2 ran speculatively, later ones not at all
             done = k + 1;
             r.converged = 1;
             break;
         }
     }
     r.iterations = done;
+    // leave the compact format from the half that holds the state after `done` iterations: psi.xyz back,
+    // phi_n o psi = apply(phi_n, psi) (the state of solver.cu:168)
+    SOBFU_TRY(sobfu_hip::launch_unpack_vec(P[done & 1], d_psi_local, t->NL, st));
+    SOBFU_TRY(sobfu_hip_tile_apply(d_phi_n_full, Z, d_phi_n_psi_local, d_psi_local, X, Y, Lz, st));
+    SOBFU_HIP_TRY(hipStreamSynchronize(st));
     if (report) *report = r;
     return 0;
 }
