@@ -46,7 +46,7 @@ struct Rccl {
 } g_rccl;
 
 constexpr int kHalo = 4, kSlots = 256;
-constexpr int kSplitAMaxPlanes = 48;  // owned planes up to which pass A is split into boundary + interior launches
+constexpr int kSplitAMaxPlanes = 64;  // owned planes up to which pass A is split into boundary + interior launches
 
 #define RCCL_TRY(expr)                                                                          \
     do {                                                                                        \
@@ -304,7 +304,7 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const int b_first = t->lo ? lo - 1 : lo, b_last = t->hi ? hi + 1 : hi;
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
     // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
-    // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N = 8 at 256^3)
+    // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N >= 4 at 256^3, if a face takes the ~65 us that ~60 GB/s per xGMI direction implies)
     const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
     const bool split_a = (t->lo || t->hi) && a_hi > a_lo && (sa ? sa[0] == '1' : (hi - lo) <= kSplitAMaxPlanes);
     bool red_pending = false;  // an all-reduce has been issued on the comm stream and ev_red recorded behind it
