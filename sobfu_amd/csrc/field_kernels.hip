@@ -32,16 +32,34 @@ __global__ void __launch_bounds__(256) apply_kernel(const float2* __restrict__ p
 
 // estimate_inverse_kernel x n_sweeps -- vector_fields.cu:111-138.  A sweep reads psi (never written) and the
 // voxel's OWN psi_inv value only, so the reference's 48 launches collapse into one kernel that iterates the
-// fixed point in registers: psi_inv is read once and written once instead of 48 times, bit-identical result.
+// fixed point p <- x - u(p) in registers: psi_inv is read once and written once instead of 48 times, bit-identical result.
+// The float iteration soon repeats itself: once a sweep returns its input bit for bit every later sweep does too, and once
+// it returns the value before that (period 2) the tail just alternates -- in both cases the value after n_sweeps is known
+// and the lane stops (same bits as running all sweeps; typically < 10 of the 48 are needed).
 __global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
                                                                   Dims d, Dims pd, int zbase, int n_sweeps) {
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
-    float4 v = psi_inv[i];
+    float4 v = psi_inv[i], w = v;  // p_it, p_(it-1)
     const float4 id = f4((float) x, (float) y, (float) (z + zbase));
+    auto same = [](const float4& a, const float4& b) {
+        return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+               __float_as_uint(a.z) == __float_as_uint(b.z);
+    };
     for (int it = 0; it < n_sweeps; ++it) {
-        float4 u = interp_disp(psi, pd, v.x, v.y, v.z);
-        v        = sub4(id, mul4(u, 1.f));
+        const float4 u  = interp_disp(psi, pd, v.x, v.y, v.z);
+        const float4 nv = sub4(id, mul4(u, 1.f));  // p_(it+1)
+        const int left  = n_sweeps - (it + 1);     // sweeps still to run after this one
+        if (same(nv, v)) {                         // fixed point
+            v = nv;
+            break;
+        }
+        if (it > 0 && same(nv, w)) {               // period 2: ..., w, v, w (= nv), v, w, ...
+            v = (left & 1) ? v : nv;
+            break;
+        }
+        w = v;
+        v = nv;
     }
     psi_inv[i] = v;
 }

@@ -541,6 +541,36 @@ def test_max_size_512(ops, oracle):
     assert float(psi[-1, -1, -1, 0]) == 511.0 and float(psi[-1, -1, -1, 2]) == 511.0
 
 
+@pytest.mark.parametrize("amp", [0.05, 0.45, 1.7])
+def test_inverse_early_exit_is_exact(ops, oracle, amp):
+    """The one-kernel inverse stops a lane once its fixed-point iteration has provably entered a period-1 or period-2 cycle:
+    every sweep count (odd and even, before and after the cycle starts) must give the oracle's plain n-sweep result."""
+    dims = (33, 18, 11)
+    X, Y, Z = dims
+    psi = oracle.new_field(dims)
+    oracle.init_identity(psi)
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    smooth = np.stack([np.sin(0.4 * y + 0.3 * z), np.cos(0.5 * x + 0.2 * z), np.sin(0.3 * x + 0.6 * y)], -1)
+    psi[..., :3] += (amp * (0.7 * smooth + 0.3 * hash_field((Z, Y, X), 31, 1.0)[..., None])).astype(np.float32)
+    psi_d = dev(psi)
+    cycles = 0
+    for n in (0, 1, 2, 3, 6, 7, 20, 47, 48, 49):
+        inv_o = oracle.new_field(dims)
+        oracle.init_identity(inv_o)
+        inv_o[..., 3] = 5.0  # a w lane that only n = 0 may keep
+        inv_d = dev(inv_o)
+        oracle.estimate_inverse(psi, inv_o, n)
+        ops.estimate_inverse(psi_d, inv_d, n)
+        assert same(host(inv_d), inv_o), n
+        if n == 48:
+            a = oracle.new_field(dims)
+            oracle.init_identity(a)
+            oracle.estimate_inverse(psi, a, 47)
+            cycles = int((a[..., :3].view(np.uint32) != inv_o[..., :3].view(np.uint32)).any(-1).sum())
+    if amp >= 1.0:
+        assert cycles > 0  # the rough field really has lanes that never settle on a fixed point
+
+
 def test_native_tiled_loop_single_rank(ops, oracle):
     """sobfu_hip_tiled_* (C++ loop + RCCL) with one rank: identical to the solver handle; the RCCL entry points it uses
     (communicator bootstrap, grouped send/recv, MAX all-reduce) are exercised on the real library through self-transfers."""
