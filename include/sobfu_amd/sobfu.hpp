@@ -25,6 +25,7 @@
 #include <hip/hip_vector_types.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -676,7 +677,22 @@ public:
     cv::Vec3i get_dims() const { return dims; }
     kfusion::cuda::CudaData get_data() { return data; }
     const kfusion::cuda::CudaData get_data() const { return data; }
+    void set_data(kfusion::cuda::CudaData& d) { data = d; }
     void clear() { device::VectorField f(data.ptr<float4>(), kfusion::device_cast<int3>(dims)); device::clear(f); }
+    void print() {  // debug listing of the non-zero vectors (src/sobfu/vector_fields.cpp:31-54), x outermost like the reference
+        const size_t X = (size_t) dims[0], Y = (size_t) dims[1], Z = (size_t) dims[2];
+        std::vector<float4> h(X * Y * Z);
+        data.download(h.data());
+        std::cout << "--- FIELD ---" << std::endl;
+        for (size_t i = 0; i < X; ++i)
+            for (size_t j = 0; j < Y; ++j)
+                for (size_t k = 0; k < Z; ++k) {
+                    const float4& v = h[i + X * (j + Y * k)];
+                    if (std::fabs(v.x) > 1e-5f || std::fabs(v.y) > 1e-5f || std::fabs(v.z) > 1e-5f)
+                        std::cout << "(x,y,z)=(" << i << ", " << j << ", " << k << "), (u,v,w)=(" << v.x << ", " << v.y << "," << v.z << ")"
+                                  << std::endl;
+                }
+    }
     int get_no_nans() {  // debug helper of the reference (src/sobfu/vector_fields.cpp:56-79)
         size_t n = (size_t) dims[0] * dims[1] * dims[2];
         std::unique_ptr<float4[]> h(new float4[n]);
@@ -723,6 +739,24 @@ public:
 private:
     kfusion::cuda::CudaData data;
     cv::Vec3i dims;
+};
+
+// SpatialGradients (include/sobfu/vector_fields.hpp:102-112, src/sobfu/vector_fields.cpp:148-165): the reference's solver
+// workspace -- six vector fields and two Jacobians (5.1 GB at 256^3, half of it never touched).  Kept for source
+// compatibility only: Solver below does NOT allocate it (its workspace is one nabla_U field + the compact state).
+struct SpatialGradients {
+    explicit SpatialGradients(cv::Vec3i d)
+        : nabla_phi_n(new TsdfGradient(d)), nabla_phi_n_o_psi(new TsdfGradient(d)), J(new Jacobian(d)), J_inv(new Jacobian(d)),
+          L(new Laplacian(d)), L_o_psi_inv(new Laplacian(d)), nabla_U(new PotentialGradient(d)), nabla_U_S(new PotentialGradient(d)) {}
+    ~SpatialGradients() {
+        delete nabla_phi_n; delete nabla_phi_n_o_psi; delete J; delete J_inv; delete L; delete L_o_psi_inv; delete nabla_U; delete nabla_U_S;
+    }
+    SpatialGradients(const SpatialGradients&) = delete;
+    SpatialGradients& operator=(const SpatialGradients&) = delete;
+    TsdfGradient *nabla_phi_n, *nabla_phi_n_o_psi;
+    Jacobian *J, *J_inv;
+    Laplacian *L, *L_o_psi_inv;
+    PotentialGradient *nabla_U, *nabla_U_S;
 };
 
 // Solver (include/sobfu/solver.hpp:52-101, src/sobfu/solver.cpp:7-101): the workspace + hot loop live behind the

@@ -78,6 +78,16 @@ static void test_identity_and_memory() {
     CHECK(psi->get_no_nans() == 0);
 }
 
+static void test_workspace_structs() {
+    // SpatialGradients / set_data / get_no_nans: source-compatibility members of the reference's host classes
+    sobfu::cuda::SpatialGradients sg(cv::Vec3i(8, 6, 4));
+    CHECK(sg.nabla_U->get_dims()[1] == 6 && sg.J != nullptr && sg.L_o_psi_inv->get_no_nans() == 0);
+    sobfu::cuda::VectorField a(cv::Vec3i(8, 6, 4)), b(cv::Vec3i(8, 6, 4));
+    kfusion::cuda::CudaData d = a.get_data();
+    b.set_data(d);
+    CHECK(b.get_data().ptr<float>() == a.get_data().ptr<float>());
+}
+
 static void test_tsdf_gradient() {
     Fixture f;
     cv::Ptr<TsdfVolume> phi(new TsdfVolume(f.params));
@@ -302,6 +312,7 @@ int main() {
     }
     kfusion::cuda::setDevice(0);
     test_identity_and_memory();
+    test_workspace_structs();
     test_tsdf_gradient();
     test_jacobian_laplacian();
     test_data_term();
