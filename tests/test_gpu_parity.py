@@ -357,6 +357,40 @@ def test_solver_serial_frames_warm_start(ops, oracle):
     sv.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_solver_randomised_configurations(ops, oracle, seed):
+    """Differential run of the whole estimate_psi on random shapes, parameters, filter choices, thresholds and code paths
+    (quiet compact two-pass, verbose API-format, single-kernel iteration): everything bit-equal to the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(2, 48, 3))
+    if seed % 4 == 0:
+        dims = (int(rng.integers(60, 140)), int(rng.integers(2, 20)), int(rng.integers(2, 20)))
+    s, lam = [(7, 0.1), (7, 0.05), (7, 0.2), (7, 0.4)][seed % 4]
+    alpha, w_reg = float(rng.uniform(0.005, 0.08)), float(rng.uniform(0.0, 0.9))
+    iters = int(rng.integers(1, 7))
+    pg, pn = rand_volume(dims, 2000 + seed), rand_volume(dims, 3000 + seed)
+    psi0 = warped_identity(oracle, dims, 4000 + seed, float(rng.uniform(0.0, 1.2)))
+    psi = psi0.copy()
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=iters, alpha=alpha, w_reg=w_reg, s=s, lam=lam, verbosity=2, inverse_iters=48)
+    norms = r["trace"][:, 2]
+    thr = float(norms[len(norms) // 2]) if seed % 3 == 0 and iters > 1 else -1.0
+    if thr >= 0:
+        psi = psi0.copy()
+        r = oracle.estimate_psi(pg, pn, psi, max_iter=iters, alpha=alpha, w_reg=w_reg, s=s, lam=lam, max_update_norm=thr, verbosity=2,
+                                inverse_iters=48)
+    for mode in ("quiet", "verbose", "fused"):
+        sv = ops.Solver(dims, max_iter=iters, alpha=alpha, w_reg=w_reg, s=s, lam=lam, max_update_norm=thr, verbosity=2 if mode == "verbose" else 0)
+        if mode == "fused":
+            sv.set_fused(True)
+        psi_d, psi_inv_d, pnp_d, pgi_d = dev(psi0), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+        rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+        assert rep.iterations == r["iters"], (mode, dims)
+        assert same(host(psi_d), psi) and same(host(pnp_d), r["phi_n_psi"]), (mode, dims)
+        assert same(host(psi_inv_d), r["psi_inv"]) and same(host(pgi_d), r["phi_global_psi_inv"]), (mode, dims)
+        assert same(hist[:r["iters"]], r["trace"][:r["iters"], 2]), (mode, dims)
+        sv.close()
+
+
 def test_solver_rejects_bad_filter(ops):
     from sobfu_amd._lib import HipError
 
