@@ -170,6 +170,10 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
+    if (rc == 0) {  // max-norm slot rows for 4096 iterations up front: a solve never reallocates inside a timed region
+        rc = (int) hipMalloc((void**) &t->slots, (size_t) (4096 + 1) * kSlots * 4);
+        if (rc == 0) t->slots_iters = 4096;
+    }
     if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
