@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--dim", type=int, default=256, help="grid edge (256 = the BASELINE metric's grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: every rank solves its OWN grid (independent sequences, BASELINE config 5 style: no exchange, weak "
+                         "scaling) instead of the default -- ONE grid cut into N z-slabs with RCCL halo exchange (strong scaling)")
     args = ap.parse_args()
 
     import torch
@@ -98,7 +101,7 @@ def main():
 
     P = boxing_params(args.dim)
     force_tiled = os.environ.get("SOBFU_FORCE_TILED") == "1"  # exercise the slab path on one GPU (debugging)
-    if world > 1 or force_tiled:
+    if (world > 1 and not args.replicas) or force_tiled:
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -130,7 +133,8 @@ def main():
         assert np.isfinite(hist).all() and float(hist.max()) > 0
         ms_a, ms_b, n = sv.get_profile()
         res = dict(seconds=dt, N=N, ms_a=ms_a / max(n, 1), ms_b=ms_b / max(n, 1), last_norm=float(hist[-1]),
-                   workspace=sv.workspace_bytes(), parallelism="single")
+                   workspace=sv.workspace_bytes(),
+                   parallelism="single" if world == 1 else f"{world} independent {args.dim}^3 sequences, one per GPU (replicas, no exchange)")
         sv.close()
 
     if dist.is_initialized():
@@ -140,7 +144,8 @@ def main():
         res["seconds"] = float(t.item())
 
     if rank == 0:
-        its = args.steps / res["seconds"]
+        replicas = world > 1 and args.replicas
+        its = (world if replicas else 1) * args.steps / res["seconds"]
         N = res["N"]
         ach_b = N * B_PASS_B / (res["ms_b"] * 1e-3) / 1e9 if res.get("ms_b") else None
         pmc = None
@@ -152,7 +157,7 @@ def main():
             "metric": f"solver iterations/sec on {args.dim}^3 voxel grid",
             "value": its, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * res["seconds"] / args.steps, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if (world > 1 and not replicas) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.dim}^3 TSDF, params_boxing.ini solver values (alpha 0.001, w_reg 0.6, S=7, "
                                    f"lambda 0.1, max_update_norm 1e-10), two analytic spheres 1.3 voxels apart, "
                                    f"{args.steps} solver iterations per solve",
