@@ -125,9 +125,13 @@ def main():
         sv.set_profiling(True)
         sv.get_profile(reset=True)
         torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
         t0 = time.perf_counter()
         rep, hist = sv.iterate(pg, pn, pnp, psi, args.steps)
         torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
         dt = time.perf_counter() - t0
         assert rep.iterations == args.steps, (rep.iterations, args.steps)
         assert np.isfinite(hist).all() and float(hist.max()) > 0
