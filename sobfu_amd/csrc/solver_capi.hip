@@ -364,6 +364,9 @@ int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const s
         s->bytes = s->N * 16 + 65536 * 8;
         rc = ensure_slots(s, params->max_iter > 0 ? params->max_iter : 1);
     }
+    // the quiet path's compact state is part of the workspace from the start (like the reference's constructor, which
+    // allocates everything up front): the first solve of a sequence pays no allocation
+    if (rc == 0 && s->compact && params->verbosity == 0) rc = ensure_compact(s);
     if (rc != 0) {
         sobfu_hip_solver_destroy(s);
         return rc;
