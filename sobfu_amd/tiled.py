@@ -369,6 +369,52 @@ class NativeTiledSolver:
         return TiledSolver.gather_owned(self, local)
 
 
+def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iters=60):
+    """Per-piece timings of the native loop on the machine at hand (microseconds; rank 0's view after a MAX over ranks)."""
+    import os
+
+    L, lib, check = solver.layout, solver._lib.lib(), solver._lib.check
+    X, Y, _ = dims
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / n * 1e6], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    field = torch.zeros((L.Lz, Y, X, 3), dtype=torch.float32, device="cuda")
+    out["exchange_4_planes_us"] = timed(lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(HALO), st), "exchange"), reps)
+    out["exchange_bytes_per_face"] = HALO * X * Y * 12
+    slots = torch.zeros(SLOTS, dtype=torch.int32, device="cuda")
+    out["allreduce_256_slots_us"] = timed(lambda: check(lib.sobfu_hip_tiled_allreduce_max_u32(solver._h, C.c_void_p(slots.data_ptr()), C.c_size_t(SLOTS), st), "allreduce"), reps)
+    pnp, psi = solver.new_local(2), solver.identity_psi()
+
+    def loop(s):
+        return lambda: s.iterate(pg, pn_full, pnp, psi, iters)
+
+    prev = os.environ.get("SOBFU_TILED_SPLIT_A")
+    for name, val in (("iteration_us_pass_a_unsplit", "0"), ("iteration_us_pass_a_split", "1")):
+        os.environ["SOBFU_TILED_SPLIT_A"] = val
+        out[name] = timed(loop(solver), 2) / iters
+    if prev is None:
+        os.environ.pop("SOBFU_TILED_SPLIT_A", None)
+    else:
+        os.environ["SOBFU_TILED_SPLIT_A"] = prev
+    out["iteration_us_default_schedule"] = timed(loop(solver), 2) / iters
+    dry = NativeTiledSolver(dims, dry=(world, rank), **kw)  # same slab, no peers: the compute side alone
+    out["iteration_us_compute_only"] = timed(loop(dry), 2) / iters
+    dry.close()
+    return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}
+
+
 def bench_tiled(P, steps, warmup, rank, world):
     """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N z-slabs (strong scaling)."""
     from . import ops
@@ -436,6 +482,14 @@ def bench_tiled(P, steps, warmup, rank, world):
         parity = bool(int(ok.item()))
         if not parity:
             print(f"[rank {rank}] tiled self-check: slab differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
-    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
+    # diagnostics for the next tuning round, outside the timed region (every rank takes part in the collective ones):
+    # what one halo exchange, one slot all-reduce and the compute side alone cost on THIS machine, and both pass-A schedules
+    diag = None
+    if native and os.environ.get("SOBFU_TILED_DIAG", "1") == "1":
+        try:
+            diag = _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank)
+        except Exception as e:  # noqa: BLE001 -- diagnostics must never take the benchmark down
+            print(f"[rank {rank}] tiled diagnostics failed: {e}", file=sys.stderr, flush=True)
+    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity, tiled_diag=diag,
                 parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange, "
                             + ("native C++ loop" if native else "torch.distributed loop"))
