@@ -189,6 +189,10 @@ def main():
             out["tiled_parity_vs_single_gpu"] = "bit-exact" if res["tiled_parity"] else "MISMATCH"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P)
+    if res.get("diag_hung"):  # a diagnostics collective never returned on this rank: report what was measured and leave
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        os._exit(0)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

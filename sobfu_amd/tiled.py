@@ -484,12 +484,28 @@ def bench_tiled(P, steps, warmup, rank, world):
             print(f"[rank {rank}] tiled self-check: slab differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
     # diagnostics for the next tuning round, outside the timed region (every rank takes part in the collective ones):
     # what one halo exchange, one slot all-reduce and the compute side alone cost on THIS machine, and both pass-A schedules
-    diag = None
+    diag, hung = None, False
     if native and os.environ.get("SOBFU_TILED_DIAG", "1") == "1":
-        try:
-            diag = _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank)
-        except Exception as e:  # noqa: BLE001 -- diagnostics must never take the benchmark down
-            print(f"[rank {rank}] tiled diagnostics failed: {e}", file=sys.stderr, flush=True)
-    return dict(seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity, tiled_diag=diag,
+        # in a worker thread with a deadline: whatever happens in there (an exception on one rank would leave the others
+        # waiting in a collective), the benchmark line is still printed
+        import threading
+
+        box, dev_index = {}, torch.cuda.current_device()
+
+        def work():
+            try:
+                torch.cuda.set_device(dev_index)
+                box["diag"] = _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank)
+            except Exception as e:  # noqa: BLE001
+                box["error"] = repr(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("SOBFU_TILED_DIAG_TIMEOUT", "120")))
+        hung = th.is_alive()
+        diag = box.get("diag") or {"error": "timed out" if hung else box.get("error", "unknown")}
+        if "error" in diag:
+            print(f"[rank {rank}] tiled diagnostics: {diag['error']}", file=sys.stderr, flush=True)
+    return dict(diag_hung=hung, seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity, tiled_diag=diag,
                 parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange, "
                             + ("native C++ loop" if native else "torch.distributed loop"))
