@@ -21,6 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only does dmabuf IPC (RCCL across processes needs it)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 B_PASS_B = 64           # nabla_U r16 + psi r16 w16 + phi_n gather 8 + phi_n o psi w8
