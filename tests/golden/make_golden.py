@@ -9,6 +9,9 @@ also compared against committed data, independent of each other's builds:
     kernels_17x9x5.npz   per-kernel outputs on an odd-sized volume: gradient, negative Laplacian, Jacobian (mode 1), potential
                          gradient, the three convolutions, psi update, warp, 5-sweep inverse, fusion
 
+    mesh_14x11x9.npz     marching cubes of a small ellipsoid-like volume with unobserved holes: occupied-voxel table, vertices, normals
+                         (volume -> world pose with a rotation)
+
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import os
@@ -79,9 +82,27 @@ def kernel_fixture():
                         reg_energy=np.float32(O.reg_energy_sobolev(J)), max_update=np.array(O.max_update_norm(upd), np.float32))
 
 
+def mesh_fixture():
+    dims = (14, 11, 9)
+    X, Y, Z = dims
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    sdf = np.sqrt(((x - 6.3) / 5.1) ** 2 + ((y - 5.2) / 3.9) ** 2 + ((z - 4.1) / 3.2) ** 2) - 1.0
+    vol = np.stack([np.clip(sdf, -1, 1), (hash_field((Z, Y, X), 77) > -0.9).astype(np.float32)], -1).astype(np.float32)
+    R = np.array([[0.36, 0.48, -0.8], [-0.8, 0.6, 0.0], [0.48, 0.64, 0.6]], np.float32)
+    t = np.array([0.05, -0.1, 0.2], np.float32)
+    size = (0.7, 0.55, 0.45)
+    occ, count = O.mc_occupied_voxels(vol, 4096)
+    total = O.mc_offsets(occ, count)
+    v, n = O.marching_cubes(vol, size, R, t)
+    assert len(v) == total > 300
+    np.savez_compressed(os.path.join(HERE, "mesh_14x11x9.npz"), vol=vol, R=R, t=t, size=np.array(size, np.float32), occupied=occ[:, :count],
+                        vertices=v, normals=n)
+
+
 if __name__ == "__main__":
     O.build()
     solver_fixture()
     kernel_fixture()
+    mesh_fixture()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
