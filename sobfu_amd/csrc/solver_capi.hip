@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kSlots      = 256;
 constexpr int kCheckEvery = 32;
+constexpr int kMaxRunAhead = 96;  // iterations the host may enqueue beyond the last max-norm row it has examined
 constexpr int kProfEvery  = 8;
 
 float host_sqrt_rd(float s) {  // __fsqrt_rd
@@ -62,6 +63,9 @@ struct sobfu_hip_solver {
     float* c_psi2 = nullptr;  // 12 B/voxel
     float* c_f2   = nullptr;  //  4 B/voxel
     uint32_t* slots    = nullptr;  // (slots_iters + 1) x 256
+    uint32_t* h_rows   = nullptr;  // pinned mirror of the slot rows for the non-blocking convergence poll
+    int h_rows_iters   = 0;
+    hipEvent_t ev_chk  = nullptr;
     void* red_scratch  = nullptr;  // 65536 x 8 B block partials
     int slots_iters    = 0;
     bool keep_updates  = false;
@@ -102,6 +106,18 @@ int ensure_slots(sobfu_hip_solver* s, int iters) {
     SOBFU_HIP_TRY(hipMalloc((void**) &s->slots, (size_t) (iters + 1) * kSlots * 4));
     s->slots_iters = iters;
     s->bytes += (size_t) (iters + 1) * kSlots * 4;
+    return 0;
+}
+
+// pinned host mirror + event for the convergence poll (rows are copied asynchronously; the host never drains the stream
+// just to look at them)
+int ensure_poll(sobfu_hip_solver* s, int iters) {
+    if (!s->ev_chk) SOBFU_HIP_TRY(hipEventCreateWithFlags(&s->ev_chk, hipEventDisableTiming));
+    if (iters <= s->h_rows_iters) return 0;
+    if (s->h_rows) SOBFU_HIP_TRY(hipHostFree(s->h_rows));
+    s->h_rows = nullptr;
+    SOBFU_HIP_TRY(hipHostMalloc((void**) &s->h_rows, (size_t) iters * kSlots * 4, hipHostMallocDefault));
+    s->h_rows_iters = iters;
     return 0;
 }
 
@@ -201,7 +217,9 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
     if (prof) SOBFU_TRY(ensure_events(s, (size_t) 3 * max_iter));
     int launched = 0;
     if (!verbose) {
-        int checked = 0;
+        int checked = 0, fl_to = 0;
+        bool in_flight = false;
+        if (can_converge) SOBFU_TRY(ensure_poll(s, max_iter));
         for (int it = 1; it <= max_iter && !converged; ++it) {
             const uint32_t* prev = (it > 1) ? s->slots + (size_t) (it - 1) * kSlots : nullptr;
             uint32_t* cur        = s->slots + (size_t) it * kSlots;
@@ -222,23 +240,44 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
             }
             if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 2], st));
             launched = it;
-            if (can_converge && (it % kCheckEvery == 0 || it == max_iter)) {
-                const int n = it - checked;
-                hs.resize((size_t) n * kSlots);
-                SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + (size_t) (checked + 1) * kSlots, hs.size() * 4,
-                                             hipMemcpyDeviceToHost, st));
-                SOBFU_HIP_TRY(hipStreamSynchronize(st));
-                for (int k = 0; k < n; ++k) {
-                    float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
-                    if (per_iter) per_iter[checked + k] = v;
-                    r.last_max_update_norm = v;
-                    done = checked + k + 1;
-                    if (v <= p.max_update_norm) {  // solver.cu:183 -- later launches were device-side no-ops
-                        converged = true;
-                        break;
+            if (can_converge) {
+                // the host looks at the max-norm rows WITHOUT draining the stream: every kCheckEvery iterations the finished
+                // rows are copied to pinned memory behind the kernels, and the copy's event is polled; the host may run
+                // at most kMaxRunAhead iterations past the last row it has seen (launches after the break are no-ops,
+                // but each still costs a few us)
+                auto examine = [&](int upto) {
+                    for (int k = checked; k < upto && !converged; ++k) {
+                        float v = slots_to_norm(s->h_rows + (size_t) k * kSlots);
+                        if (per_iter) per_iter[k] = v;
+                        r.last_max_update_norm = v;
+                        done = k + 1;
+                        if (v <= p.max_update_norm) converged = true;  // solver.cu:183 -- later launches were device-side no-ops
+                    }
+                    checked = upto;
+                };
+                if (!in_flight && (it % kCheckEvery == 0 || it == max_iter)) {
+                    SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) checked * kSlots, s->slots + (size_t) (checked + 1) * kSlots,
+                                                 (size_t) (it - checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
+                    SOBFU_HIP_TRY(hipEventRecord(s->ev_chk, st));
+                    in_flight = true;
+                    fl_to     = it;
+                }
+                if (in_flight) {
+                    const bool must_wait = it == max_iter || it - checked >= kMaxRunAhead;
+                    hipError_t q = must_wait ? hipEventSynchronize(s->ev_chk) : hipEventQuery(s->ev_chk);
+                    if (q == hipSuccess) {
+                        examine(fl_to);
+                        in_flight = false;
+                        if (!converged && it == max_iter && checked < it) {  // rows launched after the copy was issued
+                            SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) checked * kSlots, s->slots + (size_t) (checked + 1) * kSlots,
+                                                         (size_t) (it - checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
+                            SOBFU_HIP_TRY(hipStreamSynchronize(st));
+                            examine(it);
+                        }
+                    } else if (q != hipErrorNotReady) {
+                        return (int) q;
                     }
                 }
-                checked = it;
             }
         }
         if (!can_converge) {
@@ -381,6 +420,8 @@ int sobfu_hip_solver_destroy(sobfu_hip_solver* s) {
     if (s->updates) (void) hipFree(s->updates);
     if (s->slots) (void) hipFree(s->slots);
     if (s->red_scratch) (void) hipFree(s->red_scratch);
+    if (s->h_rows) (void) hipHostFree(s->h_rows);
+    if (s->ev_chk) (void) hipEventDestroy(s->ev_chk);
     for (float* q : {s->c_psi, s->c_f, s->c_g, s->c_n, s->c_psi2, s->c_f2})
         if (q) (void) hipFree(q);
     for (hipEvent_t e : s->events) (void) hipEventDestroy(e);
