@@ -277,6 +277,9 @@ class TiledSolver:
                     break
         return done, norms[:done]
 
+    def estimate_psi(self, *args, **kw):
+        return estimate_psi_tiled(self, *args, **kw)
+
     def gather_owned(self, local):
         """all_gather of the owned planes -> full volume on every rank (z-concatenation)."""
         own = self.layout.owned(local).contiguous()
@@ -287,6 +290,31 @@ class TiledSolver:
                  for r in range(self.world)]
         dist.all_gather(parts, own, group=self.group)
         return torch.cat(parts, dim=0)
+
+
+def estimate_psi_tiled(solver, phi_global_local, phi_global_psi_inv_local, phi_n_full, phi_n_psi_local, psi_local, psi_inv_local,
+                       n_iters, inverse_iters=48, gather=None):
+    """One frame's Solver::estimate_psi (src/sobfu/cuda/solver.cu:85-205) on slabs: the tiled iteration loop, then the
+    two per-frame collectives of SURVEY 8(e) -- all-gather psi for the 48-sweep inverse (it gathers psi at arbitrary
+    psi^-1(x)), all-gather phi_global for the canonical -> live warp -- each followed by the slab kernel.  HIP backend only
+    (C ABI: sobfu_hip_tile_init_identity / tile_estimate_inverse / tile_apply).  `gather` overrides solver.gather_owned
+    (tests).  Returns (iterations, per-iteration max norms)."""
+    from . import _lib
+
+    L = solver.layout
+    X, Y, Z = L.dims
+    lib, st = _lib.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gather = gather or solver.gather_owned
+    done, norms = solver.iterate(phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters)
+    psi_full = gather(psi_local)                                                              # solver.cu:196-197
+    _lib.check(lib.sobfu_hip_tile_init_identity(C.c_void_p(psi_inv_local.data_ptr()), X, Y, L.Lz, L.zbase, st), "tile_init_identity")
+    _lib.check(lib.sobfu_hip_tile_estimate_inverse(C.c_void_p(psi_full.data_ptr()), Z, C.c_void_p(psi_inv_local.data_ptr()), X, Y, L.Lz,
+                                                   L.zbase, C.c_int(inverse_iters), st), "tile_estimate_inverse")
+    pg_full = gather(phi_global_local)                                                        # solver.cu:199
+    _lib.check(lib.sobfu_hip_tile_apply(C.c_void_p(pg_full.data_ptr()), Z, C.c_void_p(phi_global_psi_inv_local.data_ptr()),
+                                        C.c_void_p(psi_inv_local.data_ptr()), X, Y, L.Lz, st), "tile_apply")
+    torch.cuda.current_stream().synchronize()  # psi_full / pg_full die with this frame
+    return done, norms
 
 
 class NativeTiledSolver:
@@ -304,6 +332,7 @@ class NativeTiledSolver:
 
         self._lib = _lib
         L = _lib.lib()
+        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
@@ -367,6 +396,9 @@ class NativeTiledSolver:
 
     def gather_owned(self, local):
         return TiledSolver.gather_owned(self, local)
+
+    def estimate_psi(self, *args, **kw):
+        return estimate_psi_tiled(self, *args, **kw)
 
 
 def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iters=60):

@@ -140,3 +140,86 @@ def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
             assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), np.asarray(hist_r[:expect], np.float32).view(np.uint32))
         assert np.array_equal(psi_t[..., :3].view(np.uint32), psi_e.cpu().numpy()[..., :3].view(np.uint32))
         assert np.array_equal(pnp_t.view(np.uint32), pnp_e.cpu().numpy().view(np.uint32))
+
+
+class LoopGather:
+    """all_gather of the owned planes between the rank threads of one process (stands in for dist.all_gather)"""
+
+    def __init__(self, n):
+        self.parts, self.bar = [None] * n, threading.Barrier(n)
+
+    def make(self, rank, layout):
+        import torch
+
+        def gather(local):
+            torch.cuda.current_stream().synchronize()
+            self.parts[rank] = layout.owned(local).contiguous()
+            torch.cuda.current_stream().synchronize()
+            self.bar.wait(timeout=60)
+            full = torch.cat(self.parts, 0)
+            torch.cuda.current_stream().synchronize()
+            self.bar.wait(timeout=60)  # nobody replaces its part while a peer is still concatenating
+            return full
+
+        return gather
+
+
+@pytest.mark.parametrize("dims,world", [((40, 24, 36), 3), ((33, 17, 16), 4)])
+def test_tiled_frame_estimate_psi_loopback(dims, world):
+    """A whole frame on slabs (iterations, all-gather psi -> 48-sweep inverse, all-gather phi_global -> canonical warp) =
+    the single-GPU Solver::estimate_psi, bit for bit, on every rank's owned planes."""
+    import torch
+
+    import oracle
+    from sobfu_amd import ops, tiled
+
+    rng = np.random.default_rng(9)
+    X, Y, Z = dims
+    pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    psi0 = oracle.new_field(dims)
+    oracle.init_identity(psi0)
+    psi0[..., :3] += rng.uniform(-0.5, 0.5, psi0[..., :3].shape).astype(np.float32)
+    n_iters = 5
+    ref = ops.Solver(dims, max_iter=n_iters, alpha=0.05, w_reg=0.4)
+    psi_r, inv_r, pnp_r, pgi_r = torch.from_numpy(psi0.copy()).cuda(), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+    ref.estimate_psi(torch.from_numpy(pg).cuda(), pgi_r, torch.from_numpy(pn).cuda(), pnp_r, psi_r, inv_r)
+    ref.close()
+
+    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(world, r)) for r in range(world)]
+    lb, lg = Loopback(solvers, X, Y), LoopGather(world)
+    for s in solvers:
+        s.set_transport(lb.exchange, lb.allreduce)
+    pn_d = torch.from_numpy(pn).cuda()
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            s = solvers[r]
+            L = s.layout
+            with torch.cuda.stream(torch.cuda.Stream()):
+                pg_l = torch.from_numpy(np.ascontiguousarray(L.take(pg))).cuda()
+                psi_l = torch.from_numpy(np.ascontiguousarray(L.take(psi0))).cuda()
+                pnp_l, pgi_l, inv_l = s.new_local(2), s.new_local(2), s.new_local(4)
+                done, _ = s.estimate_psi(pg_l, pgi_l, pn_d, pnp_l, psi_l, inv_l, n_iters, gather=lg.make(r, L))
+                torch.cuda.current_stream().synchronize()
+            out[r] = (done, L.owned(psi_l).cpu().numpy(), L.owned(pnp_l).cpu().numpy(), L.owned(inv_l).cpu().numpy(), L.owned(pgi_l).cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            lb.bar.abort()
+            lg.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errs, errs
+    for s in solvers:
+        s.close()
+    cat = lambda i: np.concatenate([o[i] for o in out], 0)  # noqa: E731
+    assert all(o[0] == n_iters for o in out)
+    assert np.array_equal(cat(1)[..., :3].view(np.uint32), psi_r.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(cat(2).view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
+    assert np.array_equal(cat(3)[..., :3].view(np.uint32), inv_r.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(cat(4).view(np.uint32), pgi_r.cpu().numpy().view(np.uint32))
