@@ -54,6 +54,12 @@ int sobfu_hip_integrate_depth(const float* d_dists, int dists_step_bytes, int ro
                               int Y, int Z, const float voxel_size[3], float trunc_dist, float eta,
                               const float R[9], const float t[3], float fx, float fy, float cx, float cy,
                               void* stream);
+/* The same on a z-slab of a larger volume (multi-GPU tiles): local planes [0, Lz) are global planes [zbase, zbase + Lz);
+ * the per-slice accumulation of the camera-frame z (tsdf_volume.cu:76) is replayed from global plane 0, so the slab holds
+ * exactly the planes the whole-volume call would produce. */
+int sobfu_hip_tile_integrate_depth(const float* d_dists, int dists_step_bytes, int rows, int cols, float* d_vol_local, int X,
+                                   int Y, int Lz, int zbase, const float voxel_size[3], float trunc_dist, float eta,
+                                   const float R[9], const float t[3], float fx, float fy, float cx, float cy, void* stream);
 /* integrate(phi_global, phi_n_psi) (tsdf_volume.cu:103-130,164-173): running weighted average fusion. */
 int sobfu_hip_integrate_fuse(float* d_phi_global, const float* d_phi_n_psi, int X, int Y, int Z, float max_weight,
                              void* stream);

@@ -23,6 +23,7 @@ struct IntegrateArgs {
     float vsx, vsy, vsz, trunc, eta;
     float R[9], t[3];
     float fx, fy, cx, cy;
+    int zbase;  // global z of local plane 0 (multi-GPU slabs; 0 for a whole volume)
 };
 
 // TsdfIntegrator::operator()(TsdfVolume&) -- tsdf_volume.cu:62-101
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(256) integrate_depth_kernel(IntegrateArgs a) {
     float camx = dot3(a.R + 0, vcx, vcy, vcz) + a.t[0];
     float camy = dot3(a.R + 3, vcx, vcy, vcz) + a.t[1];
     float camz = dot3(a.R + 6, vcx, vcy, vcz) + a.t[2];
-    for (int i = 0; i < z0; ++i) camx += 0.f, camy += 0.f, camz += a.vsz;  // replay of `vc_cam += zstep` (:76)
+    for (int i = 0; i < z0 + a.zbase; ++i) camx += 0.f, camy += 0.f, camz += a.vsz;  // replay of `vc_cam += zstep` (:76)
     int z1 = min(z0 + kZC, a.d.z);
     for (int z = z0; z < z1; ++z, camx += 0.f, camy += 0.f, camz += a.vsz) {
         float coox = __builtin_fmaf(a.fx, camx / camz, a.cx), cooy = __builtin_fmaf(a.fy, camy / camz, a.cy);
@@ -196,10 +197,21 @@ int sobfu_hip_integrate_depth(const float* d_dists, int step, int rows, int cols
                               const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx,
                               float fy, float cx, float cy, void* stream) {
     SOBFU_CHECK_ARGS(d_dists && d_vol && vs && R && t && X > 0 && Y > 0 && Z > 0 && rows > 0 && cols > 0 && step >= cols * 4);
-    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol, {X, Y, Z}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy};
+    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol, {X, Y, Z}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, 0};
     for (int i = 0; i < 9; ++i) a.R[i] = R[i];
     for (int i = 0; i < 3; ++i) a.t[i] = t[i];
     hipLaunchKernelGGL(integrate_depth_kernel, chunk_grid(X, Y, Z), voxel_block(), 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile_integrate_depth(const float* d_dists, int step, int rows, int cols, float* d_vol_local, int X, int Y, int Lz, int zbase,
+                                   const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx, float fy,
+                                   float cx, float cy, void* stream) {
+    SOBFU_CHECK_ARGS(d_dists && d_vol_local && vs && R && t && X > 0 && Y > 0 && Lz > 0 && zbase >= 0 && rows > 0 && cols > 0 && step >= cols * 4);
+    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol_local, {X, Y, Lz}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, zbase};
+    for (int i = 0; i < 9; ++i) a.R[i] = R[i];
+    for (int i = 0; i < 3; ++i) a.t[i] = t[i];
+    hipLaunchKernelGGL(integrate_depth_kernel, chunk_grid(X, Y, Lz), voxel_block(), 0, (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }
 

@@ -317,6 +317,52 @@ def estimate_psi_tiled(solver, phi_global_local, phi_global_psi_inv_local, phi_n
     return done, norms
 
 
+class TiledFusion:
+    """SobFusion::operator() (src/sobfu/sob_fusion.cpp:71-145) with the volume cut into z-slabs: every rank runs the depth
+    pre-steps (640 x 480: negligible), integrates ITS slab of phi_global and the whole phi_n (the warp gathers anywhere), the
+    solve runs tiled, the fusion touches owned planes only.  phi_global / phi_n o psi / psi / psi^-1 live as local slabs.
+
+    params: dims, size (metres), trunc, eta (metres), max_weight, intr (fx, fy, cx, cy), R, t (volume -> camera), start_frame,
+    bilateral (ksz, sigma_spatial, sigma_depth), trunc_depth, max_iter; `solver` is a TiledSolver / NativeTiledSolver."""
+
+    def __init__(self, solver, params, gather=None):
+        from . import ops
+
+        self.ops, self.solver, self.P, self.gather = ops, solver, params, gather
+        self.L = solver.layout
+        self.frame = 0
+        X, Y, Z = self.L.dims
+        self.vs = tuple(float(params["size"][i]) / self.L.dims[i] for i in range(3))
+        self.phi_global = self.phi_n = self.phi_n_psi = self.phi_global_psi_inv = self.psi = self.psi_inv = None
+
+    def __call__(self, depth_u16):
+        ops, P, L, s = self.ops, self.P, self.L, self.solver
+        ks, ss, sd = P["bilateral"]
+        d = ops.bilateral_filter(depth_u16, ks, ss, sd)                              # sob_fusion.cpp:78
+        ops.truncate_depth(d, P["trunc_depth"])                                      # :85
+        dists = ops.compute_dists(d, P["intr"])                                      # :91
+        if self.frame == 0:                                                          # :93-123
+            self.phi_global = s.new_local(2)
+            ops.tile_integrate_depth(dists, self.phi_global, L.zbase, self.vs, P["trunc"], P["eta"], P["R"], P["t"], P["intr"])
+            self.phi_n = ops.new_volume(L.dims)
+            self.phi_n_psi, self.phi_global_psi_inv = s.new_local(2), s.new_local(2)
+            self.psi, self.psi_inv = s.identity_psi(), s.identity_psi()
+            self.frame += 1
+            return None
+        ops.clear_volume(self.phi_n)                                                 # :129
+        ops.integrate_depth(dists, self.phi_n, self.vs, P["trunc"], P["eta"], P["R"], P["t"], P["intr"])  # :130
+        own = slice(L.own_lo, L.own_hi)
+        result = None
+        if self.frame < P["start_frame"]:                                            # :136-139
+            ops.integrate_fuse(self.phi_global[own], L.owned(L.take(self.phi_n)).contiguous(), P["max_weight"])
+        else:
+            result = s.estimate_psi(self.phi_global, self.phi_global_psi_inv, self.phi_n, self.phi_n_psi, self.psi, self.psi_inv,
+                                    P["max_iter"], gather=self.gather)               # :141
+            ops.integrate_fuse(self.phi_global[own], self.phi_n_psi[own], P["max_weight"])  # :142 (owned planes)
+        self.frame += 1
+        return result
+
+
 class NativeTiledSolver:
     """The same slab loop run entirely in C++ (sobfu_amd/csrc/tiled_capi.hip): RCCL send/recv issued from the library on
     a dedicated communication stream, overlapped with the interior compute, no Python per iteration.  torch.distributed is

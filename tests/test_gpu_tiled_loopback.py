@@ -223,3 +223,77 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     assert np.array_equal(cat(2).view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
     assert np.array_equal(cat(3)[..., :3].view(np.uint32), inv_r.cpu().numpy()[..., :3].view(np.uint32))
     assert np.array_equal(cat(4).view(np.uint32), pgi_r.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_fusion_frames_loopback(world):
+    """BASELINE config 1 (64^3, translating sphere, three frames) through TiledFusion on N slabs = the same frames through the
+    single-GPU launchers: phi_global after every frame and psi at the end, bit for bit."""
+    import torch
+
+    from sobfu_amd import ops, synthetic, tiled
+
+    dims, size = (64, 64, 64), (0.5, 0.5, 0.5)
+    vs = 0.5 / 64
+    intr = (570.342, 570.342, 320.0, 240.0)
+    P = dict(size=size, trunc=5 * vs, eta=2 * vs, max_weight=128.0, intr=intr, R=np.eye(3, dtype=np.float32),
+             t=np.array([-0.25, -0.25, 0.5], np.float32), start_frame=1, bilateral=(7, 4.5, 0.005), trunc_depth=1.5, max_iter=6)
+    frames = [torch.from_numpy(synthetic.render_sphere_depth((0.005 * n, 0.0, 0.75), 0.1, intr, 480, 640)).cuda() for n in range(3)]
+    kw = dict(alpha=0.1, w_reg=0.2)
+
+    # single-GPU pipeline through the same launchers
+    sv = ops.Solver(dims, max_iter=P["max_iter"], **kw)
+    pg, pn, pnp, pgi = (ops.new_volume(dims) for _ in range(4))
+    psi, psi_inv = ops.new_field(dims), ops.new_field(dims)
+    ops.init_identity(psi)
+    ops.init_identity(psi_inv)
+    ref_pg = []
+    for n, f in enumerate(frames):
+        d = ops.bilateral_filter(f, *P["bilateral"])
+        ops.truncate_depth(d, P["trunc_depth"])
+        dists = ops.compute_dists(d, intr)
+        if n == 0:
+            ops.integrate_depth(dists, pg, (vs,) * 3, P["trunc"], P["eta"], P["R"], P["t"], intr)
+        else:
+            ops.clear_volume(pn)
+            ops.integrate_depth(dists, pn, (vs,) * 3, P["trunc"], P["eta"], P["R"], P["t"], intr)
+            sv.estimate_psi(pg, pgi, pn, pnp, psi, psi_inv)
+            ops.integrate_fuse(pg, pnp, P["max_weight"])
+        ref_pg.append(pg.cpu().numpy().copy())
+    sv.close()
+
+    solvers = [tiled.NativeTiledSolver(dims, dry=(world, r), **kw) for r in range(world)]
+    lb, lg = Loopback(solvers, dims[0], dims[1]), LoopGather(world)
+    for s in solvers:
+        s.set_transport(lb.exchange, lb.allreduce)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                fu = tiled.TiledFusion(solvers[r], P, gather=lg.make(r, solvers[r].layout))
+                L, pgs = solvers[r].layout, []
+                for f in frames:
+                    fu(f)
+                    torch.cuda.current_stream().synchronize()
+                    pgs.append(L.owned(fu.phi_global).cpu().numpy().copy())
+                out[r] = (pgs, L.owned(fu.psi).cpu().numpy(), L.owned(fu.psi_inv).cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            lb.bar.abort()
+            lg.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=240)
+    assert not errs, errs
+    for s in solvers:
+        s.close()
+    for n in range(3):
+        got = np.concatenate([o[0][n] for o in out], 0)
+        assert np.array_equal(got.view(np.uint32), ref_pg[n].view(np.uint32)), n
+    assert np.array_equal(np.concatenate([o[1] for o in out], 0)[..., :3].view(np.uint32), psi.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(np.concatenate([o[2] for o in out], 0)[..., :3].view(np.uint32), psi_inv.cpu().numpy()[..., :3].view(np.uint32))
+    assert float(np.abs(psi.cpu().numpy()[..., 0] - np.arange(64)[None, None, :]).max()) > 1e-3  # the solves really moved psi
