@@ -87,6 +87,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:  # only rank 0 owns stdout: libraries (RCCL's version banner) write there from every process, some at exit
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -192,14 +194,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(P)
     if res.get("diag_hung"):  # a diagnostics collective never returned on this rank: report what was measured and leave
         if rank == 0:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
             print(json.dumps(out), flush=True)
         os._exit(0)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:  # after the process group is gone, so the JSON is the LAST line on stdout (RCCL prints a banner there)
+    if rank == 0:  # after the process group is gone, and after flushing C stdio (RCCL's version banner sits in libc's stdout
+        # buffer until exit when stdout is a pipe), so that the JSON is the LAST line on stdout
+        import ctypes
+
         sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+        os._exit(0)  # nothing (destructors, atexit hooks of the communication libraries) may write to stdout after the line
 
 
 if __name__ == "__main__":
