@@ -291,6 +291,9 @@ int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, 
 int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
                             float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
                             float* per_iter_max_norm, void* stream);
+/* diagnostics: host microseconds per iteration the last sobfu_hip_tiled_iterate spent ISSUING its loop (launches, events,
+ * RCCL calls) -- against the measured time per iteration it tells whether a thin slab is host-bound */
+double sobfu_hip_tiled_last_enqueue_us(const sobfu_hip_tiled* t);
 /* Pluggable transport for communicator-less handles (MPI, an in-process loopback for tests, ...).  `exchange` must make
  * planes [own_lo - planes, own_lo) / [own_hi, own_hi + planes) of the 12-byte slab field equal to the neighbours'
  * [own_hi - planes, own_hi) / [own_lo, own_lo + planes) (local plane indices of each rank); `allreduce_max` must leave the

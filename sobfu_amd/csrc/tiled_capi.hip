@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +83,7 @@ struct sobfu_hip_tiled {
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
+    double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
 };
 
 extern "C" {
@@ -204,6 +206,8 @@ int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_f
     return 0;
 }
 
+double sobfu_hip_tiled_last_enqueue_us(const sobfu_hip_tiled* t) { return t ? t->last_enqueue_us : 0.0; }
+
 int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, int* hi, int* Lz, int* zbase) {
     SOBFU_CHECK_ARGS(t);
     if (z0) *z0 = t->z0;
@@ -312,6 +316,7 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
     const bool split_a = (t->lo || t->hi) && a_hi > a_lo && (sa ? sa[0] == '1' : (hi - lo) <= kSplitAMaxPlanes);
     bool red_pending = false;  // an all-reduce has been issued on the comm stream and ev_red recorded behind it
+    const auto host_t0 = std::chrono::steady_clock::now();
     for (int it = 1; it <= n_iters; ++it) {
         const float *psi_in = P[(it - 1) & 1], *f_in = F[(it - 1) & 1];
         float *psi_out = P[it & 1], *f_out = F[it & 1];
@@ -350,6 +355,8 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
     }
+    if (n_iters > 0)
+        t->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / n_iters;
     if (multi && n_iters > 0) {  // rows the loop has not reduced yet: all of them without a threshold, the tail otherwise
         if (red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
         const int first = can_converge ? std::max(1, n_iters - 1) : 1;  // rows 1 .. n_iters-2 went through the comm stream

@@ -487,6 +487,8 @@ def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iter
     else:
         os.environ["SOBFU_TILED_SPLIT_A"] = prev
     out["iteration_us_default_schedule"] = timed(loop(solver), 2) / iters
+    lib.sobfu_hip_tiled_last_enqueue_us.restype = C.c_double
+    out["host_enqueue_us_per_iteration"] = float(lib.sobfu_hip_tiled_last_enqueue_us(solver._h))
     dry = NativeTiledSolver(dims, dry=(world, rank), **kw)  # same slab, no peers: the compute side alone
     out["iteration_us_compute_only"] = timed(loop(dry), 2) / iters
     dry.close()
