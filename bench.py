@@ -186,6 +186,8 @@ def main():
             "last_max_update_norm": res.get("last_norm"),
             "solver_workspace_bytes": res.get("workspace"),
         }
+        if res.get("tiled_autotune_us"):
+            out["tiled_autotune_us"] = res["tiled_autotune_us"]
         if res.get("tiled_diag"):  # N > 1: what the pieces of the native loop cost on this machine (outside the timed region)
             out["tiled_diag"] = res["tiled_diag"]
         if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its slab bitwise

@@ -83,6 +83,7 @@ struct sobfu_hip_tiled {
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
+    int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
 };
 
@@ -206,6 +207,12 @@ int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_f
     return 0;
 }
 
+int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule) {
+    SOBFU_CHECK_ARGS(t && schedule >= 0 && schedule <= 3);
+    t->schedule = schedule;
+    return 0;
+}
+
 double sobfu_hip_tiled_last_enqueue_us(const sobfu_hip_tiled* t) { return t ? t->last_enqueue_us : 0.0; }
 
 int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, int* hi, int* Lz, int* zbase) {
@@ -313,8 +320,12 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
     // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
     // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N >= 4 at 256^3, if a face takes the ~65 us that ~60 GB/s per xGMI direction implies)
+    // the schedule (results do not depend on it): environment (debugging) > sobfu_hip_tiled_set_schedule (autotuner) > heuristic
     const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
-    const bool split_a = (t->lo || t->hi) && a_hi > a_lo && (sa ? sa[0] == '1' : (hi - lo) <= kSplitAMaxPlanes);
+    const char* se = std::getenv("SOBFU_TILED_SERIAL");
+    const bool want_split = sa ? sa[0] == '1' : (t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes));
+    const bool split_a = (t->lo || t->hi) && a_hi > a_lo && want_split;
+    const bool serial = se ? se[0] == '1' : t->schedule == 3;
     bool red_pending = false;  // an all-reduce has been issued on the comm stream and ev_red recorded behind it
     const auto host_t0 = std::chrono::steady_clock::now();
     for (int it = 1; it <= n_iters; ++it) {
@@ -329,6 +340,16 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
             return sobfu_hip::launch_pass_b(t->nU, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev,
                                             p.max_update_norm, 0, st, Z, lo, hi, true, za, zb, za2, zb2, psi_out, it > 3 ? 2 : 1);
         };
+        if (serial) {
+            // no overlap, no cross-stream events: pass A, the exchange and pass B in line on `st`.  Every event record / wait
+            // between two kernels costs a few microseconds of drained pipeline (~20 us per iteration for the overlapped
+            // schedule's three), which a fast exchange on a thin slab does not repay.
+            SOBFU_TRY(A(lo, hi));
+            if (multi) SOBFU_TRY(exchange(t, t->nU, H, st));
+            SOBFU_TRY(B(b_first, b_last));
+            if (multi && can_converge && it >= 2 && it < n_iters) SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, st));
+            continue;
+        }
         // both boundary regions of a pass go out as ONE launch (two plane ranges)
         if (split_a) SOBFU_TRY(A(lo, a_lo, a_hi, hi));
         else SOBFU_TRY(A(lo, hi));

@@ -446,6 +446,33 @@ class NativeTiledSolver:
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)
 
+    SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)"}
+
+    def set_schedule(self, schedule):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_set_schedule(self._h, C.c_int(int(schedule))), "tiled_set_schedule")
+        self.schedule = int(schedule)
+
+    def autotune(self, phi_global_local, phi_n_full, iters=40):
+        """Times the three ways of issuing an iteration on THIS machine (they give identical results) on scratch state and keeps
+        the fastest; every rank takes part and all agree (MAX over ranks).  Returns {schedule: us per iteration}."""
+        pnp, psi = self.new_local(2), self.identity_psi()
+        times = {}
+        for sched in self.SCHEDULES:
+            self.set_schedule(sched)
+            self.iterate(phi_global_local, phi_n_full, pnp, psi, 4)
+            torch.cuda.synchronize()
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            self.iterate(phi_global_local, phi_n_full, pnp, psi, iters)
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / iters * 1e6], dtype=torch.float64, device="cuda")
+            if dist.is_initialized():
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            times[sched] = float(t.item())
+        self.set_schedule(min(times, key=times.get))
+        return times
+
 
 def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iters=60):
     """Per-piece timings of the native loop on the machine at hand (microseconds; rank 0's view after a MAX over ranks)."""
@@ -486,6 +513,9 @@ def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iter
         os.environ.pop("SOBFU_TILED_SPLIT_A", None)
     else:
         os.environ["SOBFU_TILED_SPLIT_A"] = prev
+    os.environ["SOBFU_TILED_SERIAL"] = "1"  # pass A, exchange, pass B in line on one stream (no overlap, no events)
+    out["iteration_us_serial_schedule"] = timed(loop(solver), 2) / iters
+    os.environ.pop("SOBFU_TILED_SERIAL", None)
     out["iteration_us_default_schedule"] = timed(loop(solver), 2) / iters
     lib.sobfu_hip_tiled_last_enqueue_us.restype = C.c_double
     out["host_enqueue_us_per_iteration"] = float(lib.sobfu_hip_tiled_last_enqueue_us(solver._h))
@@ -531,6 +561,9 @@ def bench_tiled(P, steps, warmup, rank, world):
     del pg_full
     pnp = solver.new_local(2)
     psi = solver.identity_psi()
+    tuned = None
+    if native and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":  # outside the timed region: pick this machine's best schedule
+        tuned = solver.autotune(pg, pn_full)
     if warmup > 0:
         solver.iterate(pg, pn_full, pnp, psi, warmup)
     torch.cuda.synchronize()
@@ -588,4 +621,6 @@ def bench_tiled(P, steps, warmup, rank, world):
             print(f"[rank {rank}] tiled diagnostics: {diag['error']}", file=sys.stderr, flush=True)
     return dict(diag_hung=hung, seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity, tiled_diag=diag,
                 parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange, "
-                            + ("native C++ loop" if native else "torch.distributed loop"))
+                            + ("native C++ loop" if native else "torch.distributed loop")
+                            + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ""),
+                tiled_autotune_us={solver.SCHEDULES[k]: round(v, 2) for k, v in tuned.items()} if tuned else None)
