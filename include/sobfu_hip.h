@@ -293,7 +293,8 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
                             float* per_iter_max_norm, void* stream);
 /* How an iteration is issued (the results never depend on it): 0 = built-in heuristic, 1 = exchange overlapped with the interior
  * compute, pass A split into boundary + interior launches, 2 = overlapped, pass A in one launch, 3 = serial (pass A, exchange,
- * pass B in line on one stream: no cross-stream events -- the better choice when the exchange is fast and the slab thin).
+ * pass B in line on one stream: no cross-stream events -- the better choice when the exchange is fast and the slab thin),
+ * 4 = serial with the max-norm all-reduce on the comm stream (two event edges instead of an exposed collective).
  * Which one wins depends on the machine's exchange latency; sobfu_amd.tiled.NativeTiledSolver.autotune times all three. */
 int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule);
 /* diagnostics: host microseconds per iteration the last sobfu_hip_tiled_iterate spent ISSUING its loop (launches, events,

@@ -83,7 +83,7 @@ struct sobfu_hip_tiled {
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
-    int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
+    int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial, 4 serial + reduction on the comm stream
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
 };
 
@@ -208,7 +208,7 @@ int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_f
 }
 
 int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule) {
-    SOBFU_CHECK_ARGS(t && schedule >= 0 && schedule <= 3);
+    SOBFU_CHECK_ARGS(t && schedule >= 0 && schedule <= 4);
     t->schedule = schedule;
     return 0;
 }
@@ -325,7 +325,8 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const char* se = std::getenv("SOBFU_TILED_SERIAL");
     const bool want_split = sa ? sa[0] == '1' : (t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes));
     const bool split_a = (t->lo || t->hi) && a_hi > a_lo && want_split;
-    const bool serial = se ? se[0] == '1' : t->schedule == 3;
+    const bool serial = se ? se[0] == '1' : (t->schedule == 3 || t->schedule == 4);
+    const bool async_reduce = t->schedule == 4;
     bool red_pending = false;  // an all-reduce has been issued on the comm stream and ev_red recorded behind it
     const auto host_t0 = std::chrono::steady_clock::now();
     for (int it = 1; it <= n_iters; ++it) {
@@ -344,10 +345,19 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
             // no overlap, no cross-stream events: pass A, the exchange and pass B in line on `st`.  Every event record / wait
             // between two kernels costs a few microseconds of drained pipeline (~20 us per iteration for the overlapped
             // schedule's three), which a fast exchange on a thin slab does not repay.
+            const bool reduce_now = multi && can_converge && it >= 2 && it < n_iters;  // row it-1: the gate of iteration it+1
+            if (reduce_now && async_reduce) {  // schedule 4: the reduction rides the comm stream beside this iteration
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
+                SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
+                SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
+            }
             SOBFU_TRY(A(lo, hi));
             if (multi) SOBFU_TRY(exchange(t, t->nU, H, st));
+            if (multi && prev && red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));  // issued one iteration ago
             SOBFU_TRY(B(b_first, b_last));
-            if (multi && can_converge && it >= 2 && it < n_iters) SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, st));
+            if (reduce_now && async_reduce) red_pending = true;
+            if (reduce_now && !async_reduce) SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, st));
             continue;
         }
         // both boundary regions of a pass go out as ONE launch (two plane ranges)

@@ -446,7 +446,8 @@ class NativeTiledSolver:
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)
 
-    SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)"}
+    SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)",
+                 4: "serial, max-norm all-reduce on the comm stream"}
 
     def set_schedule(self, schedule):
         self._lib.check(self._lib.lib().sobfu_hip_tiled_set_schedule(self._h, C.c_int(int(schedule))), "tiled_set_schedule")

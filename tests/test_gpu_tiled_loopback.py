@@ -61,7 +61,7 @@ class Loopback:
             return -1
 
 
-def run_world(dims, world, psi0, pg, pn, n_iters, thr):
+def run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule=None):
     import torch
 
     from sobfu_amd import tiled
@@ -71,6 +71,8 @@ def run_world(dims, world, psi0, pg, pn, n_iters, thr):
     lb = Loopback(solvers, X, Y)
     for s in solvers:
         s.set_transport(lb.exchange, lb.allreduce)
+        if schedule is not None:
+            s.set_schedule(schedule)
     pn_d = torch.from_numpy(pn).cuda()
     out, errs = [None] * world, []
 
@@ -102,15 +104,19 @@ def run_world(dims, world, psi0, pg, pn, n_iters, thr):
 
 
 @pytest.mark.parametrize("dims,world,split", [((40, 24, 36), 3, None), ((40, 24, 36), 3, "1"), ((33, 17, 16), 4, None), ((20, 12, 120), 2, None),
-                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0"), ((40, 24, 36), 3, "serial"), ((33, 17, 16), 4, "serial")])
+                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0"), ((40, 24, 36), 3, "serial"), ((33, 17, 16), 4, "serial"),
+                                               ((40, 24, 36), 3, "sched4"), ((33, 17, 16), 2, "sched4")])
 def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
     import torch
 
     import oracle
     from sobfu_amd import ops
 
+    schedule = None
     if split == "serial":
         monkeypatch.setenv("SOBFU_TILED_SERIAL", "1")
+    elif split == "sched4":
+        schedule = 4
     elif split is not None:
         monkeypatch.setenv("SOBFU_TILED_SPLIT_A", split)
     rng = np.random.default_rng(5)
@@ -134,7 +140,7 @@ def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
             assert rep.iterations == expect
         else:
             psi_e, pnp_e = psi_r, pnp_r
-        out = run_world(dims, world, psi0, pg, pn, n_iters, thr)
+        out = run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule)
         psi_t = np.concatenate([o[2] for o in out], 0)
         pnp_t = np.concatenate([o[3] for o in out], 0)
         for done, hist, _, _ in out:
