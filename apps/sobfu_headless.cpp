@@ -5,7 +5,7 @@
 // synthetic translating sphere.  --dump DIR writes psi, psi_inv and the four TSDF volumes as .npy (float32); --mesh DIR
 // writes marching-cubes meshes of the volumes per frame as legacy-ASCII .vtk polydata (the reference: demo.cpp:236-246).
 //
-//   sobfu_headless <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR] [--mesh DIR]
+//   sobfu_headless <params.ini> [--max-iter N] [--verbose|--vverbose] [--dims N] [--dump DIR] [--mesh DIR] [--no-stats]
 //                  (--synthetic FRAMES [--shift DX] | frame0.pgm frame1.pgm ...)
 #include <cmath>
 #include <cstdint>
@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
     int synthetic = 0;
     double shift = 0.005;
     std::string dump, mesh_dir;
+    bool print_stats = true;  // per-frame volume statistics download four volumes: --no-stats leaves only the frame loop (timing runs)
     std::vector<std::string> files;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
@@ -62,6 +63,7 @@ int main(int argc, char** argv) {
         else if (a == "--shift" && i + 1 < argc) shift = std::atof(argv[++i]);
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else if (a == "--mesh" && i + 1 < argc) mesh_dir = argv[++i];
+        else if (a == "--no-stats") print_stats = false;
         else files.push_back(a);
     }
     if (argc > 2) {  // --dims changes the voxel size: re-derive the voxel-unit parameters
@@ -93,7 +95,7 @@ int main(int argc, char** argv) {
             kfusion::SampledScopeTime fps(time_ms);  // demo.cpp:331 -- "avg. frame time" every 34 frames
             fusion(depth);
         }
-        stats("phi_global", *fusion.phi_global);
+        if (print_stats) stats("phi_global", *fusion.phi_global);
         auto save_mesh = [&](const char* name, const sobfu_amd::TriangleMesh& m) {  // demo.cpp:236-246 (name_frame.vtk)
             if (m.empty()) return;
             const std::string path = mesh_dir + "/" + name + "_" + std::to_string(n) + ".vtk";
@@ -108,7 +110,7 @@ int main(int argc, char** argv) {
                 save_mesh("phi_global_psi_inv", fusion.get_phi_global_psi_inv_mesh());
             }
         }
-        if (n > 0) {
+        if (n > 0 && print_stats) {
             stats("phi_n", *fusion.phi_n);
             if (n >= p.start_frame) {
                 stats("phi_n_psi", *fusion.phi_n_psi);
