@@ -98,6 +98,10 @@ int sobfu_hip_apply(const float* d_phi, float* d_phi_warped, const float* d_psi,
 /* estimate_inverse (:111-138): n_sweeps (reference: 48) in-place fixed-point sweeps on d_psi_inv. */
 int sobfu_hip_estimate_inverse(const float* d_psi, float* d_psi_inv, int X, int Y, int Z, int n_sweeps,
                                void* stream);
+/* The tail of Solver::estimate_psi fused (solver.cu:196-199): psi_inv <- identity, n_sweeps fixed-point sweeps, and
+ * phi_warped = phi o psi_inv, in one pass (same values as init_identity + estimate_inverse + apply). */
+int sobfu_hip_inverse_and_warp(const float* d_psi, float* d_psi_inv, const float* d_phi, float* d_phi_warped, int X, int Y, int Z,
+                               int n_sweeps, void* stream);
 /* TsdfDifferentiator::calculate (:144-208): central-difference gradient, exact 0 on boundary faces. */
 int sobfu_hip_tsdf_gradient(const float* d_vol, float* d_grad, int X, int Y, int Z, void* stream);
 /* SecondOrderDifferentiator::calculate (:278-337): NEGATIVE 7-point Laplacian of psi. */

@@ -36,12 +36,8 @@ __global__ void __launch_bounds__(256) apply_kernel(const float2* __restrict__ p
 // The float iteration soon repeats itself: once a sweep returns its input bit for bit every later sweep does too, and once
 // it returns the value before that (period 2) the tail just alternates -- in both cases the value after n_sweeps is known
 // and the lane stops (same bits as running all sweeps; typically < 10 of the 48 are needed).
-__global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
-                                                                  Dims d, Dims pd, int zbase, int n_sweeps) {
-    VOXEL_XYZ(d);
-    size_t i = vidx(d, x, y, z);
-    float4 v = psi_inv[i], w = v;  // p_it, p_(it-1)
-    const float4 id = f4((float) x, (float) y, (float) (z + zbase));
+SOBFU_DEV float4 inverse_fixed_point(const float4* __restrict__ psi, const Dims& pd, float4 v, const float4& id, int n_sweeps) {
+    float4 w = v;  // p_it = v, p_(it-1) = w
     auto same = [](const float4& a, const float4& b) {
         return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
                __float_as_uint(a.z) == __float_as_uint(b.z);
@@ -61,7 +57,29 @@ __global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* 
         w = v;
         v = nv;
     }
-    psi_inv[i] = v;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
+                                                                  Dims d, Dims pd, int zbase, int n_sweeps) {
+    VOXEL_XYZ(d);
+    size_t i = vidx(d, x, y, z);
+    const float4 id = f4((float) x, (float) y, (float) (z + zbase));
+    psi_inv[i] = inverse_fixed_point(psi, pd, psi_inv[i], id, n_sweeps);
+}
+
+// The tail of Solver::estimate_psi in one pass (solver.cu:196-199): psi^-1 <- identity, 48 sweeps, phi_global o psi^-1.
+// The lane still holds psi^-1(x) when it warps phi_global there: no identity field is written and read back, psi^-1 is not
+// re-read by the warp.
+__global__ void __launch_bounds__(256) inverse_from_identity_and_warp_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
+                                                                             const float2* __restrict__ phi, float2* __restrict__ phi_warped,
+                                                                             Dims d, int n_sweeps) {
+    VOXEL_XYZ(d);
+    size_t i = vidx(d, x, y, z);
+    const float4 id = f4((float) x, (float) y, (float) z);
+    const float4 v  = inverse_fixed_point(psi, d, id, id, n_sweeps);
+    psi_inv[i]      = v;
+    phi_warped[i]   = interp_tsdf(phi, d, v.x, v.y, v.z);
 }
 
 // TsdfDifferentiator::operator() -- vector_fields.cu:157-208 (mirrored neighbour on boundary faces => exact 0)
@@ -165,6 +183,15 @@ int sobfu_hip_estimate_inverse(const float* d_psi, float* d_psi_inv, int X, int 
     if (n_sweeps == 0) return 0;
     LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, Dims{X, Y, Z}, 0,
                  n_sweeps);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_inverse_and_warp(const float* d_psi, float* d_psi_inv, const float* d_phi, float* d_phi_warped, int X, int Y, int Z,
+                               int n_sweeps, void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && d_psi_inv && d_phi && d_phi_warped && X > 0 && Y > 0 && Z > 0 && n_sweeps >= 0 && d_psi != d_psi_inv &&
+                     d_phi != d_phi_warped);
+    LAUNCH_VOXEL(inverse_from_identity_and_warp_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, (const float2*) d_phi,
+                 (float2*) d_phi_warped, Dims{X, Y, Z}, n_sweeps);
     return (int) hipGetLastError();
 }
 

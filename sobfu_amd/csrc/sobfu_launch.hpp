@@ -23,4 +23,8 @@ int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream
 int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
 int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);
 int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z = 0);
+// whole-volume enter / leave of the compact format in one pass each (solver handle)
+int launch_compact_enter(const float* psi4, const float* pg2, const float* pn2, float* c_psi, float* c_g, float* c_n, float* c_f, int X, int Y,
+                         int Z, hipStream_t stream);
+int launch_compact_leave(const float* c_psi, const float* pn2, float* psi4, float* pnp2, int X, int Y, int Z, hipStream_t stream);
 }  // namespace sobfu_hip

@@ -203,10 +203,7 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
     float *it_psi = psi, *it_out = pnp;
     if (compact) {
         SOBFU_TRY(ensure_compact(s));
-        SOBFU_TRY(sobfu_hip::launch_pack_vec(psi, s->c_psi, s->N, st));
-        SOBFU_TRY(sobfu_hip::launch_extract_tsdf(pg, s->c_g, s->N, st));
-        SOBFU_TRY(sobfu_hip::launch_extract_tsdf(pn, s->c_n, s->N, st));
-        SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(s->c_n, s->c_f, s->c_psi, X, Y, Z, st));  // solver.cu:106
+        SOBFU_TRY(sobfu_hip::launch_compact_enter(psi, pg, pn, s->c_psi, s->c_g, s->c_n, s->c_f, X, Y, Z, st));  // incl. solver.cu:106
         it_pnp = s->c_f; it_pg = s->c_g; it_pn = s->c_n; it_psi = s->c_psi; it_out = s->c_f;
     }
     const bool fused = compact && s->fused && upd == nullptr;
@@ -293,8 +290,8 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
         }
         if (compact) {
             // `done` iterations actually executed (later launches were no-ops): the state is in ping-pong buffer done&1
-            SOBFU_TRY(sobfu_hip::launch_unpack_vec(fused ? pp_psi[done & 1] : s->c_psi, psi, s->N, st));
-            SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // the state solver.cu:168 leaves behind
+            // psi.xyz back + phi_n o psi = apply(phi_n, psi), the state solver.cu:168 leaves behind, in one pass
+            SOBFU_TRY(sobfu_hip::launch_compact_leave(fused ? pp_psi[done & 1] : s->c_psi, pn, psi, pnp, X, Y, Z, st));
         }
         if (prof) s->prof_pending = (done < launched ? done : launched) / kProfEvery;  // sampled iterations; read in get_profile()
         // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
@@ -510,9 +507,8 @@ int sobfu_hip_solver_estimate_psi(sobfu_hip_solver* s, const float* d_phi_global
     SOBFU_CHECK_ARGS(s && d_phi_global && d_phi_global_psi_inv && d_phi_n && d_phi_n_psi && d_psi && d_psi_inv);
     hipStream_t st = (hipStream_t) stream;
     SOBFU_TRY(run_loop(s, d_phi_global, d_phi_n, d_phi_n_psi, d_psi, s->p.max_iter, report, per_iter_max_norm, st));
-    SOBFU_TRY(sobfu_hip_init_identity(d_psi_inv, s->X, s->Y, s->Z, st));                               // solver.cu:196
-    SOBFU_TRY(sobfu_hip_estimate_inverse(d_psi, d_psi_inv, s->X, s->Y, s->Z, 48, st));                 // solver.cu:197
-    SOBFU_TRY(sobfu_hip_apply(d_phi_global, d_phi_global_psi_inv, d_psi_inv, s->X, s->Y, s->Z, st));   // solver.cu:199
+    // solver.cu:196-199 in one pass: psi^-1 <- identity, 48 sweeps, phi_global o psi^-1
+    SOBFU_TRY(sobfu_hip_inverse_and_warp(d_psi, d_psi_inv, d_phi_global, d_phi_global_psi_inv, s->X, s->Y, s->Z, 48, st));
     return (int) hipStreamSynchronize(st);
 }
 

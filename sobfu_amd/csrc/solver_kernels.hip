@@ -900,6 +900,32 @@ __global__ void __launch_bounds__(256) apply_tsdf_only_kernel(const float* __res
     out[i]   = interp_tsdf_only(phi, pd, p.x, p.y, p.z);
 }
 
+// Entering / leaving the compact format in ONE pass each (the solver handle's whole-volume case; the slab loop keeps the
+// separate kernels because its phi_n is a different, larger array than its slab fields):
+//   enter: psi float4 -> 12-byte psi, tsdf channels of phi_global / phi_n, F = interpolate_tsdf(phi_n, psi).tsdf (solver.cu:106)
+//   leave: 12-byte psi -> psi.xyz (w untouched), phi_n o psi = interpolate_tsdf(phi_n, psi) (the state solver.cu:168 leaves)
+__global__ void __launch_bounds__(256) compact_enter_kernel(const float4* __restrict__ psi4, const float2* __restrict__ pg2,
+                                                            const float2* __restrict__ pn2, P3* __restrict__ c_psi, float* __restrict__ c_g,
+                                                            float* __restrict__ c_n, float* __restrict__ c_f, Dims d) {
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z;
+    if (x >= d.x || y >= d.y) return;
+    const size_t i = vidx(d, x, y, z);
+    const float4 p = psi4[i];
+    stv<true>(c_psi, i, p);
+    c_g[i] = pg2[i].x;
+    c_n[i] = pn2[i].x;
+    c_f[i] = interp_tsdf(pn2, d, p.x, p.y, p.z).x;  // same lerp chain on the same tsdf values as interp_tsdf_only on c_n
+}
+__global__ void __launch_bounds__(256) compact_leave_kernel(const P3* __restrict__ c_psi, const float2* __restrict__ pn2,
+                                                            float4* __restrict__ psi4, float2* __restrict__ pnp2, Dims d) {
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z;
+    if (x >= d.x || y >= d.y) return;
+    const size_t i = vidx(d, x, y, z);
+    const float4 p = ldv<true>(c_psi, i);
+    *(v3f_u*) ((float*) (psi4 + i)) = v3f{p.x, p.y, p.z};
+    pnp2[i] = interp_tsdf(pn2, d, p.x, p.y, p.z);
+}
+
 }  // namespace
 
 // Tile configuration of the fused passes (see DESIGN.md "Kernel tuning").
@@ -1012,6 +1038,17 @@ int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, in
     return (int) hipGetLastError();
 }
 #undef SOBFU_LIN
+int launch_compact_enter(const float* psi4, const float* pg2, const float* pn2, float* c_psi, float* c_g, float* c_n, float* c_f, int X, int Y,
+                         int Z, hipStream_t stream) {
+    hipLaunchKernelGGL(compact_enter_kernel, voxel_grid(X, Y, Z), voxel_block(), 0, stream, (const float4*) psi4, (const float2*) pg2,
+                       (const float2*) pn2, (P3*) c_psi, c_g, c_n, c_f, Dims{X, Y, Z});
+    return (int) hipGetLastError();
+}
+int launch_compact_leave(const float* c_psi, const float* pn2, float* psi4, float* pnp2, int X, int Y, int Z, hipStream_t stream) {
+    hipLaunchKernelGGL(compact_leave_kernel, voxel_grid(X, Y, Z), voxel_block(), 0, stream, (const P3*) c_psi, (const float2*) pn2,
+                       (float4*) psi4, (float2*) pnp2, Dims{X, Y, Z});
+    return (int) hipGetLastError();
+}
 
 }  // namespace sobfu_hip
 
