@@ -295,10 +295,14 @@ int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, 
 int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
                             float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
                             float* per_iter_max_norm, void* stream);
+/* Optional: a second communicator (a second ncclGetUniqueId, broadcast like the first) and a stream of its own for the max-norm
+ * all-reduce of a live threshold.  With it the reduction of iteration k's row is issued right after that iteration's pass B and
+ * runs beside iteration k+1 (the late gate only needs it by pass B of k+2) without ever queueing behind a halo exchange on the
+ * main communicator; without it the reduction shares the exchange's communicator (comm stream, or in line when serial). */
+int sobfu_hip_tiled_add_reduce_comm(sobfu_hip_tiled* t, const char unique_id[128]);
 /* How an iteration is issued (the results never depend on it): 0 = built-in heuristic, 1 = exchange overlapped with the interior
  * compute, pass A split into boundary + interior launches, 2 = overlapped, pass A in one launch, 3 = serial (pass A, exchange,
- * pass B in line on one stream: no cross-stream events -- the better choice when the exchange is fast and the slab thin),
- * 4 = serial with the max-norm all-reduce on the comm stream (two event edges instead of an exposed collective).
+ * pass B in line on one stream: no cross-stream events -- the better choice when the exchange is fast and the slab thin).
  * Which one wins depends on the machine's exchange latency; sobfu_amd.tiled.NativeTiledSolver.autotune times all three. */
 int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule);
 /* diagnostics: host microseconds per iteration the last sobfu_hip_tiled_iterate spent ISSUING its loop (launches, events,

@@ -77,13 +77,17 @@ struct sobfu_hip_tiled {
     sobfu_hip_tiled_allreduce_fn rfn = nullptr;
     void* tctx = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_red = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_row = nullptr, ev_red[2] = {nullptr, nullptr};
+    // optional second communicator + stream for the max-norm all-reduce (sobfu_hip_tiled_add_reduce_comm): it then never queues
+    // behind (or in front of) a halo exchange on the main communicator
+    ncclComm_t comm2 = nullptr;
+    hipStream_t red_stream = nullptr;
     // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
     float *nU = nullptr, *c_psi = nullptr, *c_psi2 = nullptr, *c_f = nullptr, *c_f2 = nullptr, *c_g = nullptr, *c_n = nullptr;
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
-    int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial, 4 serial + reduction on the comm stream
+    int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
 };
 
@@ -134,7 +138,10 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (t->slots) (void) hipFree(t->slots);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
-    if (t->ev_red) (void) hipEventDestroy(t->ev_red);
+    for (hipEvent_t e : {t->ev_red[0], t->ev_red[1], t->ev_row})
+        if (e) (void) hipEventDestroy(e);
+    if (t->red_stream) (void) hipStreamDestroy(t->red_stream);
+    if (t->comm2 && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm2);
     if (t->comm_stream) (void) hipStreamDestroy(t->comm_stream);
     if (t->comm && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm);
     delete t;
@@ -180,7 +187,13 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
-    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red, hipEventDisableTiming);
+    // the max-norm rows travel between streams of THIS device only (pass B's atomics -> the all-reduce kernel -> the next
+    // pass B's gate): their events skip the system-scope fence (an L2 write-back + invalidate around a drained pipeline);
+    // ev_bnd / ev_xchg order data other GPUs read or wrote and keep it
+    const unsigned local_ev = hipEventDisableTiming | (std::getenv("SOBFU_TILED_SYSFENCE_EVENTS") ? 0u : hipEventDisableSystemFence);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red[0], local_ev);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red[1], local_ev);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_row, local_ev);
     if (rc == 0 && !dry) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, 128);
@@ -207,8 +220,17 @@ int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_f
     return 0;
 }
 
+int sobfu_hip_tiled_add_reduce_comm(sobfu_hip_tiled* t, const char unique_id[128]) {
+    SOBFU_CHECK_ARGS(t && unique_id && t->comm && !t->comm2);
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, 128);
+    RCCL_TRY(g_rccl.CommInitRank(&t->comm2, t->world, id, t->rank));
+    SOBFU_HIP_TRY(hipStreamCreateWithFlags(&t->red_stream, hipStreamNonBlocking));
+    return 0;
+}
+
 int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule) {
-    SOBFU_CHECK_ARGS(t && schedule >= 0 && schedule <= 4);
+    SOBFU_CHECK_ARGS(t && schedule >= 0 && schedule <= 3);
     t->schedule = schedule;
     return 0;
 }
@@ -243,9 +265,9 @@ static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t s
     return 0;
 }
 
-static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_t stream) {
+static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_t stream, bool own_comm = false) {
     if (!t->comm) return t->rfn ? t->rfn(t->tctx, t->rank, buf, n, (void*) stream) : 0;
-    RCCL_TRY(g_rccl.AllReduce(buf, buf, n, ncclUint32, ncclMax, t->comm, stream));
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, n, ncclUint32, ncclMax, own_comm ? t->comm2 : t->comm, stream));
     return 0;
 }
 
@@ -325,9 +347,13 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const char* se = std::getenv("SOBFU_TILED_SERIAL");
     const bool want_split = sa ? sa[0] == '1' : (t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes));
     const bool split_a = (t->lo || t->hi) && a_hi > a_lo && want_split;
-    const bool serial = se ? se[0] == '1' : (t->schedule == 3 || t->schedule == 4);
-    const bool async_reduce = t->schedule == 4;
-    bool red_pending = false;  // an all-reduce has been issued on the comm stream and ev_red recorded behind it
+    const bool serial = se ? se[0] == '1' : t->schedule == 3;
+    // Where the all-reduce of a max-norm row runs (the late gate gives row j until pass B of iteration j+2):
+    //   own communicator + stream (sobfu_hip_tiled_add_reduce_comm): issued right after row j's pass B, never in the way of
+    //   an exchange; otherwise on the comm stream behind the next exchange (overlapped schedules) or in line (serial).
+    enum { RED_NONE, RED_INLINE, RED_COMM_STREAM, RED_OWN_COMM };
+    const int red_mode = (!multi || !can_converge) ? RED_NONE : (t->comm2 ? RED_OWN_COMM : (serial ? RED_INLINE : RED_COMM_STREAM));
+    bool red_issued[2] = {false, false};  // an asynchronous reduce of the latest row of this parity is behind ev_red[parity]
     const auto host_t0 = std::chrono::steady_clock::now();
     for (int it = 1; it <= n_iters; ++it) {
         const float *psi_in = P[(it - 1) & 1], *f_in = F[(it - 1) & 1];
@@ -341,23 +367,32 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
             return sobfu_hip::launch_pass_b(t->nU, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev,
                                             p.max_update_norm, 0, st, Z, lo, hi, true, za, zb, za2, zb2, psi_out, it > 3 ? 2 : 1);
         };
+        auto wait_gate = [&]() -> int {  // row it-2 must be global before the first pass-B launch of this iteration
+            if (prev && red_issued[it & 1]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[it & 1], 0));
+            return 0;
+        };
+        auto after_b = [&]() -> int {  // row `it` is complete on `st`; it gates iteration it+2
+            if (it > n_iters - 2) return 0;  // the tail rows are reduced once, after the loop
+            uint32_t* r_ = t->slots + (size_t) it * kSlots;
+            if (red_mode == RED_INLINE) SOBFU_TRY(allreduce_max(t, r_, kSlots, st));
+            if (red_mode == RED_OWN_COMM) {
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_row, st));
+                SOBFU_HIP_TRY(hipStreamWaitEvent(t->red_stream, t->ev_row, 0));
+                SOBFU_TRY(allreduce_max(t, r_, kSlots, t->red_stream, true));
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_red[it & 1], t->red_stream));
+                red_issued[it & 1] = true;
+            }
+            return 0;
+        };
         if (serial) {
             // no overlap, no cross-stream events: pass A, the exchange and pass B in line on `st`.  Every event record / wait
             // between two kernels costs a few microseconds of drained pipeline (~20 us per iteration for the overlapped
             // schedule's three), which a fast exchange on a thin slab does not repay.
-            const bool reduce_now = multi && can_converge && it >= 2 && it < n_iters;  // row it-1: the gate of iteration it+1
-            if (reduce_now && async_reduce) {  // schedule 4: the reduction rides the comm stream beside this iteration
-                SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
-                SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
-                SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
-                SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
-            }
             SOBFU_TRY(A(lo, hi));
             if (multi) SOBFU_TRY(exchange(t, t->nU, H, st));
-            if (multi && prev && red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));  // issued one iteration ago
+            SOBFU_TRY(wait_gate());
             SOBFU_TRY(B(b_first, b_last));
-            if (reduce_now && async_reduce) red_pending = true;
-            if (reduce_now && !async_reduce) SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, st));
+            SOBFU_TRY(after_b());
             continue;
         }
         // both boundary regions of a pass go out as ONE launch (two plane ranges)
@@ -368,20 +403,20 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
             SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
+            if (red_mode == RED_COMM_STREAM && it >= 2 && it < n_iters) {
+                // row it-1 is complete (its pass B precedes this iteration's ev_bnd, which the comm stream has waited for) and
+                // gates iteration it+1: reduce it behind this iteration's exchange
+                SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_red[(it - 1) & 1], t->comm_stream));
+                red_issued[(it - 1) & 1] = true;
+            }
         }
         if (split_a && a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
-        // the gate row (iteration it-2) was reduced behind the PREVIOUS iteration's exchange: long done, the wait is free
-        if (multi && prev && red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
+        SOBFU_TRY(wait_gate());
         if (b_hi > b_lo) SOBFU_TRY(B(b_lo, b_hi));
         if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
         if (b_lo > b_first || b_last > b_hi) SOBFU_TRY(B(b_first, b_lo, b_hi, b_last));
-        if (multi && can_converge && it >= 2 && it < n_iters) {
-            // row it-1 is complete (its pass B precedes this iteration's ev_bnd, which the comm stream has waited for) and is
-            // the gate of iteration it+1: reduce it now, behind this iteration's exchange
-            SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
-            SOBFU_HIP_TRY(hipEventRecord(t->ev_red, t->comm_stream));
-            red_pending = true;
-        }
+        SOBFU_TRY(after_b());
         // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
@@ -389,7 +424,8 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     if (n_iters > 0)
         t->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / n_iters;
     if (multi && n_iters > 0) {  // rows the loop has not reduced yet: all of them without a threshold, the tail otherwise
-        if (red_pending) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red, 0));
+        for (int q = 0; q < 2; ++q)
+            if (red_issued[q]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[q], 0));
         const int first = can_converge ? std::max(1, n_iters - 1) : 1;  // rows 1 .. n_iters-2 went through the comm stream
         SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (n_iters - first + 1) * kSlots, st));
     }

@@ -396,6 +396,17 @@ class NativeTiledSolver:
         self._h = C.c_void_p()
         X, Y, Z = (int(d) for d in dims)
         _lib.check(L.sobfu_hip_tiled_create(C.byref(self._h), X, Y, Z, self.world, self.rank, uid, C.byref(self.params)), "tiled_create")
+        want2 = os.environ.get("SOBFU_TILED_REDUCE_COMM", "1")  # "force": also on a world of one (bring-up / tests)
+        if dry is None and ((self.world > 1 and want2 == "1") or want2 == "force"):
+            # a communicator of its own for the max-norm all-reduce (collective; every rank or none)
+            uid2 = (C.c_char * 128)()
+            if self.rank == 0:
+                _lib.check(L.sobfu_hip_tiled_unique_id(uid2), "tiled_unique_id")
+            if self.world > 1:
+                box = [bytes(uid2)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                uid2 = (C.c_char * 128).from_buffer_copy(box[0])
+            _lib.check(L.sobfu_hip_tiled_add_reduce_comm(self._h, uid2), "tiled_add_reduce_comm")
         self.layout = SlabLayout(dims, self.world, self.rank)
         v = [C.c_int() for _ in range(6)]
         _lib.check(L.sobfu_hip_tiled_layout(self._h, *[C.byref(x) for x in v]), "tiled_layout")
@@ -446,8 +457,7 @@ class NativeTiledSolver:
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)
 
-    SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)",
-                 4: "serial, max-norm all-reduce on the comm stream"}
+    SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)"}
 
     def set_schedule(self, schedule):
         self._lib.check(self._lib.lib().sobfu_hip_tiled_set_schedule(self._h, C.c_int(int(schedule))), "tiled_set_schedule")

@@ -664,8 +664,12 @@ def test_native_tiled_loop_comm_choreography_on_one_rank(ops, oracle, monkeypatc
     _, hist_r = ref.iterate(dev(pg), dev(pn), pnp_r, psi_r, 6)
     ref.close()
     monkeypatch.setenv("SOBFU_TILED_FORCE_COMM", "1")
-    for thr, expect in ((-1.0, 6), (1e-10, 6), (float(hist_r[2]), 3)):
+    cases = [(thr, expect, own, sched) for thr, expect in ((-1.0, 6), (1e-10, 6), (float(hist_r[2]), 3))
+             for own, sched in (("0", 0), ("force", 1), ("force", 3))]  # shared / own reduce communicator, overlapped / serial
+    for thr, expect, own, sched in cases:
+        monkeypatch.setenv("SOBFU_TILED_REDUCE_COMM", own)
         nt = tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+        nt.set_schedule(sched)
         psi_n, pnp_n = dev(psi0), ops.new_volume(dims)
         done, hist_n = nt.iterate(dev(pg), dev(pn), pnp_n, psi_n, 6)
         assert done == expect and same(hist_n[:done], hist_r[:done])

@@ -104,8 +104,7 @@ def run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule=None):
 
 
 @pytest.mark.parametrize("dims,world,split", [((40, 24, 36), 3, None), ((40, 24, 36), 3, "1"), ((33, 17, 16), 4, None), ((20, 12, 120), 2, None),
-                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0"), ((40, 24, 36), 3, "serial"), ((33, 17, 16), 4, "serial"),
-                                               ((40, 24, 36), 3, "sched4"), ((33, 17, 16), 2, "sched4")])
+                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0"), ((40, 24, 36), 3, "serial"), ((33, 17, 16), 4, "serial")])
 def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
     import torch
 
@@ -115,8 +114,6 @@ def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
     schedule = None
     if split == "serial":
         monkeypatch.setenv("SOBFU_TILED_SERIAL", "1")
-    elif split == "sched4":
-        schedule = 4
     elif split is not None:
         monkeypatch.setenv("SOBFU_TILED_SPLIT_A", split)
     rng = np.random.default_rng(5)
