@@ -507,7 +507,9 @@ def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iter
         return float(t.item())
 
     field = torch.zeros((L.Lz, Y, X, 3), dtype=torch.float32, device="cuda")
-    out["exchange_4_planes_us"] = timed(lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(HALO), st), "exchange"), reps)
+    for planes in (1, 2, HALO):  # latency vs bandwidth of a face message: 1/4, 1/2 and all of the loop's halo
+        out[f"exchange_{planes}_planes_us"] = timed(
+            lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(planes), st), "exchange"), reps)
     out["exchange_bytes_per_face"] = HALO * X * Y * 12
     slots = torch.zeros(SLOTS, dtype=torch.int32, device="cuda")
     out["allreduce_256_slots_us"] = timed(lambda: check(lib.sobfu_hip_tiled_allreduce_max_u32(solver._h, C.c_void_p(slots.data_ptr()), C.c_size_t(SLOTS), st), "allreduce"), reps)
