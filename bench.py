@@ -211,7 +211,9 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
-        os._exit(0)  # nothing (destructors, atexit hooks of the communication libraries) may write to stdout after the line
+        # nothing may follow the line on stdout (RCCL writes banners from destructors / at exit): point fd 1 at /dev/null for the
+        # rest of the process instead of killing it -- exit hooks (rocprofv3 writing its results) must still run
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":
