@@ -234,6 +234,15 @@ int sobfu_hip_solver_estimate_psi(sobfu_hip_solver* s, const float* d_phi_global
 int sobfu_hip_solver_iterate(sobfu_hip_solver* s, const float* d_phi_global, const float* d_phi_n,
                              float* d_phi_n_psi, float* d_psi, int n_iters, sobfu_hip_solver_report* report,
                              float* per_iter_max_norm, void* stream);
+/* The same loop in pieces (quiet solves only; SOBFU_E_UNSUPPORTED when verbosity > 0).  begin: the warp of solver.cu:106 and the
+ * entry into the iteration format, room for max_iters iterations.  step: ENQUEUES n_iters more iterations and returns without
+ * synchronising (the device-side gate turns every launch after the reference's `break` into a no-op).  end: synchronises, finds
+ * the iteration the reference stops at, rebuilds psi / phi_n_psi exactly as iterate() leaves them, fills report and
+ * per_iter_max_norm (max_iters floats, may be NULL).  One open session per handle; the four buffers must stay valid until end. */
+int sobfu_hip_solver_begin(sobfu_hip_solver* s, const float* d_phi_global, const float* d_phi_n, float* d_phi_n_psi,
+                           float* d_psi, int max_iters, void* stream);
+int sobfu_hip_solver_step(sobfu_hip_solver* s, int n_iters, void* stream);
+int sobfu_hip_solver_end(sobfu_hip_solver* s, sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream);
 /* Pointer to the `updates` buffer (Reductor::updates, src/sobfu/reductor.cpp:26); valid until destroy.  Holds
  * the last iteration's updates only when verbosity > 0 or keep_updates was set. */
 float* sobfu_hip_solver_updates(sobfu_hip_solver* s);
@@ -242,13 +251,11 @@ int sobfu_hip_solver_keep_updates(sobfu_hip_solver* s, int keep);
  * triples, tsdf-only 4-byte phi_global / phi_n / phi_n o psi -- and rebuild the caller's buffers after the loop
  * (76 instead of 112 bytes per voxel-iteration, identical results).  enable = 0 iterates directly on the API buffers. */
 int sobfu_hip_solver_set_compact(sobfu_hip_solver* s, int enable);
-/* Single-kernel iteration for quiet compact solves: nabla_U is recomputed per tile (3-cell halo) and never written to
- * memory; psi / phi_n o psi are ping-ponged.  40 instead of 76 bytes per voxel-iteration, identical results. */
-int sobfu_hip_solver_set_fused(sobfu_hip_solver* s, int enable);
-/* Per-kernel timing of the quiet path with HIP events recorded on the solver's stream around the pass A / pass B
- * launches of every 8th iteration (sampling keeps the probe from slowing the loop); totals and the number of sampled
- * iterations accumulate until reset. */
-int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int enable);
+/* Per-kernel timing of the quiet path: HIP events recorded on the solver's stream around the pass A / pass B launches of
+ * every stride-th iteration (0 = off, 1 = every iteration).  An event between two kernels drains the pipeline (a few
+ * microseconds), so time a profiled run for its kernel split, not for its wall time.  Totals and the number of timed
+ * iterations accumulate until reset; call get_profile only after the stream has been synchronised. */
+int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int stride);
 int sobfu_hip_solver_get_profile(sobfu_hip_solver* s, float* ms_pass_a, float* ms_pass_b, int* launches, int reset);
 /* Callback invoked by estimate_psi for every line the reference prints with std::cout (solver.cu:115-190);
  * NULL (default) = print to stdout like the reference. */

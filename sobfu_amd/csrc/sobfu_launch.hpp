@@ -16,9 +16,6 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
                   float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo = 0,
                   int z_hi = 0, int z_lo2 = 0, int z_hi2 = 0, float* psi_out = nullptr /* null: update psi in place */,
                   int prev_rows = 1 /* rows the gate reads, see solver_converged */);
-int launch_fused_iteration(const float* psi_in3, const float* f_in, const float* g, const float* phi_n1, float* psi_out3, float* f_out,
-                           uint32_t* slots, const float taps[7], float alpha, float w_reg, int X, int Y, int Z, const uint32_t* prev_slots,
-                           float max_update_norm, hipStream_t stream);
 int launch_pack_vec(const float* src4, float* dst3, size_t N, hipStream_t stream);
 int launch_unpack_vec(const float* src3, float* dst4, size_t N, hipStream_t stream);
 int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t stream);

@@ -25,7 +25,6 @@ namespace {
 constexpr int kSlots      = 256;
 constexpr int kCheckEvery = 32;
 constexpr int kMaxRunAhead = 96;  // iterations the host may enqueue beyond the last max-norm row it has examined
-constexpr int kProfEvery  = 8;
 
 float host_sqrt_rd(float s) {  // __fsqrt_rd
     float r = std::sqrt(s);
@@ -58,10 +57,6 @@ struct sobfu_hip_solver {
     float* c_g   = nullptr;  //  4 B/voxel  phi_global.tsdf
     float* c_n   = nullptr;  //  4 B/voxel  phi_n.tsdf
     bool compact = true;
-    // single-kernel iteration (nabla_U never leaves the chip): needs psi / F ping-pong buffers
-    bool fused = false;
-    float* c_psi2 = nullptr;  // 12 B/voxel
-    float* c_f2   = nullptr;  //  4 B/voxel
     uint32_t* slots    = nullptr;  // (slots_iters + 1) x 256
     uint32_t* h_rows   = nullptr;  // pinned mirror of the slot rows for the non-blocking convergence poll
     int h_rows_iters   = 0;
@@ -73,11 +68,26 @@ struct sobfu_hip_solver {
     void* log_user          = nullptr;
     bool log_set            = false;
     size_t bytes            = 0;
-    // optional per-kernel timing (HIP events on the solver's stream)
-    bool profiling = false;
+    // optional per-kernel timing (HIP events on the solver's stream around the launches of every prof_stride-th iteration)
+    int prof_stride = 0;
     std::vector<hipEvent_t> events;
     double ms_a = 0, ms_b = 0;
     int prof_launches = 0, prof_pending = 0;
+    // an open quiet solve (session_begin .. session_end)
+    struct Session {
+        bool active = false, compact = false;
+        const float *pg = nullptr, *pn = nullptr;
+        float *pnp = nullptr, *psi = nullptr;
+        const float *it_pnp = nullptr, *it_pg = nullptr, *it_pn = nullptr;  // what the kernels iterate on
+        float *it_psi = nullptr, *it_out = nullptr, *upd = nullptr;
+        int cap = 0;       // iterations this session may run (slot rows cleared by begin)
+        int launched = 0;  // iterations enqueued so far
+        int checked = 0, fl_to = 0;  // convergence poll: rows examined / rows of the copy in flight
+        bool in_flight = false;
+        int done = 0;  // iterations known to have executed
+        bool converged = false;
+        float last_norm = 0.f;
+    } q;
 
     void log(const std::string& line) const {
         if (log_set) {
@@ -131,14 +141,6 @@ int ensure_compact(sobfu_hip_solver* s) {
     return 0;
 }
 
-int ensure_fused(sobfu_hip_solver* s) {
-    if (s->c_psi2) return 0;
-    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_psi2, s->N * 12));
-    SOBFU_HIP_TRY(hipMalloc((void**) &s->c_f2, s->N * 4));
-    s->bytes += s->N * 16;
-    return 0;
-}
-
 int ensure_updates(sobfu_hip_solver* s) {
     if (s->updates) return 0;
     SOBFU_HIP_TRY(hipMalloc((void**) &s->updates, s->N * 16));
@@ -167,168 +169,205 @@ int ensure_events(sobfu_hip_solver* s, size_t n) {
     return 0;
 }
 
-// The gradient-descent loop.  Returns the number of iterations executed in rep->iterations.
-int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int max_iter,
-             sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
+// ---- the quiet (verbosity 0) loop in three pieces: begin / enqueue / end ------------------------------------------------
+// begin: enters the iteration format (compact: pack psi + tsdf channels + the warp of solver.cu:106; API format: the warp),
+//        clears the max-norm rows.  enqueue: launches pass A + pass B per iteration (asynchronous; the device-side gate makes
+//        every launch after the reference's `break` a no-op).  end: reads the rows, finds the iteration the reference stops at,
+//        rebuilds the caller's buffers.  sobfu_hip_solver_iterate / estimate_psi are begin + enqueue(max_iter) + end;
+//        the session entry points of the C ABI expose the pieces (a frame loop that interleaves other work, bench.py's
+//        timed region of exactly K iterations).
+int session_begin(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int cap, hipStream_t st) {
+    sobfu_hip_solver::Session& q = s->q;
+    if (q.active) return SOBFU_E_BADARG;
+    const int X = s->X, Y = s->Y, Z = s->Z;
+    q = sobfu_hip_solver::Session{};
+    q.pg = pg; q.pn = pn; q.pnp = pnp; q.psi = psi;
+    q.cap = cap;
+    q.compact = s->compact && cap > 0;
+    q.last_norm = NAN;
+    if (!q.compact) SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
+    q.active = true;
+    if (cap <= 0) return 0;
+    SOBFU_TRY(ensure_slots(s, cap));
+    SOBFU_HIP_TRY(hipMemsetAsync(s->slots, 0, (size_t) (cap + 1) * kSlots * 4, st));
+    if (s->keep_updates) {
+        SOBFU_TRY(ensure_updates(s));
+        q.upd = s->updates;
+    }
+    // compact mode: iterate on private 12-byte psi / nabla_U and tsdf-only TSDF copies; the API buffers are rebuilt by
+    // session_end (psi.xyz written back, phi_n o psi = apply(phi_n, psi) once) -- same values as iterating in place
+    q.it_pnp = pnp; q.it_pg = pg; q.it_pn = pn; q.it_psi = psi; q.it_out = pnp;
+    if (q.compact) {
+        SOBFU_TRY(ensure_compact(s));
+        SOBFU_TRY(sobfu_hip::launch_compact_enter(psi, pg, pn, s->c_psi, s->c_g, s->c_n, s->c_f, X, Y, Z, st));  // incl. solver.cu:106
+        q.it_pnp = s->c_f; q.it_pg = s->c_g; q.it_pn = s->c_n; q.it_psi = s->c_psi; q.it_out = s->c_f;
+    }
+    if (s->p.max_update_norm >= 0.f) SOBFU_TRY(ensure_poll(s, cap));
+    if (s->prof_stride > 0) SOBFU_TRY(ensure_events(s, (size_t) 3 * (cap / s->prof_stride + 1)));
+    return 0;
+}
+
+// examine the rows [q.checked, upto) that sit in the pinned mirror
+void session_examine(sobfu_hip_solver* s, int upto, float* per_iter) {
+    sobfu_hip_solver::Session& q = s->q;
+    for (int k = q.checked; k < upto && !q.converged; ++k) {
+        const float v = slots_to_norm(s->h_rows + (size_t) k * kSlots);
+        if (per_iter) per_iter[k] = v;
+        q.last_norm = v;
+        q.done = k + 1;
+        if (v <= s->p.max_update_norm) q.converged = true;  // solver.cu:183 -- later launches were device-side no-ops
+    }
+    q.checked = upto;
+}
+
+int session_enqueue(sobfu_hip_solver* s, int n, bool poll, float* per_iter, hipStream_t st) {
+    sobfu_hip_solver::Session& q = s->q;
+    if (!q.active || n < 0 || q.launched + n > q.cap) return SOBFU_E_BADARG;
+    const int X = s->X, Y = s->Y, Z = s->Z;
+    const sobfu_hip_solver_params& p = s->p;
+    const bool can_converge = p.max_update_norm >= 0.f;  // ||u|| >= 0 > negative threshold: never fires
+    const int last = q.launched + n;
+    for (int it = q.launched + 1; it <= last && !q.converged; ++it) {
+        const uint32_t* prev = (it > 1) ? s->slots + (size_t) (it - 1) * kSlots : nullptr;
+        uint32_t* cur        = s->slots + (size_t) it * kSlots;
+        // timing events (sobfu_hip_solver_set_profiling): an event between two kernels costs a few us of drained pipeline, so
+        // a profiled run is not the run whose wall time is quoted
+        const bool ev = s->prof_stride > 0 && (it % s->prof_stride == 0) && (size_t) 3 * (s->prof_pending + 1) <= s->events.size();
+        const int e0  = 3 * s->prof_pending;
+        if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0], st));
+        SOBFU_TRY(sobfu_hip::launch_pass_a(q.it_pnp, q.it_pg, q.it_psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st, q.compact));
+        if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 1], st));
+        SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, q.it_psi, q.it_pn, q.it_out, q.upd, cur, s->taps, p.alpha, X, Y, Z, prev,
+                                           p.max_update_norm, 0, st, 0, 0, 0, q.compact));
+        if (ev) {
+            SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 2], st));
+            s->prof_pending += 1;
+        }
+        q.launched = it;
+        if (can_converge && poll) {
+            // the host looks at the max-norm rows WITHOUT draining the stream: every kCheckEvery iterations the finished
+            // rows are copied to pinned memory behind the kernels, and the copy's event is polled; the host may run
+            // at most kMaxRunAhead iterations past the last row it has seen (launches after the break are no-ops,
+            // but each still costs a few us)
+            if (!q.in_flight && (it % kCheckEvery == 0 || it == last)) {
+                SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) q.checked * kSlots, s->slots + (size_t) (q.checked + 1) * kSlots,
+                                             (size_t) (it - q.checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
+                SOBFU_HIP_TRY(hipEventRecord(s->ev_chk, st));
+                q.in_flight = true;
+                q.fl_to     = it;
+            }
+            if (q.in_flight) {
+                const bool must_wait = it - q.checked >= kMaxRunAhead;
+                hipError_t e = must_wait ? hipEventSynchronize(s->ev_chk) : hipEventQuery(s->ev_chk);
+                if (e == hipSuccess) {
+                    session_examine(s, q.fl_to, per_iter);
+                    q.in_flight = false;
+                } else if (e != hipErrorNotReady) {
+                    return (int) e;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int session_end(sobfu_hip_solver* s, sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
+    sobfu_hip_solver::Session& q = s->q;
+    if (!q.active) return SOBFU_E_BADARG;
+    const sobfu_hip_solver_params& p = s->p;
+    sobfu_hip_solver_report r{};
+    r.last_max_update_norm = NAN;
+    r.last_max_update_index = NAN;
+    r.last_e_data = r.last_e_reg = NAN;
+    const bool can_converge = p.max_update_norm >= 0.f;
+    if (q.launched > 0) {
+        if (can_converge) {
+            if (q.in_flight) {
+                SOBFU_HIP_TRY(hipEventSynchronize(s->ev_chk));
+                session_examine(s, q.fl_to, per_iter);
+                q.in_flight = false;
+            }
+            if (!q.converged && q.checked < q.launched) {  // rows launched after the last copy was issued
+                SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) q.checked * kSlots, s->slots + (size_t) (q.checked + 1) * kSlots,
+                                             (size_t) (q.launched - q.checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
+                SOBFU_HIP_TRY(hipStreamSynchronize(st));
+                session_examine(s, q.launched, per_iter);
+            }
+        } else {
+            std::vector<uint32_t> hs((size_t) q.launched * kSlots);
+            SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + kSlots, hs.size() * 4, hipMemcpyDeviceToHost, st));
+            SOBFU_HIP_TRY(hipStreamSynchronize(st));
+            for (int k = 0; k < q.launched; ++k) {
+                const float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
+                if (per_iter) per_iter[k] = v;
+                q.last_norm = v;
+            }
+            q.done = q.launched;
+        }
+    }
+    // `done` iterations actually executed (later launches were no-ops): psi.xyz back + phi_n o psi = apply(phi_n, psi), the
+    // state solver.cu:168 leaves behind, in one pass
+    if (q.compact) SOBFU_TRY(sobfu_hip::launch_compact_leave(s->c_psi, q.pn, q.psi, q.pnp, s->X, s->Y, s->Z, st));
+    // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
+    for (int it = 1; it <= q.done; ++it)
+        if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
+    if (q.converged) s->log("SOLVER CONVERGED AFTER " + std::to_string(q.done) + " ITERATIONS");
+    else if (q.cap > 0 && q.done == q.cap) s->log("SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING");
+    r.iterations = q.done;
+    r.converged  = q.converged ? 1 : 0;
+    r.last_max_update_norm = q.last_norm;
+    q.active = false;
+    SOBFU_HIP_TRY(hipStreamSynchronize(st));
+    if (rep) *rep = r;
+    return 0;
+}
+
+// verbose (verbosity > 0): same kernels on the API-format arrays, plus the reference's energy / arg-max reductions and a host
+// sync per iteration (solver.cu:114-193 as written)
+int run_verbose(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int max_iter,
+                sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
     const int X = s->X, Y = s->Y, Z = s->Z;
     const sobfu_hip_solver_params& p = s->p;
     sobfu_hip_solver_report r{};
     r.last_max_update_norm = NAN;
     r.last_max_update_index = NAN;
     r.last_e_data = r.last_e_reg = NAN;
-
-    const bool compact = s->compact && p.verbosity == 0 && max_iter > 0;
-    if (!compact) SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
-    if (max_iter <= 0) {
-        SOBFU_HIP_TRY(hipStreamSynchronize(st));
-        if (rep) *rep = r;
-        return 0;
-    }
+    SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
     SOBFU_TRY(ensure_slots(s, max_iter));
     SOBFU_HIP_TRY(hipMemsetAsync(s->slots, 0, (size_t) (max_iter + 1) * kSlots * 4, st));
-    const bool verbose = p.verbosity > 0;
-    float* upd = nullptr;
-    if (verbose || s->keep_updates) {
-        SOBFU_TRY(ensure_updates(s));
-        upd = s->updates;
-    }
-    const bool can_converge = p.max_update_norm >= 0.f;  // ||u|| >= 0 > negative threshold: never fires
-    std::vector<uint32_t> hs;
-    int done = 0;  // iterations known to have executed
+    SOBFU_TRY(ensure_updates(s));
+    float* upd = s->updates;
+    int done = 0;
     bool converged = false;
-
-    // compact mode: iterate on private 12-byte psi / nabla_U and tsdf-only TSDF copies; the API buffers are rebuilt after
-    // the loop (psi.xyz written back, phi_n o psi = apply(phi_n, psi) once) -- same values as iterating in place
-    const float *it_pnp = pnp, *it_pg = pg, *it_pn = pn;
-    float *it_psi = psi, *it_out = pnp;
-    if (compact) {
-        SOBFU_TRY(ensure_compact(s));
-        SOBFU_TRY(sobfu_hip::launch_compact_enter(psi, pg, pn, s->c_psi, s->c_g, s->c_n, s->c_f, X, Y, Z, st));  // incl. solver.cu:106
-        it_pnp = s->c_f; it_pg = s->c_g; it_pn = s->c_n; it_psi = s->c_psi; it_out = s->c_f;
-    }
-    const bool fused = compact && s->fused && upd == nullptr;
-    if (fused) SOBFU_TRY(ensure_fused(s));
-    float* pp_psi[2] = {s->c_psi, s->c_psi2};
-    float* pp_f[2]   = {s->c_f, s->c_f2};
-    const bool prof = s->profiling && !verbose;
-    if (prof) SOBFU_TRY(ensure_events(s, (size_t) 3 * max_iter));
-    int launched = 0;
-    if (!verbose) {
-        int checked = 0, fl_to = 0;
-        bool in_flight = false;
-        if (can_converge) SOBFU_TRY(ensure_poll(s, max_iter));
-        for (int it = 1; it <= max_iter && !converged; ++it) {
-            const uint32_t* prev = (it > 1) ? s->slots + (size_t) (it - 1) * kSlots : nullptr;
-            uint32_t* cur        = s->slots + (size_t) it * kSlots;
-            // timing events are SAMPLED (every kProfEvery-th iteration): an event between two kernels costs several us of
-            // pipeline drain, and recording around every launch slowed the loop by ~8 % at 256^3
-            const bool ev = prof && (it % kProfEvery == 0);
-            const int e0  = 3 * (it / kProfEvery - 1);
-            if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0], st));
-            if (fused) {  // iteration `it` reads buffer (it-1)&1 and writes buffer it&1
-                if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 1], st));
-                SOBFU_TRY(sobfu_hip::launch_fused_iteration(pp_psi[(it - 1) & 1], pp_f[(it - 1) & 1], s->c_g, s->c_n, pp_psi[it & 1], pp_f[it & 1], cur,
-                                                            s->taps, p.alpha, p.w_reg, X, Y, Z, prev, p.max_update_norm, st));
-            } else {
-            SOBFU_TRY(sobfu_hip::launch_pass_a(it_pnp, it_pg, it_psi, s->nabla_U, p.w_reg, X, Y, Z, prev, p.max_update_norm, 0, st, compact));
-            if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 1], st));
-            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, it_psi, it_pn, it_out, upd, cur, s->taps, p.alpha, X, Y, Z, prev,
-                                               p.max_update_norm, 0, st, 0, 0, 0, compact));
-            }
-            if (ev) SOBFU_HIP_TRY(hipEventRecord(s->events[e0 + 2], st));
-            launched = it;
-            if (can_converge) {
-                // the host looks at the max-norm rows WITHOUT draining the stream: every kCheckEvery iterations the finished
-                // rows are copied to pinned memory behind the kernels, and the copy's event is polled; the host may run
-                // at most kMaxRunAhead iterations past the last row it has seen (launches after the break are no-ops,
-                // but each still costs a few us)
-                auto examine = [&](int upto) {
-                    for (int k = checked; k < upto && !converged; ++k) {
-                        float v = slots_to_norm(s->h_rows + (size_t) k * kSlots);
-                        if (per_iter) per_iter[k] = v;
-                        r.last_max_update_norm = v;
-                        done = k + 1;
-                        if (v <= p.max_update_norm) converged = true;  // solver.cu:183 -- later launches were device-side no-ops
-                    }
-                    checked = upto;
-                };
-                if (!in_flight && (it % kCheckEvery == 0 || it == max_iter)) {
-                    SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) checked * kSlots, s->slots + (size_t) (checked + 1) * kSlots,
-                                                 (size_t) (it - checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
-                    SOBFU_HIP_TRY(hipEventRecord(s->ev_chk, st));
-                    in_flight = true;
-                    fl_to     = it;
-                }
-                if (in_flight) {
-                    const bool must_wait = it == max_iter || it - checked >= kMaxRunAhead;
-                    hipError_t q = must_wait ? hipEventSynchronize(s->ev_chk) : hipEventQuery(s->ev_chk);
-                    if (q == hipSuccess) {
-                        examine(fl_to);
-                        in_flight = false;
-                        if (!converged && it == max_iter && checked < it) {  // rows launched after the copy was issued
-                            SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) checked * kSlots, s->slots + (size_t) (checked + 1) * kSlots,
-                                                         (size_t) (it - checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
-                            SOBFU_HIP_TRY(hipStreamSynchronize(st));
-                            examine(it);
-                        }
-                    } else if (q != hipErrorNotReady) {
-                        return (int) q;
-                    }
-                }
-            }
+    for (int it = 1; it <= max_iter; ++it) {
+        if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
+        const bool report = (p.verbosity == 1 && (it == 1 || it % 50 == 0 || it == max_iter)) || p.verbosity == 2;
+        if (report) {  // solver.cu:132-142 (J of the displacement is rebuilt in registers, not stored)
+            SOBFU_TRY(sobfu_hip_data_energy(pg, pnp, (int) s->N, s->red_scratch, &r.last_e_data, st));
+            SOBFU_TRY(sobfu_hip_reg_energy_sobolev_from_psi(psi, X, Y, Z, s->red_scratch, &r.last_e_reg, st));
+            float e = r.last_e_data + p.w_reg * r.last_e_reg;
+            s->log("data energy + w_reg * reg energy = " + fmt_g(r.last_e_data) + " + " + fmt_g(p.w_reg) + " * " +
+                   fmt_g(r.last_e_reg) + " = " + fmt_g(e));
         }
-        if (!can_converge) {
-            hs.resize((size_t) max_iter * kSlots);
-            SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + kSlots, hs.size() * 4, hipMemcpyDeviceToHost, st));
-            SOBFU_HIP_TRY(hipStreamSynchronize(st));
-            for (int k = 0; k < max_iter; ++k) {
-                float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
-                if (per_iter) per_iter[k] = v;
-                r.last_max_update_norm = v;
-            }
-            done = max_iter;
+        uint32_t* cur = s->slots + (size_t) it * kSlots;
+        SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st, false));
+        SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st, 0, 0, 0, false));
+        float mx[2];
+        SOBFU_TRY(sobfu_hip_max_update_norm(upd, (int) s->N, s->red_scratch, mx, st));  // solver.cu:172
+        r.last_max_update_norm  = mx[0];
+        r.last_max_update_index = mx[1];
+        if (per_iter) per_iter[it - 1] = mx[0];
+        done = it;
+        if (report) {  // solver.cu:175-180 (index arithmetic reproduced as written)
+            int ix = (int) (mx[1] / (float) (X * Y));
+            int iy = (int) ((mx[1] - (float) (ix * X * Y)) / (float) X);
+            int iz = (int) (mx[1] - (float) (X * (iy + Y * ix)));
+            s->log("max. update norm " + fmt_g(mx[0]) + " at voxel (" + std::to_string(iz) + ", " + std::to_string(iy) +
+                   ", " + std::to_string(ix) + ")");
         }
-        if (compact) {
-            // `done` iterations actually executed (later launches were no-ops): the state is in ping-pong buffer done&1
-            // psi.xyz back + phi_n o psi = apply(phi_n, psi), the state solver.cu:168 leaves behind, in one pass
-            SOBFU_TRY(sobfu_hip::launch_compact_leave(fused ? pp_psi[done & 1] : s->c_psi, pn, psi, pnp, X, Y, Z, st));
-        }
-        if (prof) s->prof_pending = (done < launched ? done : launched) / kProfEvery;  // sampled iterations; read in get_profile()
-        // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
-        for (int it = 1; it <= done; ++it)
-            if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
-    } else {
-        // verbose: same kernels, plus the reference's energy / arg-max reductions and a host sync per iteration
-        for (int it = 1; it <= max_iter; ++it) {
-            if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
-            const bool report = (p.verbosity == 1 && (it == 1 || it % 50 == 0 || it == max_iter)) || p.verbosity == 2;
-            if (report) {  // solver.cu:132-142 (J of the displacement is rebuilt in registers, not stored)
-                SOBFU_TRY(sobfu_hip_data_energy(pg, pnp, (int) s->N, s->red_scratch, &r.last_e_data, st));
-                SOBFU_TRY(sobfu_hip_reg_energy_sobolev_from_psi(psi, X, Y, Z, s->red_scratch, &r.last_e_reg, st));
-                float e = r.last_e_data + p.w_reg * r.last_e_reg;
-                s->log("data energy + w_reg * reg energy = " + fmt_g(r.last_e_data) + " + " + fmt_g(p.w_reg) + " * " +
-                       fmt_g(r.last_e_reg) + " = " + fmt_g(e));
-            }
-            uint32_t* cur = s->slots + (size_t) it * kSlots;
-            SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st, false));
-            SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st, 0, 0, 0, false));
-            float mx[2];
-            SOBFU_TRY(sobfu_hip_max_update_norm(upd, (int) s->N, s->red_scratch, mx, st));  // solver.cu:172
-            r.last_max_update_norm  = mx[0];
-            r.last_max_update_index = mx[1];
-            if (per_iter) per_iter[it - 1] = mx[0];
-            done = it;
-            if (report) {  // solver.cu:175-180 (index arithmetic reproduced as written)
-                int ix = (int) (mx[1] / (float) (X * Y));
-                int iy = (int) ((mx[1] - (float) (ix * X * Y)) / (float) X);
-                int iz = (int) (mx[1] - (float) (X * (iy + Y * ix)));
-                s->log("max. update norm " + fmt_g(mx[0]) + " at voxel (" + std::to_string(iz) + ", " + std::to_string(iy) +
-                       ", " + std::to_string(ix) + ")");
-            }
-            if (mx[0] <= p.max_update_norm) {
-                converged = true;
-                break;
-            }
+        if (mx[0] <= p.max_update_norm) {
+            converged = true;
+            break;
         }
     }
     if (converged) s->log("SOLVER CONVERGED AFTER " + std::to_string(done) + " ITERATIONS");
@@ -337,6 +376,20 @@ int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, 
     r.converged  = converged ? 1 : 0;
     if (rep) *rep = r;
     return 0;
+}
+
+// The gradient-descent loop.  Returns the number of iterations executed in rep->iterations.
+int run_loop(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int max_iter,
+             sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
+    if (s->q.active) return SOBFU_E_BADARG;  // a session is open on this handle
+    if (s->p.verbosity > 0 && max_iter > 0) return run_verbose(s, pg, pn, pnp, psi, max_iter, rep, per_iter, st);
+    SOBFU_TRY(session_begin(s, pg, pn, pnp, psi, max_iter, st));
+    int rc = session_enqueue(s, max_iter, true, per_iter, st);
+    if (rc != 0) {
+        s->q.active = false;
+        return rc;
+    }
+    return session_end(s, rep, per_iter, st);
 }
 
 }  // namespace
@@ -392,7 +445,6 @@ int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const s
     s->X = X; s->Y = Y; s->Z = Z;
     s->N = (size_t) X * Y * Z;
     if (const char* e = getenv("SOBFU_COMPACT")) s->compact = atoi(e) != 0;  // tuning override
-    if (const char* e = getenv("SOBFU_FUSED")) s->fused = atoi(e) != 0;
     int rc = set_params(s, params);
     if (rc == 0) rc = (int) hipMalloc((void**) &s->nabla_U, s->N * 16);
     if (rc == 0) rc = (int) hipMalloc(&s->red_scratch, 65536 * 8);
@@ -419,7 +471,7 @@ int sobfu_hip_solver_destroy(sobfu_hip_solver* s) {
     if (s->red_scratch) (void) hipFree(s->red_scratch);
     if (s->h_rows) (void) hipHostFree(s->h_rows);
     if (s->ev_chk) (void) hipEventDestroy(s->ev_chk);
-    for (float* q : {s->c_psi, s->c_f, s->c_g, s->c_n, s->c_psi2, s->c_f2})
+    for (float* q : {s->c_psi, s->c_f, s->c_g, s->c_n})
         if (q) (void) hipFree(q);
     for (hipEvent_t e : s->events) (void) hipEventDestroy(e);
     delete s;
@@ -459,22 +511,17 @@ int sobfu_hip_solver_set_compact(sobfu_hip_solver* s, int enable) {
     return 0;
 }
 
-int sobfu_hip_solver_set_fused(sobfu_hip_solver* s, int enable) {
-    SOBFU_CHECK_ARGS(s);
-    s->fused = enable != 0;
-    return 0;
-}
-
-int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int enable) {
-    SOBFU_CHECK_ARGS(s);
-    s->profiling = enable != 0;
-    if (s->profiling) SOBFU_TRY(ensure_events(s, (size_t) 3 * (s->p.max_iter > 0 ? s->p.max_iter : 1)));  // not inside a timed solve
+int sobfu_hip_solver_set_profiling(sobfu_hip_solver* s, int stride) {
+    SOBFU_CHECK_ARGS(s && stride >= 0);
+    s->prof_stride = stride;
+    const int cap = s->q.active ? s->q.cap : (s->p.max_iter > 0 ? s->p.max_iter : 1);
+    if (stride > 0) SOBFU_TRY(ensure_events(s, (size_t) 3 * (cap / stride + 1)));  // not inside a timed solve
     return 0;
 }
 
 int sobfu_hip_solver_get_profile(sobfu_hip_solver* s, float* ms_pass_a, float* ms_pass_b, int* launches, int reset) {
     SOBFU_CHECK_ARGS(s);
-    for (int it = 1; it <= s->prof_pending; ++it) {  // events of the last profiled solve (already synchronised)
+    for (int it = 1; it <= s->prof_pending; ++it) {  // events recorded since the last call (the caller has synchronised)
         float a = 0, b = 0;
         SOBFU_HIP_TRY(hipEventElapsedTime(&a, s->events[3 * (it - 1)], s->events[3 * (it - 1) + 1]));
         SOBFU_HIP_TRY(hipEventElapsedTime(&b, s->events[3 * (it - 1) + 1], s->events[3 * (it - 1) + 2]));
@@ -499,6 +546,23 @@ int sobfu_hip_solver_iterate(sobfu_hip_solver* s, const float* d_phi_global, con
     SOBFU_CHECK_ARGS(s && d_phi_global && d_phi_n && d_phi_n_psi && d_psi && n_iters >= 0);
     SOBFU_TRY(run_loop(s, d_phi_global, d_phi_n, d_phi_n_psi, d_psi, n_iters, report, per_iter_max_norm, (hipStream_t) stream));
     return (int) hipStreamSynchronize((hipStream_t) stream);
+}
+
+int sobfu_hip_solver_begin(sobfu_hip_solver* s, const float* d_phi_global, const float* d_phi_n, float* d_phi_n_psi, float* d_psi,
+                           int max_iters, void* stream) {
+    SOBFU_CHECK_ARGS(s && d_phi_global && d_phi_n && d_phi_n_psi && d_psi && max_iters >= 0);
+    if (s->p.verbosity > 0) return SOBFU_E_UNSUPPORTED;  // the verbose loop synchronises every iteration: use estimate_psi / iterate
+    return session_begin(s, d_phi_global, d_phi_n, d_phi_n_psi, d_psi, max_iters, (hipStream_t) stream);
+}
+
+int sobfu_hip_solver_step(sobfu_hip_solver* s, int n_iters, void* stream) {
+    SOBFU_CHECK_ARGS(s && n_iters >= 0);
+    return session_enqueue(s, n_iters, false, nullptr, (hipStream_t) stream);
+}
+
+int sobfu_hip_solver_end(sobfu_hip_solver* s, sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream) {
+    SOBFU_CHECK_ARGS(s);
+    return session_end(s, report, per_iter_max_norm, (hipStream_t) stream);
 }
 
 int sobfu_hip_solver_estimate_psi(sobfu_hip_solver* s, const float* d_phi_global, float* d_phi_global_psi_inv,

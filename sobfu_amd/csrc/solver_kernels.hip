@@ -628,252 +628,6 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
     }
 }
 
-// ============================================================================================================
-// Part 3: single-kernel iteration (compact format only)
-// ============================================================================================================
-// One launch = one solver iteration: nabla_U is never written to memory.  A workgroup owns a 64x8 tile, marches along z
-// and, per plane, (re)computes nabla_U on the tile PLUS a 3-cell halo from psi / F = (phi_n o psi).tsdf staged with a
-// 4-cell halo in LDS (pass A's arithmetic), then smooths / updates / warps the tile exactly like pass B.  Halo cells of
-// nabla_U are recomputed by the workgroup that needs them (1.9x pass A's cheap math) instead of being round-tripped
-// through HBM: per voxel-iteration the kernel reads psi 12 + F 4 + G 4 (+ halo) + phi_n gather 4 and writes psi 12 + F 4
-// = 40 B instead of 76 B (two-pass compact) or 112 B (API format).  psi and F are ping-ponged (a tile's halo must see
-// the previous iteration's values while neighbours already write the next).  Same arithmetic, same order: bit-identical.
-//
-// Cell bookkeeping (E3 = tile +-3 = 70x14 cells; both LDS tiles cover E3):
-//   lane t owns its tile cell ("main") and, for t < 468, one cell of E3 \ tile ("extra").  Per owned cell, for the
-//   nabla_U plane p = z + 3 produced at step z: psi/F of planes p and p+1 in registers, plane p-1 from the previous
-//   step's LDS buffer, in-plane neighbours from this step's buffer (an E3-perimeter cell fetches its one neighbour outside
-//   E3 itself).  Main cells feed the 7-plane nabla_U register pipeline, extra cells a 4-plane delay line so that their
-//   value for plane z reaches the LDS nabla_U tile at step z.
-struct FusedArgs {
-    const void* psi_in;   // P3
-    const float* f_in;    // (phi_n o psi).tsdf
-    const float* g;       // phi_global.tsdf
-    const float* phi_n;   // phi_n.tsdf (whole volume)
-    void* psi_out;        // P3
-    float* f_out;
-    uint32_t* slots;
-    Dims d;
-    Taps S;
-    float alpha, w_reg;
-    int zc;
-    const uint32_t* prev_slots;
-    float max_update_norm;
-};
-
-constexpr int FY = 8, FE3X = TX + 6, FE3Y = FY + 6;
-constexpr int FEXTRA = FE3X * FE3Y - TX * FY;  // 468
-
-// pass A's arithmetic for one cell (vector_fields.cu:157-208, 291-337; solver.cu:28-31).  c = {psi.xyz, F} of the cell;
-// xp/xm/yp/ym in-plane neighbours, zp/zm the cell's own window.
-SOBFU_DEV float4 nabla_u_cell(const float4& c, float4 xp, float4 xm, float4 yp, float4 ym, float4 zp, float4 zm, float g, float w_reg,
-                              bool xlo, bool xhi, bool ylo, bool yhi, bool zlo, bool zhi) {
-    float gx1 = xhi ? xm.w : xp.w, gx2 = xlo ? xp.w : xm.w;
-    float gy1 = yhi ? ym.w : yp.w, gy2 = ylo ? yp.w : ym.w;
-    float gz1 = zhi ? zm.w : zp.w, gz2 = zlo ? zp.w : zm.w;
-    float4 gr = f4((gx1 - gx2) / 2.f, (gy1 - gy2) / 2.f, (gz1 - gz2) / 2.f);
-    if (xlo || xhi) { xp = c; xm = c; }
-    if (ylo || yhi) { yp = c; ym = c; }
-    if (zlo || zhi) { zp = c; zm = c; }
-    float4 v = mul4(c, -6.f);
-    v = add4(v, xp);
-    v = add4(v, xm);
-    v = add4(v, yp);
-    v = add4(v, ym);
-    v = add4(v, zp);
-    v = add4(v, zm);
-    float4 L = mul4(v, -1.f);
-    return add4(mul4(gr, c.w - g), mul4(L, w_reg));
-}
-
-#ifndef SOBFU_MINW_F
-#define SOBFU_MINW_F 4
-#endif
-__global__ void __launch_bounds__(TX* FY, SOBFU_MINW_F) fused_iteration_kernel(FusedArgs a) {
-    // psi/F tile: E3 cells only -- the one neighbour an E3-perimeter cell needs outside E3 is fetched by that cell itself
-    // (register `on`); the plane below (p-1) of every cell is still in the other half of the double buffer.
-    // THREE psi/F buffers: a step reads plane p (this step's buffer) AND plane p-1 (the previous step's), so the next
-    // step must write a third one (one __syncthreads per step)
-    __shared__ float4 t_pf[3][FE3Y][FE3X];  // {psi.xyz, F} of planes z+2 / z+3 on E3, addressed by CLAMPED cell position
-    __shared__ float4 t_nu[2][FE3Y][FE3X];  // nabla_U of plane z on E3, addressed by RAW cell position
-    __shared__ uint32_t s_max[FY];
-
-    if (solver_converged(a.prev_slots, a.max_update_norm)) return;
-
-    const Dims d = a.d;
-    const int lx = threadIdx.x, wy = threadIdx.y, tid = wy * TX + lx;
-#ifndef SOBFU_NT_F
-#define SOBFU_NT_F 1  // streaming stores of psi_out / f_out (the next iteration reads them; this one never does)
-#endif
-#ifndef SOBFU_SWIZZLE_F
-#define SOBFU_SWIZZLE_F true  // XCD-aware tile map: halo re-reads hit the XCD's L2 (279 -> 271 us at 256^3)
-#endif
-    const TileId tid3 = tile_of_block<SOBFU_SWIZZLE_F>((d.x + TX - 1) / TX, (d.y + FY - 1) / FY, (d.z + a.zc - 1) / a.zc);
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * FY, zb = tid3.tz * a.zc, ze = min(zb + a.zc, d.z);
-    const uint32_t plane = (uint32_t) d.x * d.y;  // voxel indices fit 31 bits
-    auto clampx = [&](int v) { return min(max(v, 0), d.x - 1); };
-    auto clampy = [&](int v) { return min(max(v, 0), d.y - 1); };
-    auto clampz = [&](int v) { return (uint32_t) min(max(v, 0), d.z - 1); };
-
-    // ---- main cell ------------------------------------------------------------------------------------------------
-    const int x = x0 + lx, y = y0 + wy;
-    const int mgx = clampx(x), mgy = clampy(y);
-    const uint32_t m_off = (uint32_t) mgx + (uint32_t) d.x * mgy;
-    const int mcx = mgx - (x0 - 3), mcy = mgy - (y0 - 3);  // E3 index of the (clamped) main cell
-    const bool m_in = x < d.x && y < d.y;
-    // ---- extra cell (E3 \ tile) -------------------------------------------------------------------------------------
-    const bool has_e = tid < FEXTRA;
-    int ex = 0, ey = 0;  // raw E3 coordinates
-    if (tid < 210) { ey = tid / FE3X; ex = tid % FE3X; }
-    else if (tid < 420) { ey = 11 + (tid - 210) / FE3X; ex = (tid - 210) % FE3X; }
-    else { const int e = tid - 420, c6 = e % 6; ey = 3 + e / 6; ex = c6 < 3 ? c6 : TX + c6; }
-    const int egx = clampx(x0 - 3 + ex), egy = clampy(y0 - 3 + ey);
-    const uint32_t e_off = (uint32_t) egx + (uint32_t) d.x * egy;
-    const int ecx = egx - (x0 - 3), ecy = egy - (y0 - 3);
-    // the neighbour of a perimeter cell that lies outside E3 (corner cells of E3 are never read by the plus-shaped
-    // convolution, so one outward neighbour is enough).  o_dir: 0 none, 1 x-1, 2 x+1, 3 y-1, 4 y+1.
-    int o_dir = 0;
-    if (has_e) {
-        if (ex == 0) o_dir = 1; else if (ex == FE3X - 1) o_dir = 2; else if (ey == 0) o_dir = 3; else if (ey == FE3Y - 1) o_dir = 4;
-    }
-    const uint32_t o_off = (uint32_t) clampx(egx + (o_dir == 1 ? -1 : o_dir == 2 ? 1 : 0)) +
-                           (uint32_t) d.x * clampy(egy + (o_dir == 3 ? -1 : o_dir == 4 ? 1 : 0));
-
-    auto ld_pf = [&](uint32_t off, int zz) -> float4 {  // {psi.xyz, F} of voxel `off` in (clamped) plane zz
-        const uint32_t i = clampz(zz) * plane + off;
-        float4 v = ldv<true>(a.psi_in, i);
-        v.w = a.f_in[i];
-        return v;
-    };
-
-    // producer state for the nabla_U plane p = z + 3 produced at step z: plane p (c) and p+1 (n) of the owned cells
-    const int z_start = max(zb - 6, -3);
-    float4 mc_, mn_, ec_, en_, on_ = f4(0.f, 0.f, 0.f);
-    {
-        const int p = z_start + 3;
-        mc_ = ld_pf(m_off, p);
-        mn_ = ld_pf(m_off, p + 1);
-        if (has_e) { ec_ = ld_pf(e_off, p); en_ = ld_pf(e_off, p + 1); }
-        if (o_dir) on_ = ld_pf(o_off, p);
-        // plane p-1 is read from the previous step's buffer: pre-stage it for the first step
-        t_pf[2][mcy][mcx] = ld_pf(m_off, p - 1);
-        if (has_e) t_pf[2][ecy][ecx] = ld_pf(e_off, p - 1);
-    }
-    float gm = a.g[clampz(z_start + 3) * plane + m_off], ge = has_e ? a.g[clampz(z_start + 3) * plane + e_off] : 0.f;
-    float4 q[7];   // nabla_U planes z-3 .. z+3 of the main cell
-    float4 dl[4];  // nabla_U planes z .. z+3 of the extra cell
-#pragma unroll
-    for (int k = 0; k < 7; ++k) q[k] = f4(0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dl[k] = f4(0.f, 0.f, 0.f);
-
-    const bool mxlo = mgx == 0, mxhi = mgx == d.x - 1, mylo = mgy == 0, myhi = mgy == d.y - 1;
-    const bool exlo = egx == 0, exhi = egx == d.x - 1, eylo = egy == 0, eyhi = egy == d.y - 1;
-
-    float msq = 0.f;
-    for (int z = z_start; z < ze; ++z) {
-        const int buf = (z - z_start) & 1, pb = (z - z_start) % 3, pbm = (pb + 2) % 3, p = z + 3;
-        // (1) stage plane p of psi/F and plane z of nabla_U
-        t_pf[pb][mcy][mcx] = mc_;
-        if (has_e) t_pf[pb][ecy][ecx] = ec_;
-        t_nu[buf][wy + 3][lx + 3] = q[3];
-        if (has_e) t_nu[buf][ey][ex] = dl[0];
-        // (2) requests for the next step / this step's update
-        const float4 nmn = ld_pf(m_off, p + 2);
-        float4 nen = f4(0.f, 0.f, 0.f), non = f4(0.f, 0.f, 0.f);
-        if (has_e) nen = ld_pf(e_off, p + 2);
-        if (o_dir) non = ld_pf(o_off, p + 1);
-        const float ngm = a.g[clampz(p + 1) * plane + m_off], nge = has_e ? a.g[clampz(p + 1) * plane + e_off] : 0.f;
-        float4 pin = f4(0.f, 0.f, 0.f);
-        if (z >= zb) pin = ldv<true>(a.psi_in, (uint32_t) z * plane + m_off);
-        __syncthreads();
-
-        // (3) produce nabla_U plane p
-        if (p >= 0 && p < d.z) {
-            const bool zlo = p == 0, zhi = p == d.z - 1;
-            q[6] = nabla_u_cell(mc_, t_pf[pb][mcy][mcx + 1], t_pf[pb][mcy][mcx - 1], t_pf[pb][mcy + 1][mcx], t_pf[pb][mcy - 1][mcx], mn_,
-                                t_pf[pbm][mcy][mcx], gm, a.w_reg, mxlo, mxhi, mylo, myhi, zlo, zhi);
-            if (has_e) {
-                // in-plane neighbours: from the tile, except the outward one of a perimeter cell (register on_).  Index
-                // clamps keep the (unused) look-ups of corner cells inside the array.
-                const float4 xp = o_dir == 2 ? on_ : t_pf[pb][ecy][min(ecx + 1, FE3X - 1)];
-                const float4 xm = o_dir == 1 ? on_ : t_pf[pb][ecy][max(ecx - 1, 0)];
-                const float4 yp = o_dir == 4 ? on_ : t_pf[pb][min(ecy + 1, FE3Y - 1)][ecx];
-                const float4 ym = o_dir == 3 ? on_ : t_pf[pb][max(ecy - 1, 0)][ecx];
-                dl[3] = nabla_u_cell(ec_, xp, xm, yp, ym, en_, t_pf[pbm][ecy][ecx], ge, a.w_reg, exlo, exhi, eylo, eyhi, zlo, zhi);
-            }
-            if (p == 0) {
-#pragma unroll
-                for (int k = 3; k < 6; ++k) q[k] = q[6];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) dl[k] = dl[3];
-            }
-        } else if (p >= d.z) {
-            q[6]  = q[5];
-            dl[3] = dl[2];
-        }
-
-        // (4) consume: smooth, update, warp plane z of the tile (pass B's arithmetic)
-        if (z >= zb) {
-            float sxx = 0.f, sxy = 0.f, sxz = 0.f, syx = 0.f, syy = 0.f, syz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
-#pragma unroll
-            for (int j = -3; j <= 3; ++j) {
-                const float s = a.S.s[3 - j];
-                const float4 vx = (j == 0) ? q[3] : t_nu[buf][wy + 3][lx + 3 + j];
-                sxx += vx.x * s;
-                sxy += vx.y * s;
-                sxz += vx.z * s;
-                const float4 vy = (j == 0) ? q[3] : t_nu[buf][wy + 3 + j][lx + 3];
-                syx += vy.x * s;
-                syy += vy.y * s;
-                syz += vy.z * s;
-                const float4 vz = q[3 + j];
-                szx += vz.x * s;
-                szy += vz.y * s;
-                szz += vz.z * s;
-            }
-            const float tx = (sxx + syx) + szx, ty = (sxy + syy) + szy, tz = (sxz + syz) + szz;
-            const float4 u = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
-            float4 pnew = pin;
-            pnew.x -= u.x;
-            pnew.y -= u.y;
-            pnew.z -= u.z;
-            if (m_in) {
-                msq = fmaxf(msq, norm_sq4(u));
-                const uint32_t i = (uint32_t) z * plane + (uint32_t) x + (uint32_t) d.x * y;
-                if (SOBFU_NT_F) {
-                    stv_nt<true>(a.psi_out, i, pnew);
-                    __builtin_nontemporal_store(interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z), a.f_out + i);
-                } else {
-                    stv<true>(a.psi_out, i, pnew);
-                    a.f_out[i] = interp_tsdf_only(a.phi_n, d, pnew.x, pnew.y, pnew.z);
-                }
-            }
-        }
-        // (5) advance the pipelines
-#pragma unroll
-        for (int k = 0; k < 6; ++k) q[k] = q[k + 1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dl[k] = dl[k + 1];
-        mc_ = mn_; mn_ = nmn;
-        ec_ = en_; en_ = nen;
-        on_ = non;
-        gm = ngm;
-        ge = nge;
-    }
-
-    uint32_t m = __float_as_uint(msq);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
-    if (lx == 0) s_max[wy] = m;
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int w = 1; w < FY; ++w) m = max(m, s_max[w]);
-        atomicMax(a.slots + (blockIdx.x & 255u), m);
-    }
-}
-
 // --- compact-format conversions (once per solve, not per iteration) ----------------------------------------------
 __global__ void __launch_bounds__(256) pack_vec_kernel(const float4* __restrict__ src, P3* __restrict__ dst, size_t N) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1005,17 +759,6 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
     else if (compact) SOBFU_LAUNCH_B(false, true);
     else SOBFU_LAUNCH_B(false, false);
 #undef SOBFU_LAUNCH_B
-    return (int) hipGetLastError();
-}
-
-int launch_fused_iteration(const float* psi_in3, const float* f_in, const float* g, const float* phi_n1, float* psi_out3, float* f_out,
-                           uint32_t* slots, const float taps[7], float alpha, float w_reg, int X, int Y, int Z, const uint32_t* prev_slots,
-                           float max_update_norm, hipStream_t stream) {
-    const int zc = pick_zc(X, Y, Z, FY, 256 * 2, 6, "SOBFU_ZC_F");  // 68 KB LDS, <= 128 VGPR: 2 workgroups per CU
-    FusedArgs a{psi_in3, f_in, g, phi_n1, psi_out3, f_out, slots, {X, Y, Z}, {}, alpha, w_reg, zc, prev_slots, max_update_norm};
-    for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
-    dim3 grid(((X + TX - 1) / TX) * ((Y + FY - 1) / FY) * ((Z + zc - 1) / zc));
-    hipLaunchKernelGGL(fused_iteration_kernel, grid, dim3(TX, FY), 0, stream, a);
     return (int) hipGetLastError();
 }
 

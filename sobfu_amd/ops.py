@@ -309,11 +309,9 @@ class Solver:
     def set_compact(self, enable=True):
         check(_lib.lib().sobfu_hip_solver_set_compact(self._h, C.c_int(1 if enable else 0)), "set_compact")
 
-    def set_fused(self, enable=True):
-        check(_lib.lib().sobfu_hip_solver_set_fused(self._h, C.c_int(1 if enable else 0)), "set_fused")
-
-    def set_profiling(self, enable=True):
-        check(_lib.lib().sobfu_hip_solver_set_profiling(self._h, C.c_int(1 if enable else 0)), "set_profiling")
+    def set_profiling(self, stride=1):
+        """HIP events around the two launches of every stride-th iteration (0 / False = off)"""
+        check(_lib.lib().sobfu_hip_solver_set_profiling(self._h, C.c_int(int(stride))), "set_profiling")
 
     def get_profile(self, reset=True):
         """(ms in pass A, ms in pass B, iterations timed) from HIP events on the solver's stream."""
@@ -344,6 +342,23 @@ class Solver:
         check(_lib.lib().sobfu_hip_solver_estimate_psi(self._h, _ptr(phi_global), _ptr(phi_global_psi_inv), _ptr(phi_n),
                                                        _ptr(phi_n_psi), _ptr(psi), _ptr(psi_inv), C.byref(rep), hist,
                                                        _stream()), "solver_estimate_psi")
+        return rep, np.array(hist[:rep.iterations], np.float32)
+
+    def begin(self, phi_global, phi_n, phi_n_psi, psi, max_iters):
+        """the loop in pieces (sobfu_hip_solver_begin / step / end): begin enters the iteration format, step(n) ENQUEUES n
+        iterations without synchronising, end() synchronises and returns what iterate() would"""
+        self._session = (phi_global, phi_n, phi_n_psi, psi, int(max_iters))  # keeps the buffers alive
+        check(_lib.lib().sobfu_hip_solver_begin(self._h, _ptr(phi_global), _ptr(phi_n), _ptr(phi_n_psi), _ptr(psi), C.c_int(int(max_iters)),
+                                                _stream()), "solver_begin")
+
+    def step(self, n_iters):
+        check(_lib.lib().sobfu_hip_solver_step(self._h, C.c_int(int(n_iters)), _stream()), "solver_step")
+
+    def end(self):
+        rep = SolverReport()
+        hist = (C.c_float * max(1, self._session[4] if getattr(self, "_session", None) else 1))()
+        check(_lib.lib().sobfu_hip_solver_end(self._h, C.byref(rep), hist, _stream()), "solver_end")
+        self._session = None
         return rep, np.array(hist[:rep.iterations], np.float32)
 
     def iterate(self, phi_global, phi_n, phi_n_psi, psi, n_iters):

@@ -20,18 +20,35 @@ def run_bench(*args, env=None):
 
 
 def test_single_gpu_line():
-    d = run_bench("--gpus", "1", "--steps", "24", "--warmup", "8", "--dim", "128")
+    d = run_bench("--gpus", "1", "--steps", "24", "--warmup", "8", "--dim", "128", "--repeats", "5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "repeats", "region_its", "per_solve"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 8 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "iterations/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    assert d["repeats"] == 5 and len(d["region_its"]) == 5 and min(d["region_its"]) <= d["value"] <= max(d["region_its"]) + 0.1
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == 128 ** 3 * 64
+    assert r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == 128 ** 3 * 64 and r["launches_timed"] == 2 * 24
+    assert r["traffic"] is None and 0 < r["frac_physical"] < 1 and 0 < r["pass_a"]["frac_physical"] < 1
+    assert r["physical_bytes_per_launch"] == 128 ** 3 * 44
+    assert d["per_solve"]["iterations"] == 50 and d["per_solve"]["ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s" and c["sample"]
+    assert c["one_core"]["cores"] == 1 and c["one_core"]["value"] > 0
+    assert c["config1_64"]["all_cores"]["value"] > 0 and c["config1_64"]["one_core"]["value"] > 0
+
+
+def test_gpus_n_self_launches_replicas():
+    """plain `python bench.py --gpus 2` (no torchrun): bench.py re-executes itself under torch.distributed.run.  On this 1-GPU box
+    both ranks share cuda:0 (gloo process group); --replicas = BASELINE config 5's batched independent sequences."""
+    env = {"SOBFU_BENCH_SHARE_GPU": "1"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        assert k not in os.environ
+    d = run_bench("--gpus", "2", "--replicas", "--steps", "10", "--warmup", "4", "--dim", "64", "--repeats", "3", "--no-cpu-baseline", env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["repeats"] == 3 and "replicas" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
 
 
 def test_slab_path_line_on_one_gpu():

@@ -378,10 +378,10 @@ def test_solver_randomised_configurations(ops, oracle, seed):
         psi = psi0.copy()
         r = oracle.estimate_psi(pg, pn, psi, max_iter=iters, alpha=alpha, w_reg=w_reg, s=s, lam=lam, max_update_norm=thr, verbosity=2,
                                 inverse_iters=48)
-    for mode in ("quiet", "verbose", "fused"):
+    for mode in ("quiet", "verbose", "api-format"):
         sv = ops.Solver(dims, max_iter=iters, alpha=alpha, w_reg=w_reg, s=s, lam=lam, max_update_norm=thr, verbosity=2 if mode == "verbose" else 0)
-        if mode == "fused":
-            sv.set_fused(True)
+        if mode == "api-format":
+            sv.set_compact(False)
         psi_d, psi_inv_d, pnp_d, pgi_d = dev(psi0), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
         rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
         assert rep.iterations == r["iters"], (mode, dims)
@@ -686,30 +686,58 @@ def test_native_tiled_loop_comm_choreography_on_one_rank(ops, oracle, monkeypatc
 
 
 # ---------------------------------------------------------------------------------------------------
-# single-kernel iteration (nabla_U recomputed per tile, psi / F ping-pong): same bits as everything else
+# the loop in pieces (sobfu_hip_solver_begin / step / end): same bits as iterate(), whatever the step sizes
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dims", [(64, 64, 64), (40, 24, 20), (17, 9, 5), (70, 33, 19), (130, 37, 41), (2, 2, 2), (65, 9, 2), (5, 70, 3)])
-def test_fused_single_kernel_iteration(ops, oracle, dims):
+@pytest.mark.parametrize("dims", [(64, 64, 64), (40, 24, 20), (17, 9, 5), (70, 33, 19), (2, 2, 2), (65, 9, 2)])
+@pytest.mark.parametrize("compact", [True, False])
+def test_session_begin_step_end(ops, oracle, dims, compact):
     pg, pn = rand_volume(dims, 81), rand_volume(dims, 82)
     psi = warped_identity(oracle, dims, 83, 0.9)
     r = oracle.estimate_psi(pg, pn, psi, max_iter=5, alpha=0.05, w_reg=0.4, inverse_iters=0, compute_jacobian=False)
     sv = ops.Solver(dims, max_iter=5, alpha=0.05, w_reg=0.4)
-    sv.set_fused(True)
+    sv.set_compact(compact)
     psi_d, pnp_d = dev(warped_identity(oracle, dims, 83, 0.9)), ops.new_volume(dims)
-    rep, hist = sv.iterate(dev(pg), dev(pn), pnp_d, psi_d, 5)
-    assert rep.iterations == 5
+    sv.begin(dev(pg), dev(pn), pnp_d, psi_d, 5)
+    sv.step(2)
+    sv.step(0)
+    sv.step(3)
+    rep, hist = sv.end()
+    assert rep.iterations == 5 and rep.converged == 0
     assert nmis(host(psi_d), psi) == 0
     assert nmis(host(pnp_d), r["phi_n_psi"]) == 0
     assert same(hist, r["trace"][:, 2])
-    # odd iteration count + convergence break (ping-pong parity must follow the EXECUTED iterations)
+    # fewer iterations than the session's capacity: the state after exactly 3
+    psi3 = warped_identity(oracle, dims, 83, 0.9)
+    r3 = oracle.estimate_psi(pg, pn, psi3, max_iter=3, alpha=0.05, w_reg=0.4, inverse_iters=0, compute_jacobian=False)
+    psi_d3, pnp_d3 = dev(warped_identity(oracle, dims, 83, 0.9)), ops.new_volume(dims)
+    sv.begin(dev(pg), dev(pn), pnp_d3, psi_d3, 5)
+    sv.step(1)
+    sv.step(2)
+    rep3, hist3 = sv.end()
+    assert rep3.iterations == 3 and nmis(host(psi_d3), psi3) == 0 and nmis(host(pnp_d3), r3["phi_n_psi"]) == 0 and same(hist3, r3["trace"][:, 2])
+    # convergence break inside a step: later launches are device-side no-ops, end() reports the reference's iteration
     thr = float(r["trace"][2, 2])
     psi2 = warped_identity(oracle, dims, 83, 0.9)
     r2 = oracle.estimate_psi(pg, pn, psi2, max_iter=5, alpha=0.05, w_reg=0.4, max_update_norm=thr, inverse_iters=0, compute_jacobian=False)
     sv2 = ops.Solver(dims, max_iter=5, alpha=0.05, w_reg=0.4, max_update_norm=thr)
-    sv2.set_fused(True)
+    sv2.set_compact(compact)
     psi_d2, pnp_d2 = dev(warped_identity(oracle, dims, 83, 0.9)), ops.new_volume(dims)
-    rep2, _ = sv2.iterate(dev(pg), dev(pn), pnp_d2, psi_d2, 5)
-    assert rep2.iterations == r2["iters"]
+    sv2.begin(dev(pg), dev(pn), pnp_d2, psi_d2, 5)
+    sv2.step(4)
+    sv2.step(1)
+    rep2, _ = sv2.end()
+    assert rep2.iterations == r2["iters"] and rep2.converged == 1
     assert nmis(host(psi_d2), psi2) == 0 and nmis(host(pnp_d2), r2["phi_n_psi"]) == 0
+    # misuse: a second begin on an open session, step beyond the capacity, end without begin
+    from sobfu_amd._lib import HipError
+
+    sv.begin(dev(pg), dev(pn), pnp_d3, psi_d3, 2)
+    with pytest.raises(HipError):
+        sv.begin(dev(pg), dev(pn), pnp_d3, psi_d3, 2)
+    with pytest.raises(HipError):
+        sv.step(3)
+    sv.end()
+    with pytest.raises(HipError):
+        sv.end()
     sv.close()
     sv2.close()
