@@ -44,8 +44,9 @@ int main(int argc, char** argv) {
         return 2;
     }
     Params p;
-    if (!sobfu_amd::read_params_ini(argv[1], p)) {
-        std::printf("cannot read %s\n", argv[1]);
+    std::string why;
+    if (!sobfu_amd::read_params_ini(argv[1], p, nullptr, &why)) {
+        std::printf("bad parameter file: %s\n", why.c_str());
         return 2;
     }
     int synthetic = 0;

@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <cstdint>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,9 +91,32 @@ inline bool read_depth(const std::string& path, int rows, int cols, std::vector<
     const size_t npix = (size_t) rows * cols;
     if (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P' && file[2] == 'N' && file[3] == 'G') return read_depth_png(file, rows, cols, out, why);
     if (file.size() >= 2 && file[0] == 'P' && file[1] == '5') {
-        int w = 0, h = 0, maxv = 0, used = 0;
-        if (std::sscanf((const char*) file.data() + 2, "%d %d %d%n", &w, &h, &maxv, &used) != 3) return fail("bad PGM header");
-        const size_t start = 2 + (size_t) used + 1;  // one whitespace byte after maxval
+        // header: "P5" <ws> width <ws> height <ws> maxval <one ws byte>, '#' comments run to the end of their line.  Parsed by
+        // hand with bounds checks (the file buffer is not NUL-terminated).
+        size_t pos = 2;
+        int field[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) {
+            for (;;) {  // whitespace and comments before the number
+                while (pos < file.size() && std::isspace(file[pos])) ++pos;
+                if (pos < file.size() && file[pos] == '#') {
+                    while (pos < file.size() && file[pos] != '\n') ++pos;
+                    continue;
+                }
+                break;
+            }
+            size_t digits = 0;
+            long v = 0;
+            while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9' && digits < 9) {
+                v = v * 10 + (file[pos] - '0');
+                ++pos;
+                ++digits;
+            }
+            if (digits == 0 || (pos < file.size() && file[pos] >= '0' && file[pos] <= '9')) return fail("bad PGM header");
+            field[k] = (int) v;
+        }
+        if (pos >= file.size() || !std::isspace(file[pos])) return fail("bad PGM header");
+        const int w = field[0], h = field[1], maxv = field[2];
+        const size_t start = pos + 1;  // one whitespace byte after maxval
         if (w != cols || h != rows || maxv <= 255 || file.size() < start + 2 * npix) return fail("PGM is not a rows x cols 16-bit image");
         out.resize(npix);
         for (size_t i = 0; i < npix; ++i) out[i] = (uint16_t) ((file[start + 2 * i] << 8) | file[start + 2 * i + 1]);

@@ -476,15 +476,21 @@ typedef float4 PointType;
 inline void bindTextures(const int*, const int*, const int*) {}  // the case table lives in the library's constant data
 inline void unbindTextures() {}
 // occupied_voxels: 3 x cols ints (voxel index / vertex count / vertex offset); row stride in ints = step() / 4
-inline int getOccupiedVoxels(const TsdfVolume& v, cuda::DeviceArray2D<int>& occupied_voxels) {
+// `scratch` (optional, beyond the reference's signature): a buffer the caller keeps between frames for the scan steps
+// (cuda::MarchingCubes owns one) -- without it every call allocates and frees its scratch
+inline int getOccupiedVoxels(const TsdfVolume& v, cuda::DeviceArray2D<int>& occupied_voxels, cuda::DeviceArray<unsigned char>* scratch = nullptr) {
     int n = 0;
+    if (scratch && scratch->size() < sobfu_hip_mc_workspace_bytes(v.dims.x, v.dims.y, v.dims.z))
+        scratch->create(sobfu_hip_mc_workspace_bytes(v.dims.x, v.dims.y, v.dims.z));
     sobfuSafeCall(sobfu_hip_mc_occupied_voxels(nullptr, (const float*) v.data, v.dims.x, v.dims.y, v.dims.z, occupied_voxels.ptr(),
-                                               (int) (occupied_voxels.step() / sizeof(int)), occupied_voxels.cols(), &n));
+                                               (int) (occupied_voxels.step() / sizeof(int)), occupied_voxels.cols(), &n,
+                                               scratch ? scratch->ptr() : nullptr, scratch ? scratch->size() : 0));
     return n;
 }
-inline int computeOffsetsAndTotalVertices(cuda::DeviceArray2D<int>& occupied_voxels, int active_voxels) {
+inline int computeOffsetsAndTotalVertices(cuda::DeviceArray2D<int>& occupied_voxels, int active_voxels, cuda::DeviceArray<unsigned char>* scratch = nullptr) {
     int total = 0;
-    sobfuSafeCall(sobfu_hip_mc_offsets(nullptr, occupied_voxels.ptr(), (int) (occupied_voxels.step() / sizeof(int)), active_voxels, &total));
+    sobfuSafeCall(sobfu_hip_mc_offsets(nullptr, occupied_voxels.ptr(), (int) (occupied_voxels.step() / sizeof(int)), active_voxels, &total,
+                                       scratch ? scratch->ptr() : nullptr, scratch ? scratch->size() : 0));
     return total;
 }
 inline void generateTriangles(const TsdfVolume& v, const cuda::DeviceArray2D<int>& occupied_voxels, int active_voxels, const float3& volume_size,
@@ -513,10 +519,10 @@ public:
         if (normals_buffer.empty()) normals_buffer.create(DEFAULT_TRIANGLES_BUFFER_SIZE);
         occupied_voxels_buffer_.create(3, (int) (vertices_buffer.size() / 3));
         device::TsdfVolume vol = const_cast<TsdfVolume&>(volume).pod();
-        const int active_voxels = device::getOccupiedVoxels(vol, occupied_voxels_buffer_);
+        const int active_voxels = device::getOccupiedVoxels(vol, occupied_voxels_buffer_, &scan_scratch_);
         std::cout << "no. of active voxels: " << active_voxels << std::endl;  // marching_cubes.cpp:49
         if (!active_voxels) return Surface();
-        int total_vertices = device::computeOffsetsAndTotalVertices(occupied_voxels_buffer_, active_voxels);
+        int total_vertices = device::computeOffsetsAndTotalVertices(occupied_voxels_buffer_, active_voxels, &scan_scratch_);
         const int cap = (int) (std::min(vertices_buffer.size(), normals_buffer.size()) / 3 * 3);  // whole triangles that fit
         if (total_vertices > cap) total_vertices = cap;
         device::generateTriangles(vol, occupied_voxels_buffer_, active_voxels, device_cast<float3>(volume.getSize()),
@@ -529,6 +535,7 @@ public:
 
 private:
     DeviceArray2D<int> occupied_voxels_buffer_;
+    DeviceArray<unsigned char> scan_scratch_;  // kept between frames: the scan steps allocate nothing per call
     Affine3f pose;
 };
 }  // namespace cuda
@@ -801,11 +808,17 @@ private:
 namespace sobfu_amd {
 
 // Reads the reference's parameter file (params/*.ini; schema src/apps/demo.cpp:87-160, derived values :71-74).
-// Unknown keys (e.g. RHO_0 in params_boxing.ini:40, which makes the reference's own parser throw) are ignored.
-// Returns false if the file cannot be opened.
-inline bool read_params_ini(const std::string& path, Params& p, std::map<std::string, std::string>* raw = nullptr) {
+// Unknown keys (e.g. RHO_0 in params_boxing.ini:40, which makes the reference's own parser throw) are ignored; '#' starts a
+// comment anywhere on a line, as in boost::program_options' config-file parser.  Returns false (reason in *why) if the file
+// cannot be opened, if one of the keys the reference reads unconditionally (TSDF_TRUNC_DIST, ETA, VOL_POSE_T_Z --
+// vm[...].as<float>() throws there, demo.cpp:71-74) is missing, or if the volume dims / size / truncation distance are not
+// positive (a zero truncation distance would fill the volume with inf / NaN).
+inline bool read_params_ini(const std::string& path, Params& p, std::map<std::string, std::string>* raw = nullptr, std::string* why = nullptr) {
     std::ifstream f(path);
-    if (!f) return false;
+    if (!f) {
+        if (why) *why = "cannot open " + path;
+        return false;
+    }
     std::map<std::string, std::string> kv;
     std::string line;
     while (std::getline(f, line)) {
@@ -833,7 +846,21 @@ inline bool read_params_ini(const std::string& path, Params& p, std::map<std::st
     F("MAX_UPDATE_NORM", p.max_update_norm);
     I("S", p.s); F("LAMBDA", p.lambda); F("ALPHA", p.alpha); F("W_REG", p.w_reg);
     float trunc_vox = 0.f, eta_vox = 0.f, tz = 0.f;
+    for (const char* k : {"TSDF_TRUNC_DIST", "ETA", "VOL_POSE_T_Z"})
+        if (!kv.count(k)) {
+            if (why) *why = std::string("required key ") + k + " is missing from " + path;
+            return false;
+        }
     F("TSDF_TRUNC_DIST", trunc_vox); F("ETA", eta_vox); F("VOL_POSE_T_Z", tz);
+    for (int i = 0; i < 3; ++i)
+        if (p.volume_dims[i] <= 0 || !(p.volume_size[i] > 0.f)) {
+            if (why) *why = "VOL_DIMS_* / VOL_SIZE_* must be positive in " + path;
+            return false;
+        }
+    if (!(trunc_vox > 0.f)) {
+        if (why) *why = "TSDF_TRUNC_DIST must be positive in " + path;
+        return false;
+    }
     p.tsdf_trunc_dist = trunc_vox * p.voxel_sizes()[0];  // demo.cpp:71
     p.eta             = eta_vox * p.voxel_sizes()[0];    // demo.cpp:72
     p.volume_pose     = cv::Affine3f().translate(cv::Vec3f(-p.volume_size[0] / 2.f, -p.volume_size[1] / 2.f, tz));  // :73-74

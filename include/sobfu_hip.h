@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SOBFU_HIP_ABI_VERSION 1
+#define SOBFU_HIP_ABI_VERSION 2
 
 #define SOBFU_E_BADARG (-1)      /* null pointer, non-positive dims, ... */
 #define SOBFU_E_FILTER (-2)      /* (s, lambda) not in the reference's Sobolev filter table */
@@ -268,11 +268,17 @@ int sobfu_hip_solver_set_logger(sobfu_hip_solver* s, sobfu_hip_log_fn fn, void* 
  * DeviceArray2D<int>(3, cols)).  Unlike the reference (atomic append, run-dependent order) cells come out in ascending
  * voxel-index order.  Vertices / normals are float4 (x, -y, -z, 1), three per triangle, one normal per triangle.
  * ---------------------------------------------------------------------------------------------------- */
-/* getOccupiedVoxels (marching_cubes.cu:143-163): rows 0 and 1; *h_count = min(active cells, max_size).  Synchronises. */
+/* d_workspace / workspace_bytes: optional device scratch of >= sobfu_hip_mc_workspace_bytes(X, Y, Z) bytes that the caller
+ * keeps between calls (kfusion::cuda::MarchingCubes owns one); NULL or too small = the scratch is allocated and freed inside
+ * the call (two implicit device synchronisations per call). */
+size_t sobfu_hip_mc_workspace_bytes(int X, int Y, int Z);
+/* getOccupiedVoxels (marching_cubes.cu:143-163): rows 0 and 1; *h_count = min(active cells, max_size).  Synchronises.
+ * X*Y*Z > INT32_MAX: SOBFU_E_UNSUPPORTED (int voxel indices, as in the reference). */
 int sobfu_hip_mc_occupied_voxels(void* stream, const float* d_vol, int X, int Y, int Z, int* d_occupied, int stride, int max_size,
-                                 int* h_count);
+                                 int* h_count, void* d_workspace, size_t workspace_bytes);
 /* computeOffsetsAndTotalVertices (marching_cubes.cu:165-181): row 2 = exclusive scan of row 1.  Synchronises. */
-int sobfu_hip_mc_offsets(void* stream, int* d_occupied, int stride, int count, int* h_total_vertices);
+int sobfu_hip_mc_offsets(void* stream, int* d_occupied, int stride, int count, int* h_total_vertices, void* d_workspace,
+                         size_t workspace_bytes);
 /* generateTriangles (marching_cubes.cu:275-313); pose = volume -> world (R row-major, t).  Triangles that would end beyond
  * max_vertices are dropped (the reference does not check). */
 int sobfu_hip_mc_generate_triangles(void* stream, const float* d_vol, int X, int Y, int Z, const int* d_occupied, int stride, int count,

@@ -244,20 +244,30 @@ int scan_in_place_sums(int* d_sums, int nb, int* d_total, hipStream_t st) {
 
 extern "C" {
 
-int sobfu_hip_mc_occupied_voxels(void* stream, const float* d_vol, int X, int Y, int Z, int* d_occupied, int stride, int max_size,
-                                 int* h_count) {
-    SOBFU_CHECK_ARGS(d_vol && d_occupied && h_count && X > 0 && Y > 0 && Z > 0 && max_size > 0 && stride >= max_size);
-    hipStream_t st = (hipStream_t) stream;
+// Scratch of the two scan-based steps: one vertex-count byte per voxel + one int per 1024-voxel chunk (+ the total).
+// A caller-provided workspace (sobfu_hip_mc_workspace_bytes) avoids the hipMalloc / hipFree pair -- two implicit device
+// synchronisations -- per call; without one (NULL / too small) the scratch is allocated for the call.
+static size_t nv_bytes(size_t N) { return (N + 255) / 256 * 256; }
+
+size_t sobfu_hip_mc_workspace_bytes(int X, int Y, int Z) {
+    if (X <= 0 || Y <= 0 || Z <= 0) return 0;
     const size_t N = (size_t) X * Y * Z;
+    return nv_bytes(N) + ((N + kChunk - 1) / kChunk + 1) * sizeof(int);
+}
+
+int sobfu_hip_mc_occupied_voxels(void* stream, const float* d_vol, int X, int Y, int Z, int* d_occupied, int stride, int max_size,
+                                 int* h_count, void* d_workspace, size_t workspace_bytes) {
+    SOBFU_CHECK_ARGS(d_vol && d_occupied && h_count && X > 0 && Y > 0 && Z > 0 && max_size > 0 && stride >= max_size);
+    const size_t N = (size_t) X * Y * Z;
+    if (N > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;  // int32 voxel indices in `occupied`, like the reference
+    hipStream_t st = (hipStream_t) stream;
     const int nb = (int) ((N + kChunk - 1) / kChunk);
-    uint8_t* d_nv = nullptr;
-    int* d_blk = nullptr;  // nb block counts + 1 total
-    SOBFU_HIP_TRY(hipMalloc((void**) &d_nv, N));
-    int rc = (int) hipMalloc((void**) &d_blk, (size_t) (nb + 1) * sizeof(int));
-    if (rc == 0) {
-        hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(kBlock), 0, st, (const float2*) d_vol, Dims{X, Y, Z}, d_nv, d_blk);
-        rc = (int) hipGetLastError();
-    }
+    const bool own = !d_workspace || workspace_bytes < sobfu_hip_mc_workspace_bytes(X, Y, Z);
+    uint8_t* d_nv = (uint8_t*) d_workspace;
+    if (own) SOBFU_HIP_TRY(hipMalloc((void**) &d_nv, sobfu_hip_mc_workspace_bytes(X, Y, Z)));
+    int* d_blk = (int*) (d_nv + nv_bytes(N));  // nb block counts + 1 total
+    hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(kBlock), 0, st, (const float2*) d_vol, Dims{X, Y, Z}, d_nv, d_blk);
+    int rc = (int) hipGetLastError();
     if (rc == 0) rc = scan_in_place_sums(d_blk, nb, d_blk + nb, st);
     if (rc == 0) {
         hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(kBlock), 0, st, d_nv, N, d_blk, d_occupied, d_occupied + stride, max_size);
@@ -266,19 +276,20 @@ int sobfu_hip_mc_occupied_voxels(void* stream, const float* d_vol, int X, int Y,
     int found = 0;
     if (rc == 0) rc = (int) hipMemcpyAsync(&found, d_blk + nb, sizeof(int), hipMemcpyDeviceToHost, st);
     if (rc == 0) rc = (int) hipStreamSynchronize(st);
-    (void) hipFree(d_nv);
-    if (d_blk) (void) hipFree(d_blk);
+    if (own) (void) hipFree(d_nv);
     if (rc == 0) *h_count = found < max_size ? found : max_size;
     return rc;
 }
 
-int sobfu_hip_mc_offsets(void* stream, int* d_occupied, int stride, int count, int* h_total_vertices) {
+int sobfu_hip_mc_offsets(void* stream, int* d_occupied, int stride, int count, int* h_total_vertices, void* d_workspace,
+                         size_t workspace_bytes) {
     SOBFU_CHECK_ARGS(d_occupied && h_total_vertices && count >= 0 && stride >= count);
     if (count == 0) { *h_total_vertices = 0; return 0; }
     hipStream_t st = (hipStream_t) stream;
     const int nb = (count + kChunk - 1) / kChunk;
-    int* d_blk = nullptr;
-    SOBFU_HIP_TRY(hipMalloc((void**) &d_blk, (size_t) (nb + 1) * sizeof(int)));
+    const bool own = !d_workspace || workspace_bytes < (size_t) (nb + 1) * sizeof(int);
+    int* d_blk = (int*) d_workspace;
+    if (own) SOBFU_HIP_TRY(hipMalloc((void**) &d_blk, (size_t) (nb + 1) * sizeof(int)));
     hipLaunchKernelGGL(chunk_sum_kernel, dim3(nb), dim3(kBlock), 0, st, d_occupied + stride, count, d_blk);
     int rc = (int) hipGetLastError();
     if (rc == 0) rc = scan_in_place_sums(d_blk, nb, d_blk + nb, st);
@@ -288,7 +299,7 @@ int sobfu_hip_mc_offsets(void* stream, int* d_occupied, int stride, int count, i
     }
     if (rc == 0) rc = (int) hipMemcpyAsync(h_total_vertices, d_blk + nb, sizeof(int), hipMemcpyDeviceToHost, st);
     if (rc == 0) rc = (int) hipStreamSynchronize(st);
-    (void) hipFree(d_blk);
+    if (own) (void) hipFree(d_blk);
     return rc;
 }
 

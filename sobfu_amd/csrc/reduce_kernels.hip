@@ -4,8 +4,10 @@
 //
 // The float results of data_energy / reg_energy_sobolev depend on the association order, so the order is
 // reproduced: per thread ((0 + e(i)) + e(i+T)) per grid stride, stride-halving pairwise tree T/2..1, block
-// partials summed sequentially on the host.  (The reference's sm>=30 shuffle tail pairs the same elements as
-// its shared-memory tail, reductor.cu:60-107.)
+// partials summed sequentially on the host.  Like the reference's sm>=30 path (reductor.cu:60-69) the tree runs
+// through LDS only down to one wavefront; its last six levels (h = 32..1) are wave64 __shfl_down steps, which pair
+// exactly the elements the shared-memory tail pairs (lane t takes lane t+h's value from before the level), so the
+// bits do not depend on which tail runs.
 #include <cmath>
 #include <vector>
 
@@ -59,9 +61,16 @@ __global__ void __launch_bounds__(512) tree_sum_kernel(El el, float* __restrict_
     }
     s[tid] = my;
     __syncthreads();
-    for (unsigned h = T / 2; h >= 1; h >>= 1) {
+    for (unsigned h = T / 2; h >= 64; h >>= 1) {  // levels that span more than one wavefront: through LDS
         if (tid < h) s[tid] = my = my + s[tid + h];
         __syncthreads();
+    }
+    if (tid < 64) {  // wavefront tail (reductor.cu:60-69)
+#pragma unroll
+        for (unsigned h = 32; h >= 1; h >>= 1) {
+            const float o = __shfl_down(my, h, 64);
+            if (h < T && tid < h) my = my + o;
+        }
     }
     if (tid == 0) partials[blockIdx.x] = my;
 }
@@ -82,9 +91,16 @@ __global__ void __launch_bounds__(512) tree_max_kernel(const float4* __restrict_
     }
     s[tid] = lm;
     __syncthreads();
-    for (unsigned h = T / 2; h >= 1; h >>= 1) {
+    for (unsigned h = T / 2; h >= 64; h >>= 1) {
         if (tid < h && s[tid + h].x > lm.x) s[tid] = lm = s[tid + h];
         __syncthreads();
+    }
+    if (tid < 64) {  // wavefront tail: same pairs, same strict '>' (the lower lane keeps ties)
+#pragma unroll
+        for (unsigned h = 32; h >= 1; h >>= 1) {
+            const float ox = __shfl_down(lm.x, h, 64), oy = __shfl_down(lm.y, h, 64);
+            if (h < T && tid < h && ox > lm.x) lm = make_float2(ox, oy);
+        }
     }
     if (tid == 0) partials[blockIdx.x] = lm;
 }

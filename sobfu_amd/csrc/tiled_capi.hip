@@ -14,7 +14,6 @@
 // dlopen()s that same file and resolves the nine entry points used here, so libsobfu_hip.so still loads on a machine
 // without RCCL and a process never holds two copies of the library.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -29,6 +28,16 @@
 #include "sobfu_host.hpp"
 #include "sobfu_launch.hpp"
 
+
+// The handful of RCCL (= NCCL API) types this file needs, declared here so that neither building nor loading the library
+// depends on an RCCL installation (values as in rccl.h; the entry points are resolved with dlsym at run time).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint32 = 3, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+}
 
 namespace {
 
@@ -187,10 +196,12 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
-    // the max-norm rows travel between streams of THIS device only (pass B's atomics -> the all-reduce kernel -> the next
-    // pass B's gate): their events skip the system-scope fence (an L2 write-back + invalidate around a drained pipeline);
-    // ev_bnd / ev_xchg order data other GPUs read or wrote and keep it
-    const unsigned local_ev = hipEventDisableTiming | (std::getenv("SOBFU_TILED_SYSFENCE_EVENTS") ? 0u : hipEventDisableSystemFence);
+    // the max-norm rows are written by pass B's atomics on this device, but a real RCCL all-reduce may let PEERS write the
+    // reduced row straight into this buffer (direct / registered-buffer paths): every event keeps the system-scope fence
+    // until the fence-less variant has been validated on >= 2 real GPUs.  SOBFU_TILED_LOCAL_EVENTS=1 opts into events
+    // without the fence (an L2 write-back + invalidate less per edge) for the row hand-offs.
+    const char* le = std::getenv("SOBFU_TILED_LOCAL_EVENTS");
+    const unsigned local_ev = hipEventDisableTiming | ((le && le[0] == '1') ? hipEventDisableSystemFence : 0u);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red[0], local_ev);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red[1], local_ev);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_row, local_ev);

@@ -370,20 +370,33 @@ class Solver:
 
 
 # ---- marching cubes (include/kfusion/internal.hpp:213-225) ---------------------------------------------------------------
-def mc_occupied_voxels(vol, max_size):
+def mc_workspace(vol):
+    """scratch for mc_occupied_voxels / mc_offsets on volumes of this shape (keep it between frames: no allocation per call)"""
+    _lib.lib().sobfu_hip_mc_workspace_bytes.restype = C.c_size_t
+    n = int(_lib.lib().sobfu_hip_mc_workspace_bytes(*_xyz(vol)))
+    return torch.empty(n, dtype=torch.uint8, device=vol.device)
+
+
+def _ws(workspace):
+    if workspace is None:
+        return None, C.c_size_t(0)
+    return _ptr(workspace, torch.uint8), C.c_size_t(workspace.numel())
+
+
+def mc_occupied_voxels(vol, max_size, workspace=None):
     """getOccupiedVoxels -> (occupied int32 (3, max_size) on the GPU: voxel index / vertex count / vertex offset rows, count)"""
     occ = torch.zeros((3, int(max_size)), dtype=torch.int32, device=vol.device)
     n = C.c_int(0)
     check(_lib.lib().sobfu_hip_mc_occupied_voxels(_stream(), _ptr(vol), *_xyz(vol), _ptr(occ, torch.int32), C.c_int(occ.shape[1]),
-                                                  C.c_int(int(max_size)), C.byref(n)), "mc_occupied_voxels")
+                                                  C.c_int(int(max_size)), C.byref(n), *_ws(workspace)), "mc_occupied_voxels")
     return occ, n.value
 
 
-def mc_offsets(occ, count):
+def mc_offsets(occ, count, workspace=None):
     """computeOffsetsAndTotalVertices: row 2 = exclusive scan of row 1 -> total vertices"""
     total = C.c_int(0)
-    check(_lib.lib().sobfu_hip_mc_offsets(_stream(), _ptr(occ, torch.int32), C.c_int(occ.shape[1]), C.c_int(int(count)), C.byref(total)),
-          "mc_offsets")
+    check(_lib.lib().sobfu_hip_mc_offsets(_stream(), _ptr(occ, torch.int32), C.c_int(occ.shape[1]), C.c_int(int(count)), C.byref(total),
+                                          *_ws(workspace)), "mc_offsets")
     return total.value
 
 
@@ -397,14 +410,14 @@ def mc_generate_triangles(vol, occ, count, volume_size, R, t, vertices, normals)
                                                      _ptr(vertices), _ptr(normals), C.c_int(vertices.shape[0])), "mc_generate_triangles")
 
 
-def marching_cubes(vol, volume_size, R=np.eye(3), t=(0, 0, 0), max_voxels=2_000_000, max_vertices=None):
+def marching_cubes(vol, volume_size, R=np.eye(3), t=(0, 0, 0), max_voxels=2_000_000, max_vertices=None, workspace=None):
     """kfusion::cuda::MarchingCubes::run (src/kfusion/marching_cubes.cpp:23-79) -> (vertices (n, 4), normals (n, 4)) GPU tensors"""
     max_vertices = max_vertices or 3 * max_voxels
-    occ, count = mc_occupied_voxels(vol, max_voxels)
+    occ, count = mc_occupied_voxels(vol, max_voxels, workspace)
     if count == 0:
         e = torch.zeros((0, 4), dtype=torch.float32, device=vol.device)
         return e, e.clone()
-    total = min(mc_offsets(occ, count), max_vertices // 3 * 3)  # whole triangles only
+    total = min(mc_offsets(occ, count, workspace), max_vertices // 3 * 3)  # whole triangles only
     v = torch.zeros((max_vertices, 4), dtype=torch.float32, device=vol.device)
     n = torch.zeros_like(v)
     mc_generate_triangles(vol, occ, count, volume_size, R, t, v, n)

@@ -109,3 +109,44 @@ def test_npy_writer(tool, tmp_path):
         a = np.load(out)
         assert a.dtype == np.float32 and a.shape == shape
         assert np.array_equal(a.ravel(), 0.5 * np.arange(a.size, dtype=np.float32))
+
+
+def test_pgm_comments_and_malformed_headers(tool, tmp_path):
+    """PGM headers may carry '#' comment lines; short / malformed headers must be rejected without reading past the buffer"""
+    rows, cols = 5, 7
+    img = (np.arange(rows * cols, dtype=np.uint16).reshape(rows, cols) * 911 + 300).astype(np.uint16)
+    body = img.astype(">u2").tobytes()
+    p = tmp_path / "c.pgm"
+    p.write_bytes(b"P5\n# made by a depth camera\n%d %d\n# maxval next\n65535\n" % (cols, rows) + body)
+    rc, got = decode(tool, p, rows, cols, tmp_path)
+    assert rc == 0 and np.array_equal(got, img)
+    p.write_bytes(b"P5 %d\t%d 65535 " % (cols, rows) + body)  # any single whitespace byte may end the header
+    rc, got = decode(tool, p, rows, cols, tmp_path)
+    assert rc == 0 and np.array_equal(got, img)
+    for bad in (b"P5", b"P5\n", b"P5\n7", b"P5\n7 5", b"P5\n7 5\n65535", b"P5\n7 x\n65535\n", b"P5\n# only a comment",
+                b"P5\n99999999999 5\n65535\n", b"P5\n7 5\n255\n" + body, b"P5\n7 5\n65535\n" + body[:-1]):
+        p.write_bytes(bad)
+        rc, msg = decode(tool, p, rows, cols, tmp_path)
+        assert rc != 0 and "error" in msg, bad
+
+
+def test_ini_reader_requires_the_keys_the_reference_requires(tmp_path):
+    """TSDF_TRUNC_DIST / ETA / VOL_POSE_T_Z are read unconditionally by the reference (src/apps/demo.cpp:71-74): a file without
+    them, or with non-positive dims / size / truncation, is refused before anything touches the GPU"""
+    app = build_host.build_app()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    good = open(os.path.join(root, "params", "config1_sphere_64.ini")).read()
+
+    def run(text):
+        p = tmp_path / "p.ini"
+        p.write_text(text)
+        return subprocess.run([app, str(p), "--synthetic", "1"], capture_output=True, text=True)
+
+    for key in ("TSDF_TRUNC_DIST", "ETA", "VOL_POSE_T_Z"):
+        r = run("\n".join(ln for ln in good.splitlines() if not ln.startswith(key + "=")))
+        assert r.returncode == 2 and key in r.stdout, (key, r.stdout)
+    for key, val in (("VOL_DIMS_Y", "0"), ("VOL_SIZE_Z", "-1"), ("TSDF_TRUNC_DIST", "0")):
+        r = run("\n".join(f"{key}={val}" if ln.startswith(key + "=") else ln for ln in good.splitlines()))
+        assert r.returncode == 2 and "positive" in r.stdout, (key, r.stdout)
+    r = subprocess.run([app, str(tmp_path / "missing.ini"), "--synthetic", "1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot open" in r.stdout
