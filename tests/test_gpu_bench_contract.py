@@ -51,6 +51,14 @@ def test_gpus_n_self_launches_replicas():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
 
 
+def test_config5_replicas_512():
+    """BASELINE config 5's shape: 512^3 grids, one independent sequence per rank (two ranks sharing this box's GPU)"""
+    d = run_bench("--gpus", "2", "--replicas", "--dim", "512", "--steps", "4", "--warmup", "2", "--repeats", "2", "--profile-repeats", "1",
+                  "--no-cpu-baseline", env={"SOBFU_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["grid"] == [512, 512, 512] and d["value"] > 0
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 512 ** 3 * 64
+
+
 def test_slab_path_line_on_one_gpu():
     d = run_bench("--gpus", "1", "--steps", "20", "--warmup", "6", "--dim", "128", "--no-cpu-baseline", env={"SOBFU_FORCE_TILED": "1"})
     assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and "native C++ loop" in d["config"]["parallelism"]
