@@ -154,12 +154,18 @@ class Ranks:
         if self.world > 1:
             self.dist.barrier()
 
-    def max(self, values):
+    def _reduce(self, values, op):
         if self.world == 1:
             return [float(v) for v in values]
         t = self.torch.tensor(list(values), dtype=self.torch.float64, device="cpu" if self.share else "cuda")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=op)
         return [float(v) for v in t.tolist()]
+
+    def max(self, values):
+        return self._reduce(values, self.dist.ReduceOp.MAX)
+
+    def min(self, values):
+        return self._reduce(values, self.dist.ReduceOp.MIN)
 
     def close(self):
         if self.world > 1:
@@ -241,7 +247,8 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: every rank solves its OWN grid (independent sequences, BASELINE config 5 style: no exchange, weak "
                          "scaling) instead of the default -- ONE grid cut into N tiles with RCCL halo exchange (strong scaling)")
-    ap.add_argument("--tiles", type=str, default="", help="N > 1, strong scaling: tile grid PxxPyxPz (default: 2x2x2 at N=8, see sobfu_amd.tiles)")
+    ap.add_argument("--tiles", type=str, default="", help="N > 1, strong scaling: tile grid PxxPyxPz (default sobfu_amd.tiled.default_grid: "
+                                                         "2x2x2 at N=8, 1x2x2 at N=4, 1x1x2 at N=2)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
@@ -262,21 +269,9 @@ def main():
     P = boxing_params(args.dim)
     force_tiled = os.environ.get("SOBFU_FORCE_TILED") == "1"  # exercise the tile path on one GPU (debugging)
     if (world > 1 and not args.replicas) or force_tiled:
-        try:
-            from sobfu_amd import tiles
-        except ImportError:
-            tiles = None
-        if tiles is not None:
-            res = tiles.bench_tiles(args, P, ranks, timed_regions)
-        else:  # z-slab loop of round 1
-            if world == 1 and not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", _free_port())
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-            from sobfu_amd import tiled
+        from sobfu_amd import tiled
 
-            res = tiled.bench_tiled(P, args.steps, args.warmup, rank, world)
-            res["region_seconds"] = ranks.max([res["seconds"]])
+        res = tiled.bench_tiled(args, P, ranks, timed_regions)
     else:
         res = bench_single(args, P, ranks, torch)
 
@@ -345,7 +340,7 @@ def main():
                                 "iterations_per_s_incl_fixed": 50 / s50,
                                 "note": "one whole sobfu_hip_solver_iterate call of 50 iterations (BASELINE config 3's frame): enter the "
                                         "compact format + 50 iterations + max-norm rows to the host + leave, host-synchronised"}
-        for k in ("tiles_autotune_us", "tiles_diag", "tiles", "tiled_autotune_us", "tiled_diag"):
+        for k in ("tiles", "tiled_autotune_us", "tiled_diag"):
             if res.get(k):
                 out[k] = res[k]
         if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise

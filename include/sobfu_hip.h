@@ -193,6 +193,34 @@ int sobfu_hip_extract_tsdf(const float* d_src2, float* d_dst1, size_t n, void* s
 int sobfu_hip_tile_apply_tsdf_only(const float* d_phi1, int Zg, float* d_out1, const float* d_psi3, int X, int Y, int Lz,
                                    void* stream);
 
+/* 3-D tiles (the 2x2x2 split of BASELINE config 4): every field argument is a LOCAL array (Lx, Ly, Lz) whose cell (0, 0, 0) is
+ * global cell (xb, yb, zb) of the (Xg, Yg, Zg) volume and that carries halo cells on every side that faces a neighbour tile;
+ * d_phi_n / d_phi / the d_psi of estimate_inverse are WHOLE volumes.  `box` = (x0, x1, y0, y1, z0, z1): the cells a launch produces;
+ * `own`: the cells that belong to this rank (they alone enter the max-norm).  transposed != 0 maps the 64 lanes of a wave onto y
+ * instead of x -- for boxes that are thin in x (same results).  Boundary rules apply at array edges, which are volume boundaries
+ * exactly where a tile has no halo. */
+int sobfu_hip_tile3_init_identity(float* d_psi, int Lx, int Ly, int Lz, int xb, int yb, int zb, void* stream);
+int sobfu_hip_tile3_apply(const float* d_phi, int Xg, int Yg, int Zg, float* d_phi_warped, const float* d_psi, int Lx, int Ly, int Lz,
+                          void* stream);
+int sobfu_hip_tile3_estimate_inverse(const float* d_psi, int Xg, int Yg, int Zg, float* d_psi_inv, int Lx, int Ly, int Lz, int xb, int yb,
+                                     int zb, int n_sweeps, void* stream);
+int sobfu_hip_tile3_integrate_depth(const float* d_dists, int dists_step_bytes, int rows, int cols, float* d_vol_local, int Lx, int Ly,
+                                    int Lz, int xb, int yb, int zb, const float voxel_size[3], float trunc_dist, float eta,
+                                    const float R[9], const float t[3], float fx, float fy, float cx, float cy, void* stream);
+int sobfu_hip_tile3_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
+                                       float w_reg, int Lx, int Ly, int Lz, const int box[6], int transposed,
+                                       const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
+int sobfu_hip_tile3_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi, float* d_updates,
+                                        uint32_t* d_max_sq_slots, const float taps[7], float alpha, int Lx, int Ly, int Lz, int Xg,
+                                        int Yg, int Zg, const int own[6], const int box[6], int transposed,
+                                        const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
+int sobfu_hip_tile3_apply_tsdf_only(const float* d_phi1, int Xg, int Yg, int Zg, float* d_out1, const float* d_psi3, int Lx, int Ly, int Lz,
+                                    void* stream);
+/* Halo messages: n_boxes boxes (6 ints each) of a 12-byte (compact) field <-> consecutive segments of d_buf, x fastest inside a
+ * box -- the send side packs the cells a neighbour needs, the receive side scatters them into its halo cells (<= 18 boxes). */
+int sobfu_hip_tile3_pack(const float* d_field3, int Lx, int Ly, int Lz, float* d_buf, const int* boxes, int n_boxes, void* stream);
+int sobfu_hip_tile3_unpack(float* d_field3, int Lx, int Ly, int Lz, const float* d_buf, const int* boxes, int n_boxes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * solver handle  (sobfu::cuda::Solver, include/sobfu/solver.hpp:52-101, src/sobfu/solver.cpp:7-101)
  * ---------------------------------------------------------------------------------------------------- */
@@ -301,6 +329,13 @@ int sobfu_hip_tiled_unique_id(char out[128]);
 int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
                            const sobfu_hip_solver_params* params);
 int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t);
+/* The same for a Px x Py x Pz grid of tiles (rank = cx + Px * (cy + Py * cz); the cells of every axis are split as evenly as
+ * possible; every split axis needs >= 4 cells per tile).  Px = Py = 1 is the z-slab layout of sobfu_hip_tiled_create. */
+int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, int Py, int Pz, int rank, const char unique_id[128],
+                            const sobfu_hip_solver_params* params);
+/* out[24] = per axis (x, y, z): tile grid P, tile coordinates c, owned global range [g0, g1), halo cells lo / hi, local extent L,
+ * global coordinate `base` of local cell 0 -- eight triples in that order. */
+int sobfu_hip_tiled_layout3(const sobfu_hip_tiled* t, int out[24]);
 /* owned planes [z0, z1) of this rank, halo planes below / above, slab thickness Lz, global z of local plane 0 */
 int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, int* hi, int* Lz, int* zbase);
 /* n_iters iterations on this rank's slab (collective).  Local slabs: phi_global / phi_n o psi float2 (X, Y, Lz), psi
@@ -308,6 +343,13 @@ int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, 
 int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
                             float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
                             float* per_iter_max_norm, void* stream);
+/* The same loop in pieces, as sobfu_hip_solver_begin / step / end (collective; step ENQUEUES n_iters more iterations and returns
+ * without synchronising; end synchronises, reduces the max-norm rows the loop has not yet made global, finds the iteration the
+ * reference stops at and rebuilds the caller's arrays). */
+int sobfu_hip_tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full, float* d_phi_n_psi_local,
+                          float* d_psi_local, int max_iters, void* stream);
+int sobfu_hip_tiled_step(sobfu_hip_tiled* t, int n_iters, void* stream);
+int sobfu_hip_tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream);
 /* Optional: a second communicator (a second ncclGetUniqueId, broadcast like the first) and a stream of its own for the max-norm
  * all-reduce of a live threshold.  With it the reduction of iteration k's row is issued right after that iteration's pass B and
  * runs beside iteration k+1 (the late gate only needs it by pass B of k+2) without ever queueing behind a halo exchange on the
@@ -321,17 +363,27 @@ int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule);
 /* diagnostics: host microseconds per iteration the last sobfu_hip_tiled_iterate spent ISSUING its loop (launches, events,
  * RCCL calls) -- against the measured time per iteration it tells whether a thin slab is host-bound */
 double sobfu_hip_tiled_last_enqueue_us(const sobfu_hip_tiled* t);
-/* Pluggable transport for communicator-less handles (MPI, an in-process loopback for tests, ...).  `exchange` must make
- * planes [own_lo - planes, own_lo) / [own_hi, own_hi + planes) of the 12-byte slab field equal to the neighbours'
- * [own_hi - planes, own_hi) / [own_lo, own_lo + planes) (local plane indices of each rank); `allreduce_max` must leave the
+/* One halo message: `count` floats from d_send + send_off of this rank to d_recv + recv_off of rank `peer`'s matching message
+ * (every pair of neighbours exchanges exactly one message in each direction per exchange). */
+typedef struct {
+    int peer;
+    size_t send_off, recv_off, count; /* in floats */
+} sobfu_hip_tiled_msg;
+/* The messages of one exchange of a 3-D tile and the boxes (6 ints each: x0, x1, y0, y1, z0, z1, local cells) they are packed
+ * from / scattered to; returns their number (0 for z-slabs, whose messages are plane ranges of the field itself). */
+int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int* send_boxes, int* recv_boxes, int max_msgs);
+/* Pluggable transport for communicator-less handles (MPI, an in-process loopback for tests, ...).  `exchange` must deliver every
+ * message: msgs[i].count floats at d_send + msgs[i].send_off arrive at d_recv + recv_off of the message rank msgs[i].peer posts
+ * for this rank (d_send == d_recv for z-slabs, which exchange planes of the field in place); `allreduce_max` must leave the
  * element-wise maximum over all ranks in d_buf.  Both are called on the host in launch order and must order their work
  * after everything already enqueued on `stream` and before anything enqueued on it later. */
-typedef int (*sobfu_hip_tiled_exchange_fn)(void* ctx, int rank, float* d_field3, int planes, void* stream);
+typedef int (*sobfu_hip_tiled_exchange_fn)(void* ctx, int rank, const float* d_send, float* d_recv, const sobfu_hip_tiled_msg* msgs,
+                                           int n_msgs, void* stream);
 typedef int (*sobfu_hip_tiled_allreduce_fn)(void* ctx, int rank, uint32_t* d_buf, size_t n, void* stream);
 int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_fn exchange, sobfu_hip_tiled_allreduce_fn allreduce_max,
                                   void* ctx);
-/* bring-up helpers: the loop's halo exchange on a caller-provided 12-byte slab field; a self send/recv and a MAX
- * all-reduce through the same RCCL entry points (usable with a single rank) */
+/* bring-up helpers: the loop's halo exchange on a caller-provided 12-byte tile field (planes < 4: z-slabs only); a self
+ * send/recv and a MAX all-reduce through the same RCCL entry points (usable with a single rank) */
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream);
 int sobfu_hip_tiled_self_sendrecv(sobfu_hip_tiled* t, const float* d_src, float* d_dst, size_t n, void* stream);
 int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_t n, void* stream);

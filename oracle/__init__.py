@@ -167,9 +167,9 @@ def apply(phi, phi_warped, psi):
     lib().so_apply(_p(phi), _p(phi_warped), _p(psi), *_dims(phi))
 
 
-def apply_tile(phi_full, phi_warped_slab, psi_slab):
-    X, Y, Lz = _dims(psi_slab)
-    lib().so_apply_tile(_p(phi_full), C.c_int(phi_full.shape[0]), _p(phi_warped_slab), _p(psi_slab), X, Y, Lz)
+def apply_tile(phi_full, phi_warped_tile, psi_tile):
+    """apply on a tile (any local extents): phi_full is the whole volume, psi holds absolute voxel coordinates"""
+    lib().so_apply_tile3(_p(phi_full), *_dims(phi_full), _p(phi_warped_tile), _p(psi_tile), *_dims(psi_tile))
 
 
 def estimate_inverse(psi, psi_inv, n_iters=48):

@@ -351,6 +351,16 @@ void so_apply_tile(const f2 *phi, int Zg, f2 *phi_warped, const f4 *psi, int X, 
     }
 }
 
+/* the same on a 3-D tile: phi is the whole (Xg, Yg, Zg) volume, psi / phi_warped are (Lx, Ly, Lz) local arrays */
+void so_apply_tile3(const f2 *phi, int Xg, int Yg, int Zg, f2 *phi_warped, const f4 *psi, int Lx, int Ly, int Lz) {
+    size_t N = (size_t) Lx * Ly * Lz;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < N; ++i) {
+        f4 p          = psi[i];
+        phi_warped[i] = interp_tsdf(phi, Xg, Yg, Zg, p.x, p.y, p.z);
+    }
+}
+
 /* estimate_inverse_kernel x n_iters -- vector_fields.cu:111-138 (reference: 48 sweeps, in place) */
 void so_estimate_inverse(const f4 *psi, f4 *psi_inv, int X, int Y, int Z, int n_iters) {
     for (int it = 0; it < n_iters; ++it) {

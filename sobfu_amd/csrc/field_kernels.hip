@@ -14,10 +14,10 @@ namespace {
     if (x >= (d).x || y >= (d).y) return;
 
 // init_identity_kernel -- vector_fields.cu:64-79.  (float) z equals the reference's z-fold sum of 1.f exactly.
-// zbase: global z of local plane 0 (multi-GPU slabs; 0 on a single GPU)
-__global__ void __launch_bounds__(256) init_identity_kernel(float4* __restrict__ psi, Dims d, int zbase) {
+// base: global coordinates of local cell (0, 0, 0) (multi-GPU tiles; 0 on a single GPU)
+__global__ void __launch_bounds__(256) init_identity_kernel(float4* __restrict__ psi, Dims d, Dims base) {
     VOXEL_XYZ(d);
-    psi[vidx(d, x, y, z)] = f4((float) x, (float) y, (float) (z + zbase));
+    psi[vidx(d, x, y, z)] = f4((float) (x + base.x), (float) (y + base.y), (float) (z + base.z));
 }
 
 // apply_kernel -- vector_fields.cu:81-100
@@ -61,10 +61,10 @@ SOBFU_DEV float4 inverse_fixed_point(const float4* __restrict__ psi, const Dims&
 }
 
 __global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
-                                                                  Dims d, Dims pd, int zbase, int n_sweeps) {
+                                                                  Dims d, Dims pd, Dims base, int n_sweeps) {
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
-    const float4 id = f4((float) x, (float) y, (float) (z + zbase));
+    const float4 id = f4((float) (x + base.x), (float) (y + base.y), (float) (z + base.z));
     psi_inv[i] = inverse_fixed_point(psi, pd, psi_inv[i], id, n_sweeps);
 }
 
@@ -145,13 +145,38 @@ int sobfu_hip_clear_field(float* d_field, int X, int Y, int Z, void* stream) {
 
 int sobfu_hip_init_identity(float* d_psi, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && X > 0 && Y > 0 && Z > 0);
-    LAUNCH_VOXEL(init_identity_kernel, X, Y, Z, stream, (float4*) d_psi, Dims{X, Y, Z}, 0);
+    LAUNCH_VOXEL(init_identity_kernel, X, Y, Z, stream, (float4*) d_psi, Dims{X, Y, Z}, Dims{0, 0, 0});
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_tile_init_identity(float* d_psi, int X, int Y, int Lz, int zbase, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && X > 0 && Y > 0 && Lz > 0 && zbase >= 0);
-    LAUNCH_VOXEL(init_identity_kernel, X, Y, Lz, stream, (float4*) d_psi, Dims{X, Y, Lz}, zbase);
+    LAUNCH_VOXEL(init_identity_kernel, X, Y, Lz, stream, (float4*) d_psi, Dims{X, Y, Lz}, Dims{0, 0, zbase});
+    return (int) hipGetLastError();
+}
+
+// 3-D tiles: local arrays (Lx, Ly, Lz) whose cell (0, 0, 0) is global cell (xb, yb, zb) of the (Xg, Yg, Zg) volume
+int sobfu_hip_tile3_init_identity(float* d_psi, int Lx, int Ly, int Lz, int xb, int yb, int zb, void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && Lx > 0 && Ly > 0 && Lz > 0 && xb >= 0 && yb >= 0 && zb >= 0);
+    LAUNCH_VOXEL(init_identity_kernel, Lx, Ly, Lz, stream, (float4*) d_psi, Dims{Lx, Ly, Lz}, Dims{xb, yb, zb});
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile3_apply(const float* d_phi, int Xg, int Yg, int Zg, float* d_phi_warped, const float* d_psi, int Lx, int Ly, int Lz,
+                          void* stream) {
+    SOBFU_CHECK_ARGS(d_phi && d_phi_warped && d_psi && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0 && d_phi != d_phi_warped);
+    LAUNCH_VOXEL(apply_kernel, Lx, Ly, Lz, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{Lx, Ly, Lz},
+                 Dims{Xg, Yg, Zg});
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile3_estimate_inverse(const float* d_psi, int Xg, int Yg, int Zg, float* d_psi_inv, int Lx, int Ly, int Lz, int xb, int yb,
+                                     int zb, int n_sweeps, void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && d_psi_inv && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0 && xb >= 0 && yb >= 0 && zb >= 0 &&
+                     n_sweeps >= 0 && d_psi != d_psi_inv);
+    if (n_sweeps == 0) return 0;
+    LAUNCH_VOXEL(inverse_fixed_point_kernel, Lx, Ly, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{Lx, Ly, Lz},
+                 Dims{Xg, Yg, Zg}, Dims{xb, yb, zb}, n_sweeps);
     return (int) hipGetLastError();
 }
 
@@ -167,7 +192,7 @@ int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv
     SOBFU_CHECK_ARGS(d_psi && d_psi_inv && X > 0 && Y > 0 && Lz > 0 && Zg > 0 && zbase >= 0 && n_sweeps >= 0 && d_psi != d_psi_inv);
     if (n_sweeps == 0) return 0;
     LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Lz},
-                 Dims{X, Y, Zg}, zbase, n_sweeps);
+                 Dims{X, Y, Zg}, Dims{0, 0, zbase}, n_sweeps);
     return (int) hipGetLastError();
 }
 
@@ -181,8 +206,8 @@ int sobfu_hip_apply(const float* d_phi, float* d_phi_warped, const float* d_psi,
 int sobfu_hip_estimate_inverse(const float* d_psi, float* d_psi_inv, int X, int Y, int Z, int n_sweeps, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && d_psi_inv && X > 0 && Y > 0 && Z > 0 && n_sweeps >= 0 && d_psi != d_psi_inv);
     if (n_sweeps == 0) return 0;
-    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, Dims{X, Y, Z}, 0,
-                 n_sweeps);
+    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, Dims{X, Y, Z},
+                 Dims{0, 0, 0}, n_sweeps);
     return (int) hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ namespace {
 struct Taps {
     float s[7];
 };
+constexpr int kMaxMsgs = 18;  // 6 face + 12 edge neighbours of a 3-D tile
 
 // ============================================================================================================
 // Part 1: reference-shaped launchers
@@ -165,35 +166,66 @@ SOBFU_DEV float interp_tsdf_only(const float* __restrict__ v, const Dims& d, flo
 }
 
 // --- workgroup -> tile map ---------------------------------------------------------------------------------------
-// Linear workgroup id -> (x tile fastest, then y, then z-chunk).  With SOBFU_XCD_SWIZZLE the id is first remapped so
-// that each XCD (workgroup b runs on XCD b % 8 -- observed, used for speed only) owns a contiguous run of tiles and
-// serves neighbour-tile halos from its own L2.  PMC (256^3): fabric bytes per launch drop 1.013 -> 0.821 GB for pass
-// A and 1.406 -> 1.286 GB for pass B; interleaved A/B wall time: pass A -3 %, pass B +1 % (not fabric-bound) -> the
-// map is enabled for pass A only.
-struct TileId {
-    int tx, ty, tz;
+// A launch produces up to kMaxBoxes BOXES of cells of the (local) array: the whole volume on a single GPU; on a multi-GPU
+// tile, the owned cells (plus the one-cell shells pass B refreshes) or the boundary / interior regions of an overlapped
+// schedule.  Workgroups are numbered box after box; inside a box x-tile (64 lanes) fastest, then y-tile, then z-chunk.
+// A TRANSPOSED box maps the 64 lanes of a wave onto y and the workgroup's rows onto x -- for regions that are thin in x
+// (the one-column x shell of a tile, 4-column x faces), where x-major lanes would leave all but a few lanes of every
+// wave idle.  Its global accesses are strided instead of coalesced; such boxes hold a few per cent of the cells.
+// (u, v) below are the lane-axis and row-axis coordinates: (x, y), or (y, x) in a transposed box.
+//
+// With the XCD swizzle the linear id is first remapped so that each XCD (workgroup b runs on XCD b % 8 -- observed, used
+// for speed only) owns a contiguous run of tiles and serves neighbour-tile halos from its own L2.  PMC (256^3): fabric
+// bytes per launch drop 1.013 -> 0.821 GB for pass A and 1.406 -> 1.286 GB for pass B.
+constexpr int kMaxBoxes = 6;
+struct Box {
+    int x0, x1, y0, y1, z0, z1;  // cells [x0, x1) x [y0, y1) x [z0, z1)
+    int zc;                      // planes per march (z-chunk)
+    int tr;                      // transposed
 };
-template <bool XCD_SWIZZLE>
-SOBFU_DEV TileId tile_of_block(int ntx, int nty, int ntz) {
+struct BoxList {
+    int n;
+    Box b[kMaxBoxes];
+    int first[kMaxBoxes + 1];  // first workgroup of box i; first[n] = workgroups in the launch
+};
+struct TileGeom {
+    int u0, v0, zb, ze;  // tile origin along the lane / row axes, planes [zb, ze) of this march
+    int u_hi, v_hi;      // cells with u >= u_hi or v >= v_hi are outside the box (computed, not stored)
+    int DU, DV;          // array extents along the lane / row axes
+    int su, sv;          // element strides of the lane / row axes
+    bool tr;
+};
+template <bool TRANSPOSABLE, bool XCD_SWIZZLE>
+SOBFU_DEV TileGeom tile_geom(const BoxList& L, const Dims& d, int ty) {
     unsigned t = blockIdx.x;
     if (XCD_SWIZZLE) {
-        const unsigned nb = (unsigned) ntx * nty * ntz, q = nb / 8u, rem = nb % 8u, xcd = t % 8u, slot = t / 8u;
+        const unsigned nb = (unsigned) L.first[L.n], q = nb / 8u, rem = nb % 8u, xcd = t % 8u, slot = t / 8u;
         t = xcd * q + min(xcd, rem) + slot;  // bijective for any nb
     }
-    TileId r;
-    r.tx = (int) (t % ntx);
-    r.ty = (int) ((t / ntx) % nty);
-    r.tz = (int) (t / ((unsigned) ntx * nty));
-    return r;
-}
-
-// z-chunk -> plane range of a launch that covers [z_lo, z_hi) and, optionally, [z_lo2, z_hi2)
-SOBFU_DEV int z_chunks(int z_lo, int z_hi, int zc) { return z_hi > z_lo ? (z_hi - z_lo + zc - 1) / zc : 0; }
-SOBFU_DEV void chunk_range(int tz, int zc, int z_lo, int z_hi, int z_lo2, int z_hi2, int& zb, int& ze) {
-    const int n1 = z_chunks(z_lo, z_hi, zc);
-    const bool second = tz >= n1;
-    zb = second ? z_lo2 + (tz - n1) * zc : z_lo + tz * zc;
-    ze = min(zb + zc, second ? z_hi2 : z_hi);
+    Box b     = L.b[0];  // constant indices only: a dynamically indexed by-value argument would be copied to scratch
+    int first = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxBoxes; ++k)
+        if (k < L.n && (int) t >= L.first[k]) {
+            b     = L.b[k];
+            first = L.first[k];
+        }
+    t -= (unsigned) first;
+    TileGeom g;
+    g.tr          = TRANSPOSABLE && b.tr != 0;
+    const int ulo = g.tr ? b.y0 : b.x0, vlo = g.tr ? b.x0 : b.y0;
+    g.u_hi        = g.tr ? b.y1 : b.x1;
+    g.v_hi        = g.tr ? b.x1 : b.y1;
+    g.DU          = g.tr ? d.y : d.x;
+    g.DV          = g.tr ? d.x : d.y;
+    g.su          = g.tr ? d.x : 1;
+    g.sv          = g.tr ? 1 : d.x;
+    const unsigned ntu = (unsigned) ((g.u_hi - ulo + TX - 1) / TX), ntv = (unsigned) ((g.v_hi - vlo + ty - 1) / ty);
+    g.u0 = ulo + (int) (t % ntu) * TX;
+    g.v0 = vlo + (int) ((t / ntu) % ntv) * ty;
+    g.zb = b.z0 + (int) (t / (ntu * ntv)) * b.zc;
+    g.ze = min(g.zb + b.zc, b.z1);
+    return g;
 }
 
 // --- convergence gate ----------------------------------------------------------------------------------------
@@ -271,19 +303,17 @@ struct PassAArgs {
     const void* pg;   // phi_global
     const void* psi;
     void* nU;
-    Dims d;
+    Dims d;  // extents of the (local) arrays
     float w_reg;
-    int zc;  // slices per workgroup
-    int z_lo, z_hi;  // planes [z_lo, z_hi) are produced by this launch (the whole volume, or a sub-range of a slab)
-    int z_lo2, z_hi2;  // optional second range (both boundary regions of a slab in ONE launch); empty when z_hi2 <= z_lo2
+    BoxList boxes;  // the cells this launch produces
     const uint32_t* prev_slots;
     float max_update_norm;
 };
 
-template <int RPT, int WY, bool COMPACT>
+template <int RPT, int WY, bool COMPACT, bool TRANSPOSABLE>
 __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
     constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
-    constexpr int NXH = (2 * TY + 63) / 64;  // wave-tasks for the two x-halo columns
+    constexpr int NXH = (2 * TY + 63) / 64;  // wave-tasks for the two lane-halo columns
     constexpr int NTASK = 2 + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 t_psi[2][LH][LW + 2];  // {psi.xyz, F = (phi_n o psi).tsdf} -- psi.w is never read
 
@@ -291,21 +321,16 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<true>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, z_chunks(a.z_lo, a.z_hi, a.zc) + z_chunks(a.z_lo2, a.z_hi2, a.zc));
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY;
-    int zb, ze;
-    chunk_range(tid3.tz, a.zc, a.z_lo, a.z_hi, a.z_lo2, a.z_hi2, zb, ze);
-    const int x = x0 + lx, xc = min(x, d.x - 1);
-    const size_t plane = (size_t) d.x * d.y;
+    const TileGeom tg = tile_geom<TRANSPOSABLE, true>(a.boxes, d, TY);
+    const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
+    const bool tr = tg.tr;
+    const int u = u0 + lx, uc = min(u, tg.DU - 1);
+    const size_t plane = (size_t) d.x * d.y, su = (size_t) tg.su, sv = (size_t) tg.sv;
 
-    int yr[RPT];  // clamped global rows of this lane's strip
     size_t off[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        yr[r]  = min(y0 + wy * RPT + r, d.y - 1);
-        off[r] = (size_t) xc + (size_t) d.x * yr[r];
-    }
-    // halo tasks: task 0 = row above the tile, task 1 = row below, tasks 2.. = x-halo cells (col -1 / col TX)
+    for (int r = 0; r < RPT; ++r) off[r] = (size_t) uc * su + sv * (size_t) min(v0 + wy * RPT + r, tg.DV - 1);
+    // halo tasks: task 0 = row above the tile, task 1 = row below, tasks 2.. = lane-halo cells (col -1 / col TX)
     int h_lr[TPW], h_lc[TPW];  // LDS cell
     size_t h_off[TPW];
     bool h_on[TPW];
@@ -324,8 +349,8 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
         }
         h_lr[k] = lr;
         h_lc[k] = lc;
-        int gx = min(max(x0 - 1 + lc, 0), d.x - 1), gy = min(max(y0 - 1 + lr, 0), d.y - 1);
-        h_off[k] = (size_t) gx + (size_t) d.x * gy;
+        int gu = min(max(u0 - 1 + lc, 0), tg.DU - 1), gv = min(max(v0 - 1 + lr, 0), tg.DV - 1);
+        h_off[k] = (size_t) gu * su + (size_t) gv * sv;
     }
 
     // z register pipeline: m = z-1, c = z, n = z+1 (clamped loads; boundary rules applied at use)
@@ -351,6 +376,7 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
     }
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
 
+    const bool ulo = (u == 0), uhi = (u == tg.DU - 1);
     for (int z = zb; z < ze; ++z) {
         const int buf = (z - zb) & 1;
         // stage plane z
@@ -386,47 +412,50 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
         __syncthreads();
 
         const bool zlo = (z == 0), zhi = (z == d.z - 1);
-        const bool xlo = (x == 0), xhi = (x == d.x - 1);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int y = y0 + wy * RPT + r;
+            const int v  = v0 + wy * RPT + r;
             const int lr = wy * RPT + r + 1;
-            const bool ylo = (y == 0), yhi = (y == d.y - 1);
-            // raw neighbours
-            float4 pxp = t_psi[buf][lr][lx + 2], pxm = t_psi[buf][lr][lx];
-            float fxp = pxp.w, fxm = pxm.w;
-            float4 pyp, pym;
-            float fyp, fym;
-            if (r + 1 < RPT) { pyp = pc[r + 1 < RPT ? r + 1 : r]; fyp = fc[r + 1 < RPT ? r + 1 : r]; }
-            else { pyp = t_psi[buf][lr + 1][lx + 1]; fyp = pyp.w; }
-            if (r > 0) { pym = pc[r > 0 ? r - 1 : r]; fym = fc[r > 0 ? r - 1 : r]; }
-            else { pym = t_psi[buf][lr - 1][lx + 1]; fym = pym.w; }
+            const bool vlo = (v == 0), vhi = (v == tg.DV - 1);
+            // raw neighbours along the lane axis (l*) and the row axis (r*)
+            float4 plp = t_psi[buf][lr][lx + 2], plm = t_psi[buf][lr][lx];
+            float flp = plp.w, flm = plm.w;
+            float4 prp, prm;
+            float frp, frm;
+            if (r + 1 < RPT) { prp = pc[r + 1 < RPT ? r + 1 : r]; frp = fc[r + 1 < RPT ? r + 1 : r]; }
+            else { prp = t_psi[buf][lr + 1][lx + 1]; frp = prp.w; }
+            if (r > 0) { prm = pc[r > 0 ? r - 1 : r]; frm = fc[r > 0 ? r - 1 : r]; }
+            else { prm = t_psi[buf][lr - 1][lx + 1]; frm = prm.w; }
             float4 pzp = pn[r], pzm = pm[r];
             float fzp = fn[r], fzm = fm[r];
             const float4 c = pc[r];
             // TsdfDifferentiator boundary rule (vector_fields.cu:165-191): mirror the missing neighbour
-            float gx1 = xhi ? fxm : fxp, gx2 = xlo ? fxp : fxm;
-            float gy1 = yhi ? fym : fyp, gy2 = ylo ? fyp : fym;
+            float gl1 = uhi ? flm : flp, gl2 = ulo ? flp : flm;
+            float gr1 = vhi ? frm : frp, gr2 = vlo ? frp : frm;
             float gz1 = zhi ? fzm : fzp, gz2 = zlo ? fzp : fzm;
-            float4 g = f4((gx1 - gx2) / 2.f, (gy1 - gy2) / 2.f, (gz1 - gz2) / 2.f);
+            const float gl = (gl1 - gl2) / 2.f, gr = (gr1 - gr2) / 2.f;
+            float4 g = f4(tr ? gr : gl, tr ? gl : gr, (gz1 - gz2) / 2.f);
             // SecondOrderDifferentiator boundary rule (vector_fields.cu:299-331): both neighbours <- centre
-            if (xlo || xhi) { pxp = c; pxm = c; }
-            if (ylo || yhi) { pyp = c; pym = c; }
+            if (ulo || uhi) { plp = c; plm = c; }
+            if (vlo || vhi) { prp = c; prm = c; }
             if (zlo || zhi) { pzp = c; pzm = c; }
-            float4 v = mul4(c, -6.f);
-            v = add4(v, pxp);
-            v = add4(v, pxm);
-            v = add4(v, pyp);
-            v = add4(v, pym);
-            v = add4(v, pzp);
-            v = add4(v, pzm);
-            float4 L = mul4(v, -1.f);
+            // the reference adds x+, x-, y+, y-, z+, z- in that order: a transposed box swaps the roles of lanes and rows
+            const float4 pxp = tr ? prp : plp, pxm = tr ? prm : plm, pyp = tr ? plp : prp, pym = tr ? plm : prm;
+            float4 vv = mul4(c, -6.f);
+            vv = add4(vv, pxp);
+            vv = add4(vv, pxm);
+            vv = add4(vv, pyp);
+            vv = add4(vv, pym);
+            vv = add4(vv, pzp);
+            vv = add4(vv, pzm);
+            float4 L = mul4(vv, -1.f);
             // calculate_potential_gradient_kernel (solver.cu:28-31)
             float diff = fc[r] - bg[r];
             float4 o   = add4(mul4(g, diff), mul4(L, a.w_reg));
-            if (x < d.x && y < d.y) {
-                if (SOBFU_NT >= 4) stv_nt<COMPACT>(a.nU, zcur + (size_t) x + (size_t) d.x * y, o);
-                else stv<COMPACT>(a.nU, zcur + (size_t) x + (size_t) d.x * y, o);
+            if (u < tg.u_hi && v < tg.v_hi) {
+                const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
+                if (SOBFU_NT >= 4) stv_nt<COMPACT>(a.nU, i, o);
+                else stv<COMPACT>(a.nU, i, o);
             }
         }
         // shift the z pipeline
@@ -451,15 +480,13 @@ struct PassBArgs {
     Dims d;
     Taps S;
     float alpha;
-    int zc;
-    int z_lo, z_hi;  // planes produced by this launch
-    int z_lo2, z_hi2;  // optional second range (see PassAArgs)
+    BoxList boxes;  // the cells this launch produces
     const uint32_t* prev_slots;
     float max_update_norm;
-    // multi-GPU slab tiles: the fields are local slabs (d) that carry halo planes, phi_n is the whole volume (pd);
-    // only planes [own_lo, own_hi) are owned by this rank and enter the max-norm.  Single GPU: pd == d, [0, d.z).
+    // multi-GPU tiles: the fields are local arrays (d) that carry halo cells, phi_n is the whole volume (pd); only the
+    // cells of `own` belong to this rank and enter the max-norm.  Single GPU: pd == d, own = everything.
     Dims pd;
-    int own_lo, own_hi;
+    int own[6];     // x0, x1, y0, y1, z0, z1
     int prev_rows;  // rows the gate looks at (see solver_converged)
     void* psi_out;  // where the updated psi goes: == psi (in place) or the other half of a ping-pong pair (native tiled loop)
 };
@@ -467,10 +494,10 @@ struct PassBArgs {
 #ifndef SOBFU_MINW_B
 #define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
 #endif
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT>
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool TRANSPOSABLE>
 __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
-    constexpr int NXH = (2 * R * TY + 63) / 64;  // wave-tasks for the 2R x-halo columns
+    constexpr int NXH = (2 * R * TY + 63) / 64;  // wave-tasks for the 2R lane-halo columns
     constexpr int NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 tile[2][LH][LW + 2];
     __shared__ uint32_t s_max[WY];
@@ -479,18 +506,24 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileId tid3 = tile_of_block<SOBFU_SWIZZLE_B>((d.x + TX - 1) / TX, (d.y + TY - 1) / TY, z_chunks(a.z_lo, a.z_hi, a.zc) + z_chunks(a.z_lo2, a.z_hi2, a.zc));
-    const int x0 = tid3.tx * TX, y0 = tid3.ty * TY;
-    int zb, ze;
-    chunk_range(tid3.tz, a.zc, a.z_lo, a.z_hi, a.z_lo2, a.z_hi2, zb, ze);
-    const int x = x0 + lx, xc = min(x, d.x - 1);
-    const size_t plane = (size_t) d.x * d.y;
+    const TileGeom tg = tile_geom<TRANSPOSABLE, SOBFU_SWIZZLE_B>(a.boxes, d, TY);
+    const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
+    const int u = u0 + lx, uc = min(u, tg.DU - 1);
+    const size_t plane = (size_t) d.x * d.y, su = (size_t) tg.su, sv = (size_t) tg.sv;
 
     size_t off[RPT];
+    bool mine[RPT];  // the cell is stored by this launch / belongs to this rank (x, y part of the test)
+    bool owned[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) off[r] = (size_t) xc + (size_t) d.x * min(y0 + wy * RPT + r, d.y - 1);
+    for (int r = 0; r < RPT; ++r) {
+        const int v = v0 + wy * RPT + r;
+        off[r]      = (size_t) uc * su + sv * (size_t) min(v, tg.DV - 1);
+        mine[r]     = u < tg.u_hi && v < tg.v_hi;
+        const int x = tg.tr ? v : u, y = tg.tr ? u : v;
+        owned[r]    = x >= a.own[0] && x < a.own[1] && y >= a.own[2] && y < a.own[3];
+    }
 
-    // halo tasks: 0..R-1 rows above, R..2R-1 rows below, then x-halo cells (2R per tile row)
+    // halo tasks: 0..R-1 rows above, R..2R-1 rows below, then lane-halo cells (2R per tile row)
     int h_lr[TPW], h_lc[TPW];
     size_t h_off[TPW];
     bool h_on[TPW];
@@ -510,8 +543,8 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         }
         h_lr[k] = lr;
         h_lc[k] = lc;
-        int gx = min(max(x0 - R + lc, 0), d.x - 1), gy = min(max(y0 - R + lr, 0), d.y - 1);
-        h_off[k] = (size_t) gx + (size_t) d.x * gy;
+        int gu = min(max(u0 - R + lc, 0), tg.DU - 1), gv = min(max(v0 - R + lr, 0), tg.DV - 1);
+        h_off[k] = (size_t) gu * su + (size_t) gv * sv;
     }
 
     // z register pipeline q[r][0..6] = planes clamp(z-3 .. z+3)  (clamp-to-edge, solver.cu:396-424)
@@ -551,7 +584,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         }
         __syncthreads();
 
-        // y taps outside this lane's strip
+        // row-axis taps outside this lane's strip
         float4 yt[R], yb[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -560,22 +593,23 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int y = y0 + wy * RPT + r;
-            float sxx = 0.f, sxy = 0.f, sxz = 0.f, syx = 0.f, syy = 0.f, syz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
+            // the lane-axis sum (l*) and the row-axis sum (r*) are the x and y convolutions, or y and x in a transposed box:
+            // (Sx + Sy) is commutative, so the result is the same either way
+            float slx = 0.f, sly = 0.f, slz = 0.f, srx = 0.f, sry = 0.f, srz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
 #pragma unroll
             for (int j = -R; j <= R; ++j) {
                 const float s = a.S.s[R - j];
-                float4 vx = (j == 0) ? q[r][3] : tile[buf][wy * RPT + r + R][lx + R + j];
-                sxx += vx.x * s;
-                sxy += vx.y * s;
-                sxz += vx.z * s;
+                float4 vl = (j == 0) ? q[r][3] : tile[buf][wy * RPT + r + R][lx + R + j];
+                slx += vl.x * s;
+                sly += vl.y * s;
+                slz += vl.z * s;
                 const int rr = r + j;
-                float4 vy = rr < 0 ? yt[rr + R < 0 ? 0 : (rr + R > R - 1 ? R - 1 : rr + R)]
+                float4 vr = rr < 0 ? yt[rr + R < 0 ? 0 : (rr + R > R - 1 ? R - 1 : rr + R)]
                                    : (rr >= RPT ? yb[rr - RPT > R - 1 ? R - 1 : (rr - RPT < 0 ? 0 : rr - RPT)]
                                                 : q[rr < 0 ? 0 : (rr >= RPT ? RPT - 1 : rr)][3]);
-                syx += vy.x * s;
-                syy += vy.y * s;
-                syz += vy.z * s;
+                srx += vr.x * s;
+                sry += vr.y * s;
+                srz += vr.z * s;
                 float4 vz = q[r][3 + j];
                 szx += vz.x * s;
                 szy += vz.y * s;
@@ -583,19 +617,19 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             }
             // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)  -- explicit v_pk_mul/add pairing of the
             // taps was tried and is not faster (pass B 167 us either way), so the loop stays scalar
-            float tx = (sxx + syx) + szx, ty = (sxy + syy) + szy, tz = (sxz + syz) + szz;
+            float tx = (slx + srx) + szx, ty = (sly + sry) + szy, tz = (slz + srz) + szz;
             // update_psi_kernel (solver.cu:64-67)
-            float4 u = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
-            float4 p = pv[r];
-            p.x -= u.x;
-            p.y -= u.y;
-            p.z -= u.z;
-            if (x < d.x && y < d.y) {
-                if (z >= a.own_lo && z < a.own_hi) msq = fmaxf(msq, norm_sq4(u));
-                const size_t i = zcur + (size_t) x + (size_t) d.x * y;
+            float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
+            float4 p  = pv[r];
+            p.x -= uu.x;
+            p.y -= uu.y;
+            p.z -= uu.z;
+            if (mine[r]) {
+                if (owned[r] && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
+                const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
                 if (SOBFU_NT >= 1) stv_nt<COMPACT>(a.psi_out, i, p);
                 else stv<COMPACT>(a.psi_out, i, p);
-                if (WRITE_UPDATES) a.updates[i] = u;
+                if (WRITE_UPDATES) a.updates[i] = uu;
                 // apply_kernel (vector_fields.cu:95-98)
                 if (COMPACT && SOBFU_NT >= 1) __builtin_nontemporal_store(interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z), (float*) a.pnp + i);
                 else if (COMPACT) ((float*) a.pnp)[i] = interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
@@ -680,6 +714,33 @@ __global__ void __launch_bounds__(256) compact_leave_kernel(const P3* __restrict
     pnp2[i] = interp_tsdf(pn2, d, p.x, p.y, p.z);
 }
 
+// --- halo messages of a 3-D tile ------------------------------------------------------------------------------------
+// A message is a box of cells of a 12-byte field, laid out x fastest in a contiguous buffer segment.  One launch packs (or
+// unpacks) all messages of an exchange: one thread per cell, the message found by a scan of <= 18 prefix entries.
+struct MsgBoxes {
+    int n;
+    int x0[kMaxMsgs], y0[kMaxMsgs], z0[kMaxMsgs], nx[kMaxMsgs], ny[kMaxMsgs];
+    unsigned first[kMaxMsgs + 1];  // first cell of message i in the buffer; first[n] = cells in all messages
+};
+template <bool PACK>
+__global__ void __launch_bounds__(256) msg_copy_kernel(float* __restrict__ field3, float* __restrict__ buf, Dims d, MsgBoxes m) {
+    const unsigned c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= m.first[m.n]) return;
+    int x0 = m.x0[0], y0 = m.y0[0], z0 = m.z0[0], nx = m.nx[0], ny = m.ny[0];
+    unsigned first = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxMsgs; ++k)
+        if (k < m.n && c >= m.first[k]) {
+            x0 = m.x0[k]; y0 = m.y0[k]; z0 = m.z0[k]; nx = m.nx[k]; ny = m.ny[k];
+            first = m.first[k];
+        }
+    const unsigned e = c - first;
+    const int ix = (int) (e % (unsigned) nx), iy = (int) ((e / (unsigned) nx) % (unsigned) ny), iz = (int) (e / ((unsigned) nx * (unsigned) ny));
+    const size_t i = vidx(d, x0 + ix, y0 + iy, z0 + iz);
+    if (PACK) stv<true>(buf, c, ldv<true>(field3, i));
+    else stv<true>(field3, i, ldv<true>(buf, c));
+}
+
 }  // namespace
 
 // Tile configuration of the fused passes (see DESIGN.md "Kernel tuning").
@@ -718,22 +779,84 @@ int pick_zc(int X, int Y, int nz, int ty, int capacity, int refill, const char* 
     return best_zc;
 }
 
+// Fills the launch geometry of a box list: z-chunk per box (cost model above, the chip's capacity shared between the boxes)
+// and the workgroup prefix.  Returns the number of workgroups.
+static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env) {
+    L.n = 0;
+    int live = 0;
+    for (int i = 0; i < n; ++i) live += (boxes[i].x1 > boxes[i].x0 && boxes[i].y1 > boxes[i].y0 && boxes[i].z1 > boxes[i].z0) ? 1 : 0;
+    int total = 0;
+    for (int i = 0; i < n && L.n < kMaxBoxes; ++i) {
+        const LaunchBox& s = boxes[i];
+        if (!(s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0)) continue;
+        Box& b = L.b[L.n];
+        b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
+        b.tr = s.tr ? 1 : 0;
+        const int eu = s.tr ? s.y1 - s.y0 : s.x1 - s.x0, ev = s.tr ? s.x1 - s.x0 : s.y1 - s.y0, nz = s.z1 - s.z0;
+        b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, std::max(capacity / live, 1), refill, env);
+        L.first[L.n] = total;
+        total += ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty) * ((nz + b.zc - 1) / b.zc);
+        ++L.n;
+    }
+    for (int k = L.n; k <= kMaxBoxes; ++k) L.first[k] = total;
+    return total;
+}
+
+int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const LaunchBox* boxes,
+                        int n, const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact) {
+    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, {}, prev_slots, max_update_norm};
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 4, 2, zc, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
+    if (groups == 0) return 0;
+    bool tr = false;
+    for (int i = 0; i < a.boxes.n; ++i) tr = tr || a.boxes.b[i].tr;
+    const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
+    if (tr) {  // only launches that hold a transposed box pay for the lane / row role selects
+        if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, true>), grid, block, 0, stream, a);
+    } else {
+        if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, false>), grid, block, 0, stream, a);
+    }
+    return (int) hipGetLastError();
+}
+
+int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots, const float taps[7],
+                        float alpha, int X, int Y, int Z, int pX, int pY, int pZ, const int own[6], const LaunchBox* boxes, int n,
+                        const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, float* psi_out, int prev_rows) {
+    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, {}, prev_slots, max_update_norm, {pX, pY, pZ},
+                {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi};
+    for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 3, 6, zc, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
+    if (groups == 0) return 0;
+    bool tr = false;
+    for (int i = 0; i < a.boxes.n; ++i) tr = tr || a.boxes.b[i].tr;
+    const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
+#define SOBFU_LAUNCH_B(UPD, CMP, TRN) \
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, TRN>), grid, block, 0, stream, a)
+    if (tr) {
+        if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
+        else if (updates) SOBFU_LAUNCH_B(true, false, true);
+        else if (compact) SOBFU_LAUNCH_B(false, true, true);
+        else SOBFU_LAUNCH_B(false, false, true);
+    } else {
+        if (updates && compact) SOBFU_LAUNCH_B(true, true, false);
+        else if (updates) SOBFU_LAUNCH_B(true, false, false);
+        else if (compact) SOBFU_LAUNCH_B(false, true, false);
+        else SOBFU_LAUNCH_B(false, false, false);
+    }
+#undef SOBFU_LAUNCH_B
+    return (int) hipGetLastError();
+}
+
+// z-range forms (whole x-y planes of the array): the single-GPU solver and the z-slab loop
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,
                   const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, int z_lo, int z_hi,
                   int z_lo2, int z_hi2) {
-    constexpr int TY = SOBFU_RPT * SOBFU_WY;
     if (z_hi <= 0 && z_hi2 <= z_lo2) { z_lo = 0; z_hi = Z; }  // no range given: the whole grid
-    if (z_hi <= z_lo) { z_lo = z_lo2; z_hi = z_hi2; z_lo2 = z_hi2 = 0; }
-    if (z_hi <= z_lo) return 0;
-    const bool two = z_hi2 > z_lo2;
-    const int nz = std::max(z_hi - z_lo, two ? z_hi2 - z_lo2 : 0);  // the longer range sets the march length
-    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, (256 * 4) / (two ? 2 : 1), 2, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
-    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, zc, z_lo, z_hi, z_lo2, z_hi2, prev_slots, max_update_norm};
-    const int nchunks = (z_hi - z_lo + zc - 1) / zc + (two ? (z_hi2 - z_lo2 + zc - 1) / zc : 0);
-    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * nchunks);
-    if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
-    else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, dim3(TX, SOBFU_WY), 0, stream, a);
-    return (int) hipGetLastError();
+    const LaunchBox b[2] = {{0, X, 0, Y, z_lo, z_hi, false}, {0, X, 0, Y, z_lo2, z_hi2, false}};
+    return launch_pass_a_boxes(pnp, pg, psi, nU, w_reg, X, Y, Z, b, 2, prev_slots, max_update_norm, zc, stream, compact);
 }
 
 int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots,
@@ -741,25 +864,11 @@ int launch_pass_b(const float* nU, float* psi, const float* phi_n, float* pnp, f
                   float max_update_norm, int zc, hipStream_t stream, int phi_Z, int own_lo, int own_hi, bool compact, int z_lo,
                   int z_hi, int z_lo2, int z_hi2, float* psi_out, int prev_rows) {
     if (phi_Z <= 0) { phi_Z = Z; own_lo = 0; own_hi = Z; }
-    constexpr int TY = SOBFU_RPT * SOBFU_WY;
     if (z_hi <= 0 && z_hi2 <= z_lo2) { z_lo = 0; z_hi = Z; }  // no range given: the whole grid
-    if (z_hi <= z_lo) { z_lo = z_lo2; z_hi = z_hi2; z_lo2 = z_hi2 = 0; }
-    if (z_hi <= z_lo) return 0;
-    const bool two = z_hi2 > z_lo2;
-    const int nz = std::max(z_hi - z_lo, two ? z_hi2 - z_lo2 : 0);
-    if (zc <= 0) zc = pick_zc(X, Y, nz, TY, (256 * 3) / (two ? 2 : 1), 6, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
-    PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, zc, z_lo, z_hi, z_lo2, z_hi2, prev_slots, max_update_norm, {X, Y, phi_Z}, own_lo, own_hi, prev_rows, psi_out ? psi_out : psi};
-    for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
-    const int nchunks = (z_hi - z_lo + zc - 1) / zc + (two ? (z_hi2 - z_lo2 + zc - 1) / zc : 0);
-    dim3 grid(((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * nchunks);
-#define SOBFU_LAUNCH_B(UPD, CMP) \
-    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP>), grid, dim3(TX, SOBFU_WY), 0, stream, a)
-    if (updates && compact) SOBFU_LAUNCH_B(true, true);
-    else if (updates) SOBFU_LAUNCH_B(true, false);
-    else if (compact) SOBFU_LAUNCH_B(false, true);
-    else SOBFU_LAUNCH_B(false, false);
-#undef SOBFU_LAUNCH_B
-    return (int) hipGetLastError();
+    const LaunchBox b[2] = {{0, X, 0, Y, z_lo, z_hi, false}, {0, X, 0, Y, z_lo2, z_hi2, false}};
+    const int own[6] = {0, X, 0, Y, own_lo, own_hi};
+    return launch_pass_b_boxes(nU, psi, phi_n, pnp, updates, slots, taps, alpha, X, Y, Z, X, Y, phi_Z, own, b, 2, prev_slots, max_update_norm, zc,
+                               stream, compact, psi_out, prev_rows);
 }
 
 #define SOBFU_LIN(N) dim3((unsigned) (((N) + 255) / 256)), dim3(256), 0, stream
@@ -775,9 +884,31 @@ int launch_extract_tsdf(const float* src2, float* dst1, size_t N, hipStream_t st
     hipLaunchKernelGGL(extract_tsdf_kernel, SOBFU_LIN(N), (const float2*) src2, dst1, N);
     return (int) hipGetLastError();
 }
-int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z) {
+int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, int X, int Y, int Z, hipStream_t stream, int phi_Z, int phi_X,
+                           int phi_Y) {
     hipLaunchKernelGGL(apply_tsdf_only_kernel, voxel_grid(X, Y, Z), voxel_block(), 0, stream, phi1, out1, (const P3*) psi3, Dims{X, Y, Z},
-                       Dims{X, Y, phi_Z > 0 ? phi_Z : Z});
+                       Dims{phi_X > 0 ? phi_X : X, phi_Y > 0 ? phi_Y : Y, phi_Z > 0 ? phi_Z : Z});
+    return (int) hipGetLastError();
+}
+// n boxes of 6 ints (x0, x1, y0, y1, z0, z1) of a 12-byte (Lx, Ly, Lz) field <-> consecutive buffer segments (x fastest)
+int launch_msg_copy(bool pack, float* field3, float* buf, int Lx, int Ly, int Lz, const int* boxes, int n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (n > kMaxMsgs) return SOBFU_E_BADARG;
+    MsgBoxes m{};
+    m.n = n;
+    unsigned total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int* b = boxes + 6 * i;
+        if (!(b[0] >= 0 && b[1] > b[0] && b[1] <= Lx && b[2] >= 0 && b[3] > b[2] && b[3] <= Ly && b[4] >= 0 && b[5] > b[4] && b[5] <= Lz)) return SOBFU_E_BADARG;
+        m.x0[i] = b[0]; m.y0[i] = b[2]; m.z0[i] = b[4];
+        m.nx[i] = b[1] - b[0]; m.ny[i] = b[3] - b[2];
+        m.first[i] = total;
+        total += (unsigned) (b[1] - b[0]) * (unsigned) (b[3] - b[2]) * (unsigned) (b[5] - b[4]);
+    }
+    for (int k = n; k <= kMaxMsgs; ++k) m.first[k] = total;
+    const dim3 grid((total + 255u) / 256u), block(256);
+    if (pack) hipLaunchKernelGGL(msg_copy_kernel<true>, grid, block, 0, stream, field3, buf, Dims{Lx, Ly, Lz}, m);
+    else hipLaunchKernelGGL(msg_copy_kernel<false>, grid, block, 0, stream, field3, buf, Dims{Lx, Ly, Lz}, m);
     return (int) hipGetLastError();
 }
 #undef SOBFU_LIN
@@ -882,6 +1013,49 @@ int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, con
     if ((size_t) X * Y * Lz > (size_t) 0x7fffffff || (size_t) X * Y * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
     return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Lz,
                                     d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, compact != 0, z_begin, z_end);
+}
+
+// ---- 3-D tiles (sobfu_hip_tile3_*): local arrays (Lx, Ly, Lz) with halo cells on every side that faces a neighbour ----
+static bool box_ok(const int b[6], int Lx, int Ly, int Lz) {
+    return b[0] >= 0 && b[0] <= b[1] && b[1] <= Lx && b[2] >= 0 && b[2] <= b[3] && b[3] <= Ly && b[4] >= 0 && b[4] <= b[5] && b[5] <= Lz;
+}
+
+int sobfu_hip_tile3_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U, float w_reg,
+                                       int Lx, int Ly, int Lz, const int box[6], int transposed, const uint32_t* d_prev_slots,
+                                       float max_update_norm, int compact, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && Lx > 1 && Ly > 1 && Lz > 1 && box && box_ok(box, Lx, Ly, Lz));
+    if ((size_t) Lx * Ly * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
+    const sobfu_hip::LaunchBox b{box[0], box[1], box[2], box[3], box[4], box[5], transposed != 0};
+    return sobfu_hip::launch_pass_a_boxes(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, Lx, Ly, Lz, &b, 1, d_prev_slots, max_update_norm, 0,
+                                          (hipStream_t) stream, compact != 0);
+}
+
+int sobfu_hip_tile3_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi, float* d_updates,
+                                        uint32_t* d_max_sq_slots, const float taps[7], float alpha, int Lx, int Ly, int Lz, int Xg, int Yg,
+                                        int Zg, const int own[6], const int box[6], int transposed, const uint32_t* d_prev_slots,
+                                        float max_update_norm, int compact, void* stream) {
+    SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 &&
+                     Zg > 0 && own && box && box_ok(own, Lx, Ly, Lz) && box_ok(box, Lx, Ly, Lz));
+    if ((size_t) Lx * Ly * Lz > (size_t) 0x7fffffff || (size_t) Xg * Yg * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
+    const sobfu_hip::LaunchBox b{box[0], box[1], box[2], box[3], box[4], box[5], transposed != 0};
+    return sobfu_hip::launch_pass_b_boxes(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, Lx, Ly, Lz, Xg, Yg, Zg,
+                                          own, &b, 1, d_prev_slots, max_update_norm, 0, (hipStream_t) stream, compact != 0);
+}
+
+int sobfu_hip_tile3_apply_tsdf_only(const float* d_phi1, int Xg, int Yg, int Zg, float* d_out1, const float* d_psi3, int Lx, int Ly, int Lz,
+                                    void* stream) {
+    SOBFU_CHECK_ARGS(d_phi1 && d_out1 && d_psi3 && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0);
+    return sobfu_hip::launch_apply_tsdf_only(d_phi1, d_out1, d_psi3, Lx, Ly, Lz, (hipStream_t) stream, Zg, Xg, Yg);
+}
+
+int sobfu_hip_tile3_pack(const float* d_field3, int Lx, int Ly, int Lz, float* d_buf, const int* boxes, int n_boxes, void* stream) {
+    SOBFU_CHECK_ARGS(d_field3 && d_buf && boxes && n_boxes >= 0 && Lx > 0 && Ly > 0 && Lz > 0);
+    return sobfu_hip::launch_msg_copy(true, const_cast<float*>(d_field3), d_buf, Lx, Ly, Lz, boxes, n_boxes, (hipStream_t) stream);
+}
+
+int sobfu_hip_tile3_unpack(float* d_field3, int Lx, int Ly, int Lz, const float* d_buf, const int* boxes, int n_boxes, void* stream) {
+    SOBFU_CHECK_ARGS(d_field3 && d_buf && boxes && n_boxes >= 0 && Lx > 0 && Ly > 0 && Lz > 0);
+    return sobfu_hip::launch_msg_copy(false, d_field3, const_cast<float*>(d_buf), Lx, Ly, Lz, boxes, n_boxes, (hipStream_t) stream);
 }
 
 }  // extern "C"

@@ -1,8 +1,16 @@
-// Native multi-GPU solver loop: one rank (process, GPU) per z-slab, halo exchange by RCCL send/recv over xGMI issued
-// from C++ on a dedicated communication stream and overlapped with the interior compute.
+// Native multi-GPU solver loop: one rank (process, GPU) per volume TILE -- a Px x Py x Pz grid of tiles (2 x 2 x 2 on 8 GPUs,
+// BASELINE config 4; 1 x 1 x N = z-slabs), halo exchange by RCCL send/recv over xGMI issued from C++.
 //
-// Same decomposition and schedule as sobfu_amd/tiled.py (which documents the invariants), without a Python round trip
-// per iteration:
+// Every field of a rank is a local array = owned cells + 4 halo cells on each side that faces a neighbour.  One iteration needs
+// ONE exchange (Option B): pass A produces nabla_U on the owned cells, the 4-cell faces (and the 4 x 4 edge strips:
+// the one-cell shells below read nabla_U diagonally across a tile edge, never across a corner) travel to the 3 face + 3 edge
+// neighbours of a 2 x 2 x 2 tile in one grouped send/recv, and pass B then updates psi / phi_n o psi on owned +- 1 along each axis
+// -- the radius-3 convolution is exact there, so the values the next pass A reads are never exchanged.  phi_n is replicated.
+// Messages of a 3-D tile are packed into / scattered from contiguous buffers by one small kernel each; z-slabs exchange whole
+// planes in place.  The x shell (one column) runs as a TRANSPOSED box of the pass-B launch (lanes along y).
+//
+// Schedules: serial (pass A, exchange, pass B in line) for any tile grid; for z-slabs also the overlapped ones of
+// sobfu_amd/tiled.py (which documents the invariants), without a Python round trip per iteration:
 //     A_bnd (planes next to an interior face)  ->  event  ->  [comm stream] group{send, recv} of 4 nabla_U planes / face
 //     A_int, B_int (planes whose +-3 taps are owned)            ... run while the exchange is in flight
 //     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)
@@ -78,7 +86,11 @@ float host_sqrt_rd(float s) {
 
 struct sobfu_hip_tiled {
     int X, Y, Z, world, rank;
-    int z0, z1, lo, hi, Lz, own_lo, own_hi, zbase;
+    // tile grid P, this rank's tile coordinates c; per axis: owned global range [g0, g1), halo cells lo / hi, local extent L,
+    // owned local range [o0, o1), global coordinate `base` of local cell 0
+    int P[3], c[3], g0[3], g1[3], lo[3], hi[3], L[3], o0[3], o1[3], base[3];
+    bool slab;  // Px == Py == 1: halos are whole planes and travel in place (no pack / unpack)
+    int z0, z1, Lz, own_lo, own_hi, zbase;  // the z entries again, under the names the slab schedules use
     sobfu_hip_solver_params p;
     float taps[7];
     ncclComm_t comm = nullptr;
@@ -91,13 +103,25 @@ struct sobfu_hip_tiled {
     // behind (or in front of) a halo exchange on the main communicator
     ncclComm_t comm2 = nullptr;
     hipStream_t red_stream = nullptr;
-    // compact slab state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
+    // compact tile state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
     float *nU = nullptr, *c_psi = nullptr, *c_psi2 = nullptr, *c_f = nullptr, *c_f2 = nullptr, *c_g = nullptr, *c_n = nullptr;
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
+    // halo messages of a 3-D tile: one per face / edge neighbour, packed one after the other (same offsets on both sides)
+    std::vector<sobfu_hip_tiled_msg> msgs;
+    std::vector<int> sboxes, rboxes;  // 6 ints per message: the cells sent / the halo cells received
+    float *sendbuf = nullptr, *recvbuf = nullptr;
     int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
+    struct Session {  // an open solve (tiled_begin .. tiled_end)
+        bool active = false;
+        const float* pn = nullptr;
+        float *pnp = nullptr, *psi = nullptr;
+        int cap = 0, launched = 0;
+        bool red_issued[2] = {false, false};
+        int red_upto = 0;  // rows 1 .. red_upto have been (or are being) all-reduced
+    } q;
 };
 
 extern "C" {
@@ -145,6 +169,8 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     for (float* q : {t->nU, t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
         if (q) (void) hipFree(q);
     if (t->slots) (void) hipFree(t->slots);
+    if (t->sendbuf) (void) hipFree(t->sendbuf);
+    if (t->recvbuf) (void) hipFree(t->recvbuf);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
     for (hipEvent_t e : {t->ev_red[0], t->ev_red[1], t->ev_row})
@@ -157,31 +183,77 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     return 0;
 }
 
-int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
-                           const sobfu_hip_solver_params* params) {
-    SOBFU_CHECK_ARGS(out && params && unique_id && X > 1 && Y > 1 && Z > 1 && world >= 1 && rank >= 0 && rank < world);
-    bool dry = true;  // an all-zero id asks for a communicator-less handle: slab layout, kernels and stream choreography of
-    for (int i = 0; i < 128; ++i) dry = dry && unique_id[i] == 0;  // (world, rank); transport: sobfu_hip_tiled_set_transport
+int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, int Py, int Pz, int rank, const char unique_id[128],
+                            const sobfu_hip_solver_params* params) {
+    SOBFU_CHECK_ARGS(out && params && unique_id && X > 1 && Y > 1 && Z > 1 && Px >= 1 && Py >= 1 && Pz >= 1 && rank >= 0 &&
+                     rank < Px * Py * Pz);
+    bool dry = true;  // an all-zero id asks for a communicator-less handle: tile layout, kernels and stream choreography of
+    for (int i = 0; i < 128; ++i) dry = dry && unique_id[i] == 0;  // (grid, rank); transport: sobfu_hip_tiled_set_transport
     if (!dry && !g_rccl.ok()) return SOBFU_E_RCCL;
-    if (Z < world * kHalo || params->s < 7) return SOBFU_E_UNSUPPORTED;
+    if (params->s < 7) return SOBFU_E_UNSUPPORTED;
     auto* t = new sobfu_hip_tiled();
-    t->X = X; t->Y = Y; t->Z = Z; t->world = world; t->rank = rank;
-    const int base = Z / world, rem = Z % world;
-    t->z0 = rank * base + (rank < rem ? rank : rem);
-    t->z1 = t->z0 + base + (rank < rem ? 1 : 0);
-    t->lo = rank > 0 ? kHalo : 0;
-    t->hi = rank < world - 1 ? kHalo : 0;
-    t->Lz = (t->z1 - t->z0) + t->lo + t->hi;
-    t->own_lo = t->lo;
-    t->own_hi = t->lo + (t->z1 - t->z0);
-    t->zbase  = t->z0 - t->lo;
-    t->NL = (size_t) X * Y * t->Lz;
+    t->X = X; t->Y = Y; t->Z = Z; t->world = Px * Py * Pz; t->rank = rank;
+    const int dims[3] = {X, Y, Z}, P[3] = {Px, Py, Pz};
+    const int c[3] = {rank % Px, (rank / Px) % Py, rank / (Px * Py)};  // x fastest
+    int rc = 0;
+    for (int a = 0; a < 3; ++a) {
+        t->P[a] = P[a];
+        t->c[a] = c[a];
+        const int base = dims[a] / P[a], rem = dims[a] % P[a];  // the cells of an axis are split as evenly as possible
+        t->g0[a]   = c[a] * base + std::min(c[a], rem);
+        t->g1[a]   = t->g0[a] + base + (c[a] < rem ? 1 : 0);
+        t->lo[a]   = c[a] > 0 ? kHalo : 0;
+        t->hi[a]   = c[a] < P[a] - 1 ? kHalo : 0;
+        t->L[a]    = (t->g1[a] - t->g0[a]) + t->lo[a] + t->hi[a];
+        t->o0[a]   = t->lo[a];
+        t->o1[a]   = t->lo[a] + (t->g1[a] - t->g0[a]);
+        t->base[a] = t->g0[a] - t->lo[a];
+        if (P[a] > 1 && base < kHalo) rc = SOBFU_E_UNSUPPORTED;  // a tile must own at least a halo's worth of cells per split axis
+    }
+    t->slab = Px == 1 && Py == 1;
+    t->z0 = t->g0[2]; t->z1 = t->g1[2]; t->Lz = t->L[2]; t->own_lo = t->o0[2]; t->own_hi = t->o1[2]; t->zbase = t->base[2];
+    t->NL = (size_t) t->L[0] * t->L[1] * t->L[2];
     t->NF = (size_t) X * Y * Z;
     t->p  = *params;
     float h[16];
-    int rc = sobfu_hip_sobolev_filter(params->s, params->lambda, h);
+    if (rc == 0) rc = sobfu_hip_sobolev_filter(params->s, params->lambda, h);
     for (int i = 0; i < 7; ++i) t->taps[i] = h[i];
-    if (rc == 0 && (t->z1 - t->z0) < kHalo && world > 1) rc = SOBFU_E_UNSUPPORTED;
+    if (rc == 0 && !t->slab) {
+        // halo messages: every face neighbour (one non-zero offset) and edge neighbour (two); corners are never read.  Along an
+        // axis with offset +1 the 4 owned cells next to that face are sent and the 4 halo cells beyond it received; along an
+        // axis with offset 0 the owned range (the same on both sides, as the neighbour shares this coordinate).
+        size_t off = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int dl[3] = {dx, dy, dz};
+                    const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
+                    if (nnz < 1 || nnz > 2) continue;
+                    bool inside = true;
+                    for (int a = 0; a < 3; ++a) inside = inside && c[a] + dl[a] >= 0 && c[a] + dl[a] < P[a];
+                    if (!inside) continue;
+                    int sb[6], rb[6];
+                    size_t cells = 1;
+                    for (int a = 0; a < 3; ++a) {
+                        if (dl[a] > 0) { sb[2 * a] = t->o1[a] - kHalo; sb[2 * a + 1] = t->o1[a]; rb[2 * a] = t->o1[a]; rb[2 * a + 1] = t->o1[a] + kHalo; }
+                        else if (dl[a] < 0) { sb[2 * a] = t->o0[a]; sb[2 * a + 1] = t->o0[a] + kHalo; rb[2 * a] = t->o0[a] - kHalo; rb[2 * a + 1] = t->o0[a]; }
+                        else { sb[2 * a] = rb[2 * a] = t->o0[a]; sb[2 * a + 1] = rb[2 * a + 1] = t->o1[a]; }
+                        cells *= (size_t) (sb[2 * a + 1] - sb[2 * a]);
+                    }
+                    sobfu_hip_tiled_msg m;
+                    m.peer     = (c[0] + dx) + Px * ((c[1] + dy) + Py * (c[2] + dz));
+                    m.send_off = m.recv_off = off;
+                    m.count    = cells * 3;
+                    off += m.count;
+                    t->msgs.push_back(m);
+                    t->sboxes.insert(t->sboxes.end(), sb, sb + 6);
+                    t->rboxes.insert(t->rboxes.end(), rb, rb + 6);
+                }
+        if (off > 0) {
+            rc = (int) hipMalloc((void**) &t->sendbuf, off * sizeof(float));
+            if (rc == 0) rc = (int) hipMalloc((void**) &t->recvbuf, off * sizeof(float));
+        }
+    }
     if (rc == 0) rc = (int) hipMalloc((void**) &t->nU, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f, t->NL * 4);
@@ -189,6 +261,7 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
+    if (rc == 0) rc = (int) hipMemsetAsync(t->nU, 0, t->NL * 12, nullptr);  // halo cells no message fills (tile corners) stay finite
     if (rc == 0) {  // max-norm slot rows for 4096 iterations up front: a solve never reallocates inside a timed region
         rc = (int) hipMalloc((void**) &t->slots, (size_t) (4096 + 1) * kSlots * 4);
         if (rc == 0) t->slots_iters = 4096;
@@ -208,7 +281,7 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     if (rc == 0 && !dry) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id, 128);
-        ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
+        ncclResult_t r = g_rccl.CommInitRank(&t->comm, t->world, id, rank);
         if (r != ncclSuccess) {
             std::fprintf(stderr, "sobfu_hip: ncclCommInitRank failed: %s\n", g_rccl.GetErrorString(r));
             rc = SOBFU_E_RCCL;
@@ -220,6 +293,11 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
     }
     *out = t;
     return 0;
+}
+
+int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
+                           const sobfu_hip_solver_params* params) {
+    return sobfu_hip_tiled_create3(out, X, Y, Z, 1, 1, world, rank, unique_id, params);  // z-slabs
 }
 
 int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_fn exchange_fn, sobfu_hip_tiled_allreduce_fn allreduce_fn,
@@ -252,28 +330,62 @@ int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, 
     SOBFU_CHECK_ARGS(t);
     if (z0) *z0 = t->z0;
     if (z1) *z1 = t->z1;
-    if (lo) *lo = t->lo;
-    if (hi) *hi = t->hi;
+    if (lo) *lo = t->lo[2];
+    if (hi) *hi = t->hi[2];
     if (Lz) *Lz = t->Lz;
     if (zbase) *zbase = t->zbase;
     return 0;
 }
 
-// One grouped send/recv of `planes` owned planes per interior face of a 12-byte field (floats: 3 per voxel).
-static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t stream) {
-    const size_t plane_f = (size_t) t->X * t->Y * 3, cnt = plane_f * planes;
-    if (!t->comm) return t->xfn ? t->xfn(t->tctx, t->rank, field3, planes, (void*) stream) : 0;  // user transport / dry handle
-    RCCL_TRY(g_rccl.GroupStart());
-    if (t->rank > 0) {
-        RCCL_TRY(g_rccl.Send(field3 + plane_f * t->own_lo, cnt, ncclFloat32, t->rank - 1, t->comm, stream));
-        RCCL_TRY(g_rccl.Recv(field3 + plane_f * (t->own_lo - planes), cnt, ncclFloat32, t->rank - 1, t->comm, stream));
+int sobfu_hip_tiled_layout3(const sobfu_hip_tiled* t, int out[24]) {
+    SOBFU_CHECK_ARGS(t && out);
+    for (int a = 0; a < 3; ++a) {
+        out[a] = t->P[a]; out[3 + a] = t->c[a]; out[6 + a] = t->g0[a]; out[9 + a] = t->g1[a]; out[12 + a] = t->lo[a];
+        out[15 + a] = t->hi[a]; out[18 + a] = t->L[a]; out[21 + a] = t->base[a];
     }
-    if (t->rank < t->world - 1) {
-        RCCL_TRY(g_rccl.Send(field3 + plane_f * (t->own_hi - planes), cnt, ncclFloat32, t->rank + 1, t->comm, stream));
-        RCCL_TRY(g_rccl.Recv(field3 + plane_f * t->own_hi, cnt, ncclFloat32, t->rank + 1, t->comm, stream));
+    return 0;
+}
+
+int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int* send_boxes, int* recv_boxes, int max_msgs) {
+    if (!t) return SOBFU_E_BADARG;
+    const int n = (int) t->msgs.size();
+    for (int i = 0; i < n && i < max_msgs; ++i) {
+        if (msgs) msgs[i] = t->msgs[i];
+        if (send_boxes) std::memcpy(send_boxes + 6 * i, t->sboxes.data() + 6 * i, 6 * sizeof(int));
+        if (recv_boxes) std::memcpy(recv_boxes + 6 * i, t->rboxes.data() + 6 * i, 6 * sizeof(int));
+    }
+    return n;  // number of messages of an exchange (0 for z-slabs, which exchange planes in place)
+}
+
+// One halo exchange of a 12-byte tile field.  z-slabs: `planes` owned planes per interior face travel in place (no copy on
+// either side).  3-D tiles: the faces / edge strips are packed into the send buffer, travel as one message per neighbour, and are
+// scattered into the halo cells -- all on `stream`.
+static int transfer(sobfu_hip_tiled* t, const float* d_send, float* d_recv, const sobfu_hip_tiled_msg* msgs, int n, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (!t->comm) return t->xfn ? t->xfn(t->tctx, t->rank, d_send, d_recv, msgs, n, (void*) stream) : 0;  // user transport / dry handle
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        RCCL_TRY(g_rccl.Send(d_send + msgs[i].send_off, msgs[i].count, ncclFloat32, msgs[i].peer, t->comm, stream));
+        RCCL_TRY(g_rccl.Recv(d_recv + msgs[i].recv_off, msgs[i].count, ncclFloat32, msgs[i].peer, t->comm, stream));
     }
     RCCL_TRY(g_rccl.GroupEnd());
     return 0;
+}
+
+static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t stream) {
+    if (t->slab) {
+        const size_t plane_f = (size_t) t->X * t->Y * 3, cnt = plane_f * planes;
+        sobfu_hip_tiled_msg m[2];
+        int n = 0;
+        if (t->rank > 0) m[n++] = {t->rank - 1, plane_f * t->own_lo, plane_f * (t->own_lo - planes), cnt};
+        if (t->rank < t->world - 1) m[n++] = {t->rank + 1, plane_f * (t->own_hi - planes), plane_f * t->own_hi, cnt};
+        return transfer(t, field3, field3, m, n, stream);
+    }
+    const int n = (int) t->msgs.size();
+    if (n == 0) return 0;
+    SOBFU_TRY(sobfu_hip::launch_msg_copy(true, field3, t->sendbuf, t->L[0], t->L[1], t->L[2], t->sboxes.data(), n, stream));
+    SOBFU_TRY(transfer(t, t->sendbuf, t->recvbuf, t->msgs.data(), n, stream));
+    return sobfu_hip::launch_msg_copy(false, field3, t->recvbuf, t->L[0], t->L[1], t->L[2], t->rboxes.data(), n, stream);
 }
 
 static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_t stream, bool own_comm = false) {
@@ -284,7 +396,7 @@ static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_
 
 // Debug / bring-up: exchange `planes` planes of a caller-provided 12-byte slab field exactly as the loop does.
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream) {
-    SOBFU_CHECK_ARGS(t && d_field3 && planes > 0 && planes <= kHalo);
+    SOBFU_CHECK_ARGS(t && d_field3 && planes > 0 && planes <= kHalo && (t->slab || planes == kHalo));
     return exchange(t, d_field3, planes, (hipStream_t) stream);
 }
 
@@ -305,9 +417,10 @@ int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_
     return 0;
 }
 
-// The gradient-descent loop (reference src/sobfu/cuda/solver.cu:106-193) on this rank's slab.  API-format arguments:
-// d_phi_global_local / d_phi_n_psi_local float2 (X, Y, Lz), d_phi_n_full float2 (X, Y, Z), d_psi_local float4 (X, Y, Lz)
-// whose owned +-1 planes are exact on entry (identity: sobfu_hip_tile_init_identity) and on exit.  Synchronises `stream`.
+// The gradient-descent loop (reference src/sobfu/cuda/solver.cu:106-193) on this rank's tile, in three pieces (begin / step / end;
+// sobfu_hip_tiled_iterate = all three).  API-format arguments: d_phi_global_local / d_phi_n_psi_local float2 (Lx, Ly, Lz),
+// d_phi_n_full float2 (X, Y, Z), d_psi_local float4 (Lx, Ly, Lz) whose owned cells and one-cell shells are exact on entry
+// (identity: sobfu_hip_tile3_init_identity) and on exit.
 //
 // Convergence without a stall: psi and F = (phi_n o psi).tsdf are PING-PONGED (iteration k reads buffer (k-1)&1 and writes
 // buffer k&1), and the device-side gate of iteration k looks at the max-norm row of iteration k-2.  When the threshold fires
@@ -316,40 +429,56 @@ int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_
 // global therefore has a whole iteration to complete and is issued on the comm stream behind the exchange: nothing in the
 // loop ever waits for a reduction that is still in flight (a same-iteration gate costs an exposed collective or a
 // stream round trip per iteration: 67 vs 55 us per iteration in the N = 8 compute-side timing).
-int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
-                            float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
-                            float* per_iter_max_norm, void* stream) {
-    SOBFU_CHECK_ARGS(t && d_phi_global_local && d_phi_n_full && d_phi_n_psi_local && d_psi_local && n_iters >= 0);
-    hipStream_t st = (hipStream_t) stream;
-    const int X = t->X, Y = t->Y, Z = t->Z, Lz = t->Lz;
-    const sobfu_hip_solver_params& p = t->p;
-    sobfu_hip_solver_report r{};
-    r.last_max_update_norm = r.last_max_update_index = r.last_e_data = r.last_e_reg = NAN;
+static int tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full, float* d_phi_n_psi_local,
+                       float* d_psi_local, int max_iters, hipStream_t st) {
+    sobfu_hip_tiled::Session& q = t->q;
+    if (q.active) return SOBFU_E_BADARG;
+    const int X = t->X, Y = t->Y, Z = t->Z, Lx = t->L[0], Ly = t->L[1], Lz = t->L[2];
     float* P[2] = {t->c_psi, t->c_psi2};
     float* F[2] = {t->c_f, t->c_f2};
-    // enter the compact format (includes the warp of solver.cu:106); both halves start equal so that planes no launch
-    // writes (beyond owned +-1) hold the caller's values whichever half the loop ends in
+    q = sobfu_hip_tiled::Session{};
+    q.pn = d_phi_n_full; q.pnp = d_phi_n_psi_local; q.psi = d_psi_local;
+    q.cap = max_iters;
+    // enter the compact format (includes the warp of solver.cu:106); both halves start equal so that cells no launch
+    // writes (beyond the one-cell shells) hold the caller's values whichever half the loop ends in
     SOBFU_TRY(sobfu_hip::launch_pack_vec(d_psi_local, P[0], t->NL, st));
     SOBFU_TRY(sobfu_hip::launch_extract_tsdf(d_phi_global_local, t->c_g, t->NL, st));
     SOBFU_TRY(sobfu_hip::launch_extract_tsdf(d_phi_n_full, t->c_n, t->NF, st));
-    SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(t->c_n, F[0], P[0], X, Y, Lz, st, Z));
+    SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(t->c_n, F[0], P[0], Lx, Ly, Lz, st, Z, X, Y));
     SOBFU_HIP_TRY(hipMemcpyAsync(P[1], P[0], t->NL * 12, hipMemcpyDeviceToDevice, st));
     SOBFU_HIP_TRY(hipMemcpyAsync(F[1], F[0], t->NL * 4, hipMemcpyDeviceToDevice, st));
-    if (n_iters > t->slots_iters) {
+    if (max_iters > t->slots_iters) {
         if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
         t->slots = nullptr;
-        SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (n_iters + 1) * kSlots * 4));
-        t->slots_iters = n_iters;
+        SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (max_iters + 1) * kSlots * 4));
+        t->slots_iters = max_iters;
     }
-    if (n_iters > 0) SOBFU_HIP_TRY(hipMemsetAsync(t->slots, 0, (size_t) (n_iters + 1) * kSlots * 4, st));
+    if (max_iters > 0) SOBFU_HIP_TRY(hipMemsetAsync(t->slots, 0, (size_t) (max_iters + 1) * kSlots * 4, st));
+    q.active = true;
+    return 0;
+}
+
+static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
+    sobfu_hip_tiled::Session& q = t->q;
+    if (!q.active || n_steps < 0 || q.launched + n_steps > q.cap) return SOBFU_E_BADARG;
+    const int X = t->X, Y = t->Y, Z = t->Z, Lx = t->L[0], Ly = t->L[1], Lz = t->L[2];
+    const sobfu_hip_solver_params& p = t->p;
+    float* P[2] = {t->c_psi, t->c_psi2};
+    float* F[2] = {t->c_f, t->c_f2};
+    const int n_iters = q.cap;  // the last iteration this solve can reach (rows past cap - 2 gate nothing)
     // SOBFU_TILED_FORCE_COMM=1 runs the communication choreography (streams, events, empty exchange group, world-1
     // all-reduce) on a single rank too: bring-up / test hook for 1-GPU machines
     const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
     const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
     const int lo = t->own_lo, hi = t->own_hi, H = kHalo;
-    const int a_lo = t->lo ? std::min(lo + H, hi) : lo, a_hi = t->hi ? std::max(hi - H, a_lo) : hi;
-    const int b_lo = t->lo ? std::min(lo + 3, hi) : lo, b_hi = t->hi ? std::max(hi - 3, b_lo) : hi;
-    const int b_first = t->lo ? lo - 1 : lo, b_last = t->hi ? hi + 1 : hi;
+    const int a_lo = t->lo[2] ? std::min(lo + H, hi) : lo, a_hi = t->hi[2] ? std::max(hi - H, a_lo) : hi;
+    const int b_lo = t->lo[2] ? std::min(lo + 3, hi) : lo, b_hi = t->hi[2] ? std::max(hi - 3, b_lo) : hi;
+    const int b_first = t->lo[2] ? lo - 1 : lo, b_last = t->hi[2] ? hi + 1 : hi;
+    // x / y: pass A produces the owned cells; pass B also the one-cell y shells (rows of the same boxes) and -- serial schedule
+    // only, the one 3-D tiles use -- the one-column x shells as transposed boxes of the same launch
+    const int ax0 = t->o0[0], ax1 = t->o1[0], ay0 = t->o0[1], ay1 = t->o1[1];
+    const int by0 = t->lo[1] ? ay0 - 1 : ay0, by1 = t->hi[1] ? ay1 + 1 : ay1;
+    const int own[6] = {ax0, ax1, ay0, ay1, lo, hi};
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
     // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
     // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N >= 4 at 256^3, if a face takes the ~65 us that ~60 GB/s per xGMI direction implies)
@@ -357,44 +486,54 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
     const char* se = std::getenv("SOBFU_TILED_SERIAL");
     const bool want_split = sa ? sa[0] == '1' : (t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes));
-    const bool split_a = (t->lo || t->hi) && a_hi > a_lo && want_split;
-    const bool serial = se ? se[0] == '1' : t->schedule == 3;
+    const bool split_a = (t->lo[2] || t->hi[2]) && a_hi > a_lo && want_split;
+    const bool serial = !t->slab || (se ? se[0] == '1' : t->schedule == 3);  // the overlapped schedules exist for z-slabs only
     // Where the all-reduce of a max-norm row runs (the late gate gives row j until pass B of iteration j+2):
     //   own communicator + stream (sobfu_hip_tiled_add_reduce_comm): issued right after row j's pass B, never in the way of
     //   an exchange; otherwise on the comm stream behind the next exchange (overlapped schedules) or in line (serial).
     enum { RED_NONE, RED_INLINE, RED_COMM_STREAM, RED_OWN_COMM };
     const int red_mode = (!multi || !can_converge) ? RED_NONE : (t->comm2 ? RED_OWN_COMM : (serial ? RED_INLINE : RED_COMM_STREAM));
-    bool red_issued[2] = {false, false};  // an asynchronous reduce of the latest row of this parity is behind ev_red[parity]
+    bool* red_issued = q.red_issued;  // an asynchronous reduce of the latest row of this parity is behind ev_red[parity]
     const auto host_t0 = std::chrono::steady_clock::now();
-    for (int it = 1; it <= n_iters; ++it) {
+    const int last = q.launched + n_steps;
+    for (int it = q.launched + 1; it <= last; ++it) {
         const float *psi_in = P[(it - 1) & 1], *f_in = F[(it - 1) & 1];
         float *psi_out = P[it & 1], *f_out = F[it & 1];
         const uint32_t* prev = (it > 2 && can_converge) ? t->slots + (size_t) (it - 2) * kSlots : nullptr;  // the late gate
         uint32_t* row        = t->slots + (size_t) it * kSlots;
         auto A = [&](int za, int zb, int za2 = 0, int zb2 = 0) {  // pass A writes scratch only: never gated
-            return sobfu_hip::launch_pass_a(f_in, t->c_g, psi_in, t->nU, p.w_reg, X, Y, Lz, nullptr, 0.f, 0, st, true, za, zb, za2, zb2);
+            const sobfu_hip::LaunchBox bx[2] = {{ax0, ax1, ay0, ay1, za, zb, false}, {ax0, ax1, ay0, ay1, za2, zb2, false}};
+            return sobfu_hip::launch_pass_a_boxes(f_in, t->c_g, psi_in, t->nU, p.w_reg, Lx, Ly, Lz, bx, 2, nullptr, 0.f, 0, st, true);
         };
-        auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0) {
-            return sobfu_hip::launch_pass_b(t->nU, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, X, Y, Lz, prev,
-                                            p.max_update_norm, 0, st, Z, lo, hi, true, za, zb, za2, zb2, psi_out, it > 3 ? 2 : 1);
+        auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0, bool x_shells = false) {
+            const sobfu_hip::LaunchBox bx[4] = {{ax0, ax1, by0, by1, za, zb, false}, {ax0, ax1, by0, by1, za2, zb2, false},
+                                                {ax0 - 1, (x_shells && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
+                                                {ax1, (x_shells && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
+            return sobfu_hip::launch_pass_b_boxes(t->nU, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y,
+                                                  Z, own, bx, 4, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
         };
         auto wait_gate = [&]() -> int {  // row it-2 must be global before the first pass-B launch of this iteration
             if (prev && red_issued[it & 1]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[it & 1], 0));
             return 0;
         };
         auto after_b = [&]() -> int {  // row `it` is complete on `st`; it gates iteration it+2
-            if (it > n_iters - 2) return 0;  // the tail rows are reduced once, after the loop
+            if (it > n_iters - 2) return 0;  // the tail rows are reduced once, by tiled_end
             uint32_t* r_ = t->slots + (size_t) it * kSlots;
-            if (red_mode == RED_INLINE) SOBFU_TRY(allreduce_max(t, r_, kSlots, st));
+            if (red_mode == RED_INLINE) {
+                SOBFU_TRY(allreduce_max(t, r_, kSlots, st));
+                q.red_upto = it;
+            }
             if (red_mode == RED_OWN_COMM) {
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_row, st));
                 SOBFU_HIP_TRY(hipStreamWaitEvent(t->red_stream, t->ev_row, 0));
                 SOBFU_TRY(allreduce_max(t, r_, kSlots, t->red_stream, true));
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_red[it & 1], t->red_stream));
                 red_issued[it & 1] = true;
+                q.red_upto = it;
             }
             return 0;
         };
+        q.launched = it;
         if (serial) {
             // no overlap, no cross-stream events: pass A, the exchange and pass B in line on `st`.  Every event record / wait
             // between two kernels costs a few microseconds of drained pipeline (~20 us per iteration for the overlapped
@@ -402,7 +541,7 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
             SOBFU_TRY(A(lo, hi));
             if (multi) SOBFU_TRY(exchange(t, t->nU, H, st));
             SOBFU_TRY(wait_gate());
-            SOBFU_TRY(B(b_first, b_last));
+            SOBFU_TRY(B(b_first, b_last, 0, 0, true));
             SOBFU_TRY(after_b());
             continue;
         }
@@ -420,6 +559,7 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
                 SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_red[(it - 1) & 1], t->comm_stream));
                 red_issued[(it - 1) & 1] = true;
+                q.red_upto = it - 1;
             }
         }
         if (split_a && a_hi > a_lo) SOBFU_TRY(A(a_lo, a_hi));
@@ -432,13 +572,26 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
     }
-    if (n_iters > 0)
-        t->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / n_iters;
+    if (n_steps > 0)
+        t->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / n_steps;
+    return 0;
+}
+
+static int tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, float* per_iter_max_norm, hipStream_t st) {
+    sobfu_hip_tiled::Session& q = t->q;
+    if (!q.active) return SOBFU_E_BADARG;
+    const sobfu_hip_solver_params& p = t->p;
+    float* P[2] = {t->c_psi, t->c_psi2};
+    sobfu_hip_solver_report r{};
+    r.last_max_update_norm = r.last_max_update_index = r.last_e_data = r.last_e_reg = NAN;
+    const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
+    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
+    const int n_iters = q.launched;
     if (multi && n_iters > 0) {  // rows the loop has not reduced yet: all of them without a threshold, the tail otherwise
-        for (int q = 0; q < 2; ++q)
-            if (red_issued[q]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[q], 0));
-        const int first = can_converge ? std::max(1, n_iters - 1) : 1;  // rows 1 .. n_iters-2 went through the comm stream
-        SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (n_iters - first + 1) * kSlots, st));
+        for (int k = 0; k < 2; ++k)
+            if (q.red_issued[k]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[k], 0));
+        const int first = q.red_upto + 1;
+        if (first <= n_iters) SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (n_iters - first + 1) * kSlots, st));
     }
     std::vector<uint32_t> hs((size_t) std::max(n_iters, 1) * kSlots, 0u);
     if (n_iters > 0) SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), t->slots + kSlots, (size_t) n_iters * kSlots * 4, hipMemcpyDeviceToHost, st));
@@ -461,11 +614,45 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     r.iterations = done;
     // leave the compact format from the half that holds the state after `done` iterations: psi.xyz back,
     // phi_n o psi = apply(phi_n, psi) (the state of solver.cu:168)
-    SOBFU_TRY(sobfu_hip::launch_unpack_vec(P[done & 1], d_psi_local, t->NL, st));
-    SOBFU_TRY(sobfu_hip_tile_apply(d_phi_n_full, Z, d_phi_n_psi_local, d_psi_local, X, Y, Lz, st));
+    SOBFU_TRY(sobfu_hip::launch_unpack_vec(P[done & 1], q.psi, t->NL, st));
+    SOBFU_TRY(sobfu_hip_tile3_apply(q.pn, t->X, t->Y, t->Z, q.pnp, q.psi, t->L[0], t->L[1], t->L[2], st));
     SOBFU_HIP_TRY(hipStreamSynchronize(st));
+    q.active = false;
     if (report) *report = r;
     return 0;
+}
+
+int sobfu_hip_tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full, float* d_phi_n_psi_local,
+                          float* d_psi_local, int max_iters, void* stream) {
+    SOBFU_CHECK_ARGS(t && d_phi_global_local && d_phi_n_full && d_phi_n_psi_local && d_psi_local && max_iters >= 0);
+    return tiled_begin(t, d_phi_global_local, d_phi_n_full, d_phi_n_psi_local, d_psi_local, max_iters, (hipStream_t) stream);
+}
+
+int sobfu_hip_tiled_step(sobfu_hip_tiled* t, int n_iters, void* stream) {
+    SOBFU_CHECK_ARGS(t && n_iters >= 0);
+    return tiled_step(t, n_iters, (hipStream_t) stream);
+}
+
+int sobfu_hip_tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream) {
+    SOBFU_CHECK_ARGS(t);
+    return tiled_end(t, report, per_iter_max_norm, (hipStream_t) stream);
+}
+
+int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full,
+                            float* d_phi_n_psi_local, float* d_psi_local, int n_iters, sobfu_hip_solver_report* report,
+                            float* per_iter_max_norm, void* stream) {
+    SOBFU_CHECK_ARGS(t && d_phi_global_local && d_phi_n_full && d_phi_n_psi_local && d_psi_local && n_iters >= 0);
+    hipStream_t st = (hipStream_t) stream;
+    SOBFU_TRY(tiled_begin(t, d_phi_global_local, d_phi_n_full, d_phi_n_psi_local, d_psi_local, n_iters, st));
+    const int rc = tiled_step(t, n_iters, st);
+    if (rc != 0) {
+        // peers may be blocked in a collective this rank never issued: drain what was enqueued and give the session up (the
+        // caller must treat the communicator as dead -- sobfu_hip_tiled_destroy)
+        (void) hipStreamSynchronize(st);
+        t->q.active = false;
+        return rc;
+    }
+    return tiled_end(t, report, per_iter_max_norm, st);
 }
 
 }  // extern "C"

@@ -23,7 +23,8 @@ struct IntegrateArgs {
     float vsx, vsy, vsz, trunc, eta;
     float R[9], t[3];
     float fx, fy, cx, cy;
-    int zbase;  // global z of local plane 0 (multi-GPU slabs; 0 for a whole volume)
+    int zbase;  // global z of local plane 0 (multi-GPU tiles; 0 for a whole volume)
+    int xbase, ybase;  // likewise along x / y (3-D tiles)
 };
 
 // TsdfIntegrator::operator()(TsdfVolume&) -- tsdf_volume.cu:62-101
@@ -31,7 +32,7 @@ __global__ void __launch_bounds__(256) integrate_depth_kernel(IntegrateArgs a) {
     int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
     if (x >= a.d.x || y >= a.d.y) return;
     int z0 = blockIdx.z * kZC;
-    float vcx = x * a.vsx + a.vsx / 2.f, vcy = y * a.vsy + a.vsy / 2.f, vcz = a.vsz / 2.f;
+    float vcx = (x + a.xbase) * a.vsx + a.vsx / 2.f, vcy = (y + a.ybase) * a.vsy + a.vsy / 2.f, vcz = a.vsz / 2.f;
     float camx = dot3(a.R + 0, vcx, vcy, vcz) + a.t[0];
     float camy = dot3(a.R + 3, vcx, vcy, vcz) + a.t[1];
     float camz = dot3(a.R + 6, vcx, vcy, vcz) + a.t[2];
@@ -197,7 +198,7 @@ int sobfu_hip_integrate_depth(const float* d_dists, int step, int rows, int cols
                               const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx,
                               float fy, float cx, float cy, void* stream) {
     SOBFU_CHECK_ARGS(d_dists && d_vol && vs && R && t && X > 0 && Y > 0 && Z > 0 && rows > 0 && cols > 0 && step >= cols * 4);
-    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol, {X, Y, Z}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, 0};
+    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol, {X, Y, Z}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, 0, 0, 0};
     for (int i = 0; i < 9; ++i) a.R[i] = R[i];
     for (int i = 0; i < 3; ++i) a.t[i] = t[i];
     hipLaunchKernelGGL(integrate_depth_kernel, chunk_grid(X, Y, Z), voxel_block(), 0, (hipStream_t) stream, a);
@@ -208,10 +209,22 @@ int sobfu_hip_tile_integrate_depth(const float* d_dists, int step, int rows, int
                                    const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx, float fy,
                                    float cx, float cy, void* stream) {
     SOBFU_CHECK_ARGS(d_dists && d_vol_local && vs && R && t && X > 0 && Y > 0 && Lz > 0 && zbase >= 0 && rows > 0 && cols > 0 && step >= cols * 4);
-    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol_local, {X, Y, Lz}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, zbase};
+    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol_local, {X, Y, Lz}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, zbase, 0, 0};
     for (int i = 0; i < 9; ++i) a.R[i] = R[i];
     for (int i = 0; i < 3; ++i) a.t[i] = t[i];
     hipLaunchKernelGGL(integrate_depth_kernel, chunk_grid(X, Y, Lz), voxel_block(), 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile3_integrate_depth(const float* d_dists, int step, int rows, int cols, float* d_vol_local, int Lx, int Ly, int Lz, int xb,
+                                    int yb, int zb, const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx,
+                                    float fy, float cx, float cy, void* stream) {
+    SOBFU_CHECK_ARGS(d_dists && d_vol_local && vs && R && t && Lx > 0 && Ly > 0 && Lz > 0 && xb >= 0 && yb >= 0 && zb >= 0 && rows > 0 &&
+                     cols > 0 && step >= cols * 4);
+    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol_local, {Lx, Ly, Lz}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, zb, xb, yb};
+    for (int i = 0; i < 9; ++i) a.R[i] = R[i];
+    for (int i = 0; i < 3; ++i) a.t[i] = t[i];
+    hipLaunchKernelGGL(integrate_depth_kernel, chunk_grid(Lx, Ly, Lz), voxel_block(), 0, (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }
 

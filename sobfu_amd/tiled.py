@@ -1,26 +1,25 @@
-"""Multi-GPU solver loop: the volume is cut into z-slabs, one rank (one process, one GPU) per slab.
+"""Multi-GPU solver loop: the volume is cut into a Px x Py x Pz grid of TILES, one rank (one process, one GPU) per tile.
 
-SURVEY.md section 8(e).  Frames of a sequence are sequentially dependent (psi persists), so the path shards by
-VOLUME TILE.  Slabs along z (z is the slowest-varying axis of the layout) make every halo a contiguous block of
-planes: halo exchange is zero-copy `isend/irecv` straight out of / into the field arrays -- no pack kernels.
+SURVEY.md section 8(e).  Frames of a sequence are sequentially dependent (psi persists), so the path shards by VOLUME TILE:
+2 x 2 x 2 tiles of 128^3 on 8 GPUs for the 256^3 grid (BASELINE config 4); 1 x 1 x N are z-slabs, whose halos are whole planes
+(z is the slowest-varying axis of the layout) and travel zero-copy straight out of / into the field arrays.
 
-Per rank:  psi, phi_n o psi, phi_global, nabla_U are LOCAL slabs (X, Y, Lz) = owned planes + HALO (=4) planes towards
-each neighbour; phi_n is replicated (the warp gathers at absolute coordinates anywhere in the volume).
+Per rank:  psi, phi_n o psi, phi_global, nabla_U are LOCAL arrays = owned cells + HALO (= 4) cells on every side that faces a
+neighbour; phi_n is replicated (the warp gathers at absolute coordinates anywhere in the volume).
 
-One iteration = ONE exchange (Option B of the survey, which in a 1-D decomposition needs no edge data), overlapped
-with the interior compute (the kernels take the range of planes a launch produces):
-    A_bnd  nabla_U on the 4 owned planes next to each interior face (reads psi, phi_n o psi at owned +-1)
-    E      start the exchange of those planes (one grouped RCCL send/recv on RCCL's stream) -> nabla_U exact on owned +-4
-    A_int  nabla_U on the remaining owned planes                       } run while E is in flight: they touch
-    B_int  psi, phi_n o psi on the planes whose +-3 taps are all owned } neither the planes being sent nor received
-    wait E
-    B_bnd  psi, phi_n o psi on the remaining planes out to owned +-1: the radius-3 convolution is exact there, so psi
-           and phi_n o psi stay exact on owned +-1 -- all the next pass A reads -- without ever being exchanged
-           (invariant; identity psi satisfies it at the start).  max ||u||^2 takes OWNED planes only.
+One iteration = ONE exchange (Option B of the survey):
+    A      nabla_U on the owned cells (reads psi, phi_n o psi at owned +- 1 along each axis)
+    E      the 4-cell faces of nabla_U go to the face neighbours and 4 x 4 edge strips to the edge neighbours (one message per
+           neighbour, one grouped RCCL send/recv); corners are never needed: every stencil is axis-aligned
+    B      psi, phi_n o psi on owned +- 1 along each axis: the radius-3 convolution is exact there, so psi and phi_n o psi stay
+           exact on the one-cell shells -- all the next pass A reads -- without ever being exchanged (invariant; identity psi
+           satisfies it at the start).  A shell cell one step outside along axis a reads nabla_U up to 3 further along a (face
+           halo, hence width 4) and up to 3 along any other axis b (edge strip).  max ||u||^2 takes OWNED cells only.
     R      all_reduce(MAX) of the 256 max-norm slots -- only when max_update_norm >= 0 (otherwise the test never fires)
-Halo planes further out are never read.  Clamp / mirror rules act at a slab's array edge, which is the volume
-boundary exactly where the slab has no halo, so the result equals the single-GPU run bit for bit (the max is
-order-independent).
+z-slabs overlap E with the interior compute (the kernels take the range of planes a launch produces):
+    A_bnd (4 owned planes next to each interior face) -> E || A_int, B_int (planes whose +-3 taps are all owned) -> wait E -> B_bnd
+Halo cells further out are never read.  Clamp / mirror rules act at a tile's array edge, which is the volume boundary exactly
+where the tile has no halo, so the result equals the single-GPU run bit for bit (the max is order-independent).
 
 The kernel backend is pluggable: `HipBackend` (product; C ABI on torch CUDA tensors over RCCL) -- the CPU tests inject an
 oracle-backed backend over gloo to check the decomposition logic without a GPU.
@@ -28,6 +27,7 @@ oracle-backed backend over gloo to check the decomposition logic without a GPU.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import sys
 import time
 
@@ -39,50 +39,169 @@ HALO = 4
 SLOTS = 256
 
 
-class SlabLayout:
-    """Which z planes a rank owns and how its local slab is laid out."""
+def default_grid(world):
+    """Tile grid for `world` ranks: as cubic as the factorisation allows, larger factors on the slower axes (x, the axis the
+    64 lanes of a wave run along, is split last): 8 -> 2 x 2 x 2 (BASELINE config 4), 4 -> 1 x 2 x 2, 2 -> 1 x 1 x 2."""
+    best = None
+    for px in range(1, world + 1):
+        if world % px:
+            continue
+        for py in range(1, world // px + 1):
+            if (world // px) % py:
+                continue
+            pz = world // (px * py)
+            if px <= py <= pz:
+                key = (pz - px, pz)
+                if best is None or key < best[0]:
+                    best = (key, (px, py, pz))
+    return best[1]
+
+
+def parse_grid(text, world):
+    """'2x2x2' -> (2, 2, 2); '' -> default_grid(world)"""
+    if not text:
+        return default_grid(world)
+    g = tuple(int(v) for v in text.lower().split("x"))
+    if len(g) != 3 or g[0] * g[1] * g[2] != world or min(g) < 1:
+        raise ValueError(f"tile grid {text!r} does not have {world} tiles")
+    return g
+
+
+class TileLayout:
+    """Which cells a rank owns and how its local arrays are laid out.  rank = cx + Px * (cy + Py * cz); index triples are
+    (x, y, z); the cells of every axis are split as evenly as possible (sobfu_hip_tiled_create3 computes the same layout)."""
+
+    def __init__(self, dims, grid, rank, halo=HALO):
+        dims, grid = tuple(int(d) for d in dims), tuple(int(g) for g in grid)
+        world = grid[0] * grid[1] * grid[2]
+        if not 0 <= rank < world:
+            raise ValueError("rank outside the tile grid")
+        self.dims, self.grid, self.world, self.rank, self.halo = dims, grid, world, rank, halo
+        self.coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+        g0, g1, lo, hi = [], [], [], []
+        for a in range(3):
+            base, rem = divmod(dims[a], grid[a])
+            if grid[a] > 1 and base < halo:
+                raise ValueError(f"axis {'xyz'[a]} ({dims[a]} cells) is too thin for {grid[a]} tiles with halo {halo}")
+            c = self.coords[a]
+            g0.append(c * base + min(c, rem))
+            g1.append(g0[-1] + base + (1 if c < rem else 0))
+            lo.append(halo if c > 0 else 0)
+            hi.append(halo if c < grid[a] - 1 else 0)
+        self.g0, self.g1, self.lo3, self.hi3 = tuple(g0), tuple(g1), tuple(lo), tuple(hi)
+        self.L = tuple(g1[a] - g0[a] + lo[a] + hi[a] for a in range(3))              # local extents
+        self.o0 = tuple(lo)                                                           # owned local range [o0, o1)
+        self.o1 = tuple(lo[a] + g1[a] - g0[a] for a in range(3))
+        self.base = tuple(g0[a] - lo[a] for a in range(3))                            # global coordinate of local cell 0
+        self.slab = grid[0] == 1 and grid[1] == 1
+        # the z entries under the names the slab schedules use
+        self.z0, self.z1, self.lo, self.hi = g0[2], g1[2], lo[2], hi[2]
+        self.Lz, self.own_lo, self.own_hi, self.zbase = self.L[2], self.o0[2], self.o1[2], self.base[2]
+
+    def local_shape(self, channels=None):
+        shp = (self.L[2], self.L[1], self.L[0])
+        return shp if channels is None else shp + (channels,)
+
+    def take(self, full):
+        """local array (with halos) cut out of a full-volume array / tensor"""
+        b, L = self.base, self.L
+        return full[b[2]:b[2] + L[2], b[1]:b[1] + L[1], b[0]:b[0] + L[0]]
+
+    def owned(self, local):
+        return local[self.o0[2]:self.o1[2], self.o0[1]:self.o1[1], self.o0[0]:self.o1[0]]
+
+    def owned_global(self, full):
+        return full[self.g0[2]:self.g1[2], self.g0[1]:self.g1[1], self.g0[0]:self.g1[0]]
+
+    def own_box(self):
+        return (self.o0[0], self.o1[0], self.o0[1], self.o1[1], self.o0[2], self.o1[2])
+
+    def pass_b_boxes(self):
+        """[(box, transposed)] pass B produces: the owned cells with their one-cell y / z shells, and the one-column x shells
+        (lanes along y).  Cells on tile edges (two shells at once) come out of stale halo data and are never read."""
+        o0, o1, lo, hi = self.o0, self.o1, self.lo3, self.hi3
+        ext = lambda a: (o0[a] - (1 if lo[a] else 0), o1[a] + (1 if hi[a] else 0))  # noqa: E731
+        boxes = [((o0[0], o1[0]) + ext(1) + ext(2), False)]
+        if lo[0]:
+            boxes.append(((o0[0] - 1, o0[0], o0[1], o1[1], o0[2], o1[2]), True))
+        if hi[0]:
+            boxes.append(((o1[0], o1[0] + 1, o0[1], o1[1], o0[2], o1[2]), True))
+        return boxes
+
+    def messages(self, width=None):
+        """[(peer, send_box, recv_box)] of one exchange: every face neighbour (one non-zero offset) and edge neighbour (two).
+        Along an axis with offset +1 the `width` owned cells next to that face go out and the `width` halo cells beyond it come
+        in; along an axis with offset 0 the owned range (the neighbour shares that coordinate, hence the range)."""
+        w = self.halo if width is None else width
+        out = []
+        for dz, dy, dx in itertools.product((-1, 0, 1), repeat=3):
+            d = (dx, dy, dz)
+            nnz = sum(1 for v in d if v)
+            if nnz < 1 or nnz > 2:
+                continue
+            n = tuple(self.coords[a] + d[a] for a in range(3))
+            if any(n[a] < 0 or n[a] >= self.grid[a] for a in range(3)):
+                continue
+            sb, rb = [], []
+            for a in range(3):
+                if d[a] > 0:
+                    sb += [self.o1[a] - w, self.o1[a]]
+                    rb += [self.o1[a], self.o1[a] + w]
+                elif d[a] < 0:
+                    sb += [self.o0[a], self.o0[a] + w]
+                    rb += [self.o0[a] - w, self.o0[a]]
+                else:
+                    sb += [self.o0[a], self.o1[a]]
+                    rb += [self.o0[a], self.o1[a]]
+            out.append((n[0] + self.grid[0] * (n[1] + self.grid[1] * n[2]), tuple(sb), tuple(rb)))
+        return out
+
+
+class SlabLayout(TileLayout):
+    """z-slabs: the 1 x 1 x world tile grid"""
 
     def __init__(self, dims, world, rank, halo=HALO):
-        X, Y, Z = (int(d) for d in dims)
-        if Z < world * halo:
-            raise ValueError(f"Z={Z} is too thin for {world} slabs with halo {halo}")
-        base, rem = divmod(Z, world)
-        starts = [r * base + min(r, rem) for r in range(world + 1)]
-        self.dims, self.world, self.rank, self.halo = (X, Y, Z), world, rank, halo
-        self.z0, self.z1 = starts[rank], starts[rank + 1]
-        self.lo = halo if rank > 0 else 0            # halo planes below
-        self.hi = halo if rank < world - 1 else 0    # halo planes above
-        self.Lz = (self.z1 - self.z0) + self.lo + self.hi
-        self.own_lo, self.own_hi = self.lo, self.lo + (self.z1 - self.z0)
-        self.zbase = self.z0 - self.lo               # global z of local plane 0
+        if int(dims[2]) < world * halo:
+            raise ValueError(f"Z={dims[2]} is too thin for {world} slabs with halo {halo}")
+        super().__init__(dims, (1, 1, world), rank, halo)
         if world > 1 and (self.z1 - self.z0) < halo:
             raise ValueError("a slab must own at least `halo` planes")
 
-    def local_shape(self, channels):
-        X, Y, _ = self.dims
-        return (self.Lz, Y, X, channels)
 
-    def take(self, full):
-        """local slab (with halos) cut out of a full-volume array/tensor"""
-        return full[self.zbase:self.zbase + self.Lz]
-
-    def owned(self, local):
-        return local[self.own_lo:self.own_hi]
+def _cut(t, box):
+    return t[box[4]:box[5], box[2]:box[3], box[0]:box[1]]
 
 
-def halo_ops(layout: SlabLayout, fields, group=None):
-    """P2P op list of one exchange (built once per solve: the views stay valid while the buffers live)."""
+def halo_ops(layout: TileLayout, fields, group=None):
+    """P2P op list of one exchange (built once per solve: the buffers stay valid while the solve lives).
+    fields: list of (tensor (Lz, Ly, Lx, ...), width).  z-slabs: zero-copy views of the planes.  3-D tiles: staging buffers;
+    returns (ops, pack, unpack) where pack() copies the send boxes out before the ops start and unpack() scatters the received
+    boxes after they finished."""
     L = layout
-    ops = []
+    ops, packs, unpacks = [], [], []
     for t, w in fields:
-        assert t.shape[0] == L.Lz and t.is_contiguous() and 0 < w <= L.halo
-        if L.rank > 0:
-            ops.append(dist.P2POp(dist.isend, t[L.own_lo:L.own_lo + w], L.rank - 1, group))
-            ops.append(dist.P2POp(dist.irecv, t[L.own_lo - w:L.own_lo], L.rank - 1, group))
-        if L.rank < L.world - 1:
-            ops.append(dist.P2POp(dist.isend, t[L.own_hi - w:L.own_hi], L.rank + 1, group))
-            ops.append(dist.P2POp(dist.irecv, t[L.own_hi:L.own_hi + w], L.rank + 1, group))
-    return ops
+        assert tuple(t.shape[:3]) == L.local_shape() and t.is_contiguous() and 0 < w <= L.halo
+        for peer, sb, rb in L.messages(w):
+            src, dst = _cut(t, sb), _cut(t, rb)
+            if src.is_contiguous() and dst.is_contiguous():
+                ops.append(dist.P2POp(dist.isend, src, peer, group))
+                ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+            else:
+                sbuf, rbuf = torch.empty_like(src, memory_format=torch.contiguous_format), torch.empty_like(dst, memory_format=torch.contiguous_format)
+                packs.append((sbuf, src))
+                unpacks.append((dst, rbuf))
+                ops.append(dist.P2POp(dist.isend, sbuf, peer, group))
+                ops.append(dist.P2POp(dist.irecv, rbuf, peer, group))
+
+    def pack():
+        for buf, view in packs:
+            buf.copy_(view)
+
+    def unpack():
+        for view, buf in unpacks:
+            view.copy_(buf)
+
+    return ops, pack, unpack
 
 
 def start_halo_ops(ops):
@@ -99,9 +218,12 @@ def run_halo_ops(ops):
     finish_halo_ops(start_halo_ops(ops))
 
 
-def exchange_halos(layout: SlabLayout, fields, group=None):
-    """fields: list of (tensor (Lz, ...), radius).  Zero-copy neighbour exchange of `radius` owned planes."""
-    run_halo_ops(halo_ops(layout, fields, group))
+def exchange_halos(layout: TileLayout, fields, group=None):
+    """fields: list of (tensor (Lz, Ly, Lx, ...), width): neighbour exchange of the `width`-cell faces / edge strips."""
+    ops, pack, unpack = halo_ops(layout, fields, group)
+    pack()
+    run_halo_ops(ops)
+    unpack()
 
 
 class _SlabState:
@@ -112,10 +234,10 @@ class _SlabState:
 
 
 class HipBackend:
-    """Per-slab kernels through the C ABI (include/sobfu_hip.h `sobfu_hip_tile_*`).
+    """Per-tile kernels through the C ABI (include/sobfu_hip.h `sobfu_hip_tile3_*`).
 
     Iterates in the compact format (12-byte psi / nabla_U, tsdf-only phi_global / phi_n / phi_n o psi -- fewer bytes both
-    through HBM and over xGMI); `begin` converts the caller's API-format slabs, `end` rebuilds them."""
+    through HBM and over xGMI); `begin` converts the caller's API-format arrays, `end` rebuilds them."""
 
     device = "cuda"
 
@@ -136,64 +258,59 @@ class HipBackend:
         return C.c_void_p(t.data_ptr())
 
     def init_identity(self, psi, layout):
-        X, Y, _ = layout.dims
-        self._call("sobfu_hip_tile_init_identity", self._p(psi), X, Y, layout.Lz, layout.zbase)
+        self._call("sobfu_hip_tile3_init_identity", self._p(psi), *layout.L, *layout.base)
 
     def _buf(self, key, shape):
         t = self._cache.get(key)
         if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.empty(shape, dtype=torch.float32, device="cuda")
+            t = torch.zeros(shape, dtype=torch.float32, device="cuda")
             self._cache[key] = t
         return t
 
     def begin(self, layout, pg_local, pn_full, pnp_local, psi_local):
         X, Y, Z = layout.dims
-        Lz = layout.Lz
+        Lx, Ly, Lz = layout.L
         st = _SlabState(layout, None)
         st.pn_full, st.pnp, st.psi = pn_full, pnp_local, psi_local
         if not self.compact:
-            st.nabla_U = self._buf("nU4", (Lz, Y, X, 4))
+            st.nabla_U = self._buf("nU4", (Lz, Ly, Lx, 4))
             st.c_psi, st.c_f, st.c_g, st.c_n = psi_local, pnp_local, pg_local, pn_full
-            self._call("sobfu_hip_tile_apply", self._p(pn_full), Z, self._p(pnp_local), self._p(psi_local), X, Y, Lz)
+            self._call("sobfu_hip_tile3_apply", self._p(pn_full), X, Y, Z, self._p(pnp_local), self._p(psi_local), Lx, Ly, Lz)
             return st
-        st.nabla_U = self._buf("nU3", (Lz, Y, X, 3))
-        st.c_psi, st.c_f, st.c_g = self._buf("psi3", (Lz, Y, X, 3)), self._buf("f", (Lz, Y, X)), self._buf("g", (Lz, Y, X))
+        st.nabla_U = self._buf("nU3", (Lz, Ly, Lx, 3))
+        st.c_psi, st.c_f, st.c_g = self._buf("psi3", (Lz, Ly, Lx, 3)), self._buf("f", (Lz, Ly, Lx)), self._buf("g", (Lz, Ly, Lx))
         st.c_n = self._buf("n", (Z, Y, X))
-        nl, nf = C.c_size_t(Lz * Y * X), C.c_size_t(Z * Y * X)
+        nl, nf = C.c_size_t(Lz * Ly * Lx), C.c_size_t(Z * Y * X)
         self._call("sobfu_hip_pack_vec3", self._p(psi_local), self._p(st.c_psi), nl)
         self._call("sobfu_hip_extract_tsdf", self._p(pg_local), self._p(st.c_g), nl)
         self._call("sobfu_hip_extract_tsdf", self._p(pn_full), self._p(st.c_n), nf)
-        self._call("sobfu_hip_tile_apply_tsdf_only", self._p(st.c_n), Z, self._p(st.c_f), self._p(st.c_psi), X, Y, Lz)  # solver.cu:106
+        self._call("sobfu_hip_tile3_apply_tsdf_only", self._p(st.c_n), X, Y, Z, self._p(st.c_f), self._p(st.c_psi), Lx, Ly, Lz)  # solver.cu:106
         return st
 
-    def pass_a(self, st, z0, z1, w_reg, prev_slots, thr):
-        """nabla_U on local planes [z0, z1)"""
-        if z1 <= z0:
+    def pass_a(self, st, box, w_reg, prev_slots, thr, transposed=False):
+        """nabla_U on the local cells of `box` = (x0, x1, y0, y1, z0, z1)"""
+        if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0:
             return
-        L = st.layout
-        X, Y, _ = L.dims
         prev = self._p(prev_slots) if prev_slots is not None else None
-        self._call("sobfu_hip_tile_potential_gradient", self._p(st.c_f), self._p(st.c_g), self._p(st.c_psi), self._p(st.nabla_U),
-                   C.c_float(w_reg), X, Y, L.Lz, z0, z1, prev, C.c_float(thr), 1 if self.compact else 0)
+        self._call("sobfu_hip_tile3_potential_gradient", self._p(st.c_f), self._p(st.c_g), self._p(st.c_psi), self._p(st.nabla_U),
+                   C.c_float(w_reg), *st.layout.L, (C.c_int * 6)(*box), 1 if transposed else 0, prev, C.c_float(thr), 1 if self.compact else 0)
 
-    def pass_b(self, st, z0, z1, slots, taps, alpha, prev_slots, thr):
-        """psi update + warp on local planes [z0, z1)"""
-        if z1 <= z0:
+    def pass_b(self, st, box, slots, taps, alpha, prev_slots, thr, transposed=False):
+        """psi update + warp on the local cells of `box`"""
+        if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0:
             return
         L = st.layout
-        X, Y, Z = L.dims
         prev = self._p(prev_slots) if prev_slots is not None else None
-        self._call("sobfu_hip_tile_smooth_update_apply", self._p(st.nabla_U), self._p(st.c_psi), self._p(st.c_n), self._p(st.c_f), None,
-                   self._p(slots), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), X, Y, L.Lz, Z, L.own_lo, L.own_hi,
-                   z0, z1, prev, C.c_float(thr), 1 if self.compact else 0)
+        self._call("sobfu_hip_tile3_smooth_update_apply", self._p(st.nabla_U), self._p(st.c_psi), self._p(st.c_n), self._p(st.c_f), None,
+                   self._p(slots), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), *L.L, *L.dims, (C.c_int * 6)(*L.own_box()),
+                   (C.c_int * 6)(*box), 1 if transposed else 0, prev, C.c_float(thr), 1 if self.compact else 0)
 
     def end(self, st):
         if not self.compact:
             return
         L = st.layout
-        X, Y, Z = L.dims
-        self._call("sobfu_hip_unpack_vec3", self._p(st.c_psi), self._p(st.psi), C.c_size_t(L.Lz * Y * X))
-        self._call("sobfu_hip_tile_apply", self._p(st.pn_full), Z, self._p(st.pnp), self._p(st.psi), X, Y, L.Lz)  # state of solver.cu:168
+        self._call("sobfu_hip_unpack_vec3", self._p(st.c_psi), self._p(st.psi), C.c_size_t(L.L[0] * L.L[1] * L.L[2]))
+        self._call("sobfu_hip_tile3_apply", self._p(st.pn_full), *L.dims, self._p(st.pnp), self._p(st.psi), *L.L)  # state of solver.cu:168
 
     def sobolev_filter(self, s, lam):
         return self._ops.sobolev_filter(s, lam)
@@ -211,14 +328,16 @@ def _sqrt_rd(m_bits: int) -> float:
 
 
 class TiledSolver:
-    """The gradient-descent loop of sobfu::device::estimate_psi (reference src/sobfu/cuda/solver.cu:106-193) on slabs."""
+    """The gradient-descent loop of sobfu::device::estimate_psi (reference src/sobfu/cuda/solver.cu:106-193) on tiles."""
 
-    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, backend=None, group=None):
+    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, backend=None, group=None, grid=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group = group
         self.backend = backend or HipBackend()
-        self.layout = SlabLayout(dims, self.world, self.rank)
+        self.layout = TileLayout(dims, grid or (1, 1, self.world), self.rank)
+        if self.layout.world != self.world:
+            raise ValueError(f"tile grid {grid} needs {self.layout.world} ranks, the group has {self.world}")
         self.alpha, self.w_reg, self.thr = float(alpha), float(w_reg), float(max_update_norm)
         if s < 7:
             raise ValueError("S < 7 is unsupported (the kernels use 7 taps, reference solver.cu:211-234)")
@@ -241,26 +360,38 @@ class TiledSolver:
         st = be.begin(L, phi_global_local, phi_n_full, phi_n_psi_local, psi_local)  # includes the warp of solver.cu:106
         slots = torch.zeros((n_iters + 1, SLOTS), dtype=torch.int32, device=be.device)
         self.slots = slots
-        xch = halo_ops(L, [(st.nabla_U, HALO)], self.group) if self.world > 1 else []
+        xch, pack, unpack = halo_ops(L, [(st.nabla_U, HALO)], self.group) if self.world > 1 else ([], lambda: None, lambda: None)
+        ox, oy = (L.o0[0], L.o1[0]), (L.o0[1], L.o1[1])
         lo, hi, H = L.own_lo, L.own_hi, HALO
-        # planes next to an interior face (sent to the neighbour) vs the rest; ranges are local plane indices
-        a_lo = min(lo + H, hi) if L.lo else lo          # [lo, a_lo)  : lower boundary planes of pass A
-        a_hi = max(hi - H, a_lo) if L.hi else hi        # [a_hi, hi)  : upper boundary planes of pass A
-        b_lo = min(lo + 3, hi) if L.lo else lo          # pass B planes >= b_lo have all -3 taps inside the owned range
-        b_hi = max(hi - 3, b_lo) if L.hi else hi
-        b_first = lo - 1 if L.lo else lo                # pass B also refreshes the first halo plane (owned +-1)
-        b_last = hi + 1 if L.hi else hi
+        b_boxes = L.pass_b_boxes()
+        if L.slab:
+            # z-slabs: planes next to an interior face (sent to the neighbour) vs the rest, so that the exchange overlaps the
+            # interior compute; ranges are local plane indices
+            a_lo = min(lo + H, hi) if L.lo else lo          # [lo, a_lo)  : lower boundary planes of pass A
+            a_hi = max(hi - H, a_lo) if L.hi else hi        # [a_hi, hi)  : upper boundary planes of pass A
+            b_lo = min(lo + 3, hi) if L.lo else lo          # pass B planes >= b_lo have all -3 taps inside the owned range
+            b_hi = max(hi - 3, b_lo) if L.hi else hi
+            b_first = lo - 1 if L.lo else lo                # pass B also refreshes the first halo plane (owned +-1)
+            b_last = hi + 1 if L.hi else hi
         for it in range(1, n_iters + 1):
             prev = slots[it - 1] if (it > 1 and can_converge) else None
             row = slots[it]
-            be.pass_a(st, lo, a_lo, self.w_reg, prev, self.thr)
-            be.pass_a(st, a_hi, hi, self.w_reg, prev, self.thr)
-            works = start_halo_ops(xch)
-            be.pass_a(st, a_lo, a_hi, self.w_reg, prev, self.thr)
-            be.pass_b(st, b_lo, b_hi, row, self.taps, self.alpha, prev, self.thr)
-            finish_halo_ops(works)
-            be.pass_b(st, b_first, b_lo, row, self.taps, self.alpha, prev, self.thr)
-            be.pass_b(st, b_hi, b_last, row, self.taps, self.alpha, prev, self.thr)
+            if L.slab:
+                be.pass_a(st, ox + oy + (lo, a_lo), self.w_reg, prev, self.thr)
+                be.pass_a(st, ox + oy + (a_hi, hi), self.w_reg, prev, self.thr)
+                works = start_halo_ops(xch)
+                be.pass_a(st, ox + oy + (a_lo, a_hi), self.w_reg, prev, self.thr)
+                be.pass_b(st, ox + oy + (b_lo, b_hi), row, self.taps, self.alpha, prev, self.thr)
+                finish_halo_ops(works)
+                be.pass_b(st, ox + oy + (b_first, b_lo), row, self.taps, self.alpha, prev, self.thr)
+                be.pass_b(st, ox + oy + (b_hi, b_last), row, self.taps, self.alpha, prev, self.thr)
+            else:
+                be.pass_a(st, L.own_box(), self.w_reg, prev, self.thr)
+                pack()
+                finish_halo_ops(start_halo_ops(xch))
+                unpack()
+                for box, tr in b_boxes:
+                    be.pass_b(st, box, row, self.taps, self.alpha, prev, self.thr, transposed=tr)
             if self.world > 1 and can_converge:
                 dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
         if self.world > 1 and not can_converge:
@@ -281,46 +412,57 @@ class TiledSolver:
         return estimate_psi_tiled(self, *args, **kw)
 
     def gather_owned(self, local):
-        """all_gather of the owned planes -> full volume on every rank (z-concatenation)."""
-        own = self.layout.owned(local).contiguous()
-        if self.world == 1:
-            return own
-        base, rem = divmod(self.layout.dims[2], self.world)
-        parts = [torch.empty((base + (1 if r < rem else 0),) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
-                 for r in range(self.world)]
-        dist.all_gather(parts, own, group=self.group)
+        """all_gather of the owned cells -> full volume on every rank"""
+        return gather_owned(self.layout, local, self.group)
+
+
+def gather_owned(layout, local, group=None):
+    L = layout
+    own = L.owned(local).contiguous()
+    if L.world == 1:
+        return own
+    lays = [TileLayout(L.dims, L.grid, r) for r in range(L.world)]
+    parts = [torch.empty((l.g1[2] - l.g0[2], l.g1[1] - l.g0[1], l.g1[0] - l.g0[0]) + tuple(own.shape[3:]), dtype=own.dtype, device=own.device)
+             for l in lays]
+    dist.all_gather(parts, own, group=group)
+    if L.slab:
         return torch.cat(parts, dim=0)
+    X, Y, Z = L.dims
+    full = torch.empty((Z, Y, X) + tuple(own.shape[3:]), dtype=own.dtype, device=own.device)
+    for l, part in zip(lays, parts):
+        l.owned_global(full).copy_(part)
+    return full
 
 
 def estimate_psi_tiled(solver, phi_global_local, phi_global_psi_inv_local, phi_n_full, phi_n_psi_local, psi_local, psi_inv_local,
                        n_iters, inverse_iters=48, gather=None):
-    """One frame's Solver::estimate_psi (src/sobfu/cuda/solver.cu:85-205) on slabs: the tiled iteration loop, then the
+    """One frame's Solver::estimate_psi (src/sobfu/cuda/solver.cu:85-205) on tiles: the tiled iteration loop, then the
     two per-frame collectives of SURVEY 8(e) -- all-gather psi for the 48-sweep inverse (it gathers psi at arbitrary
-    psi^-1(x)), all-gather phi_global for the canonical -> live warp -- each followed by the slab kernel.  HIP backend only
-    (C ABI: sobfu_hip_tile_init_identity / tile_estimate_inverse / tile_apply).  `gather` overrides solver.gather_owned
+    psi^-1(x)), all-gather phi_global for the canonical -> live warp -- each followed by the tile kernel.  HIP backend only
+    (C ABI: sobfu_hip_tile3_init_identity / tile3_estimate_inverse / tile3_apply).  `gather` overrides solver.gather_owned
     (tests).  Returns (iterations, per-iteration max norms)."""
     from . import _lib
 
     L = solver.layout
-    X, Y, Z = L.dims
     lib, st = _lib.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
     gather = gather or solver.gather_owned
     done, norms = solver.iterate(phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters)
     psi_full = gather(psi_local)                                                              # solver.cu:196-197
-    _lib.check(lib.sobfu_hip_tile_init_identity(C.c_void_p(psi_inv_local.data_ptr()), X, Y, L.Lz, L.zbase, st), "tile_init_identity")
-    _lib.check(lib.sobfu_hip_tile_estimate_inverse(C.c_void_p(psi_full.data_ptr()), Z, C.c_void_p(psi_inv_local.data_ptr()), X, Y, L.Lz,
-                                                   L.zbase, C.c_int(inverse_iters), st), "tile_estimate_inverse")
+    _lib.check(lib.sobfu_hip_tile3_init_identity(C.c_void_p(psi_inv_local.data_ptr()), *L.L, *L.base, st), "tile3_init_identity")
+    _lib.check(lib.sobfu_hip_tile3_estimate_inverse(C.c_void_p(psi_full.data_ptr()), *L.dims, C.c_void_p(psi_inv_local.data_ptr()), *L.L,
+                                                    *L.base, C.c_int(inverse_iters), st), "tile3_estimate_inverse")
     pg_full = gather(phi_global_local)                                                        # solver.cu:199
-    _lib.check(lib.sobfu_hip_tile_apply(C.c_void_p(pg_full.data_ptr()), Z, C.c_void_p(phi_global_psi_inv_local.data_ptr()),
-                                        C.c_void_p(psi_inv_local.data_ptr()), X, Y, L.Lz, st), "tile_apply")
+    _lib.check(lib.sobfu_hip_tile3_apply(C.c_void_p(pg_full.data_ptr()), *L.dims, C.c_void_p(phi_global_psi_inv_local.data_ptr()),
+                                         C.c_void_p(psi_inv_local.data_ptr()), *L.L, st), "tile3_apply")
     torch.cuda.current_stream().synchronize()  # psi_full / pg_full die with this frame
     return done, norms
 
 
 class TiledFusion:
-    """SobFusion::operator() (src/sobfu/sob_fusion.cpp:71-145) with the volume cut into z-slabs: every rank runs the depth
-    pre-steps (640 x 480: negligible), integrates ITS slab of phi_global and the whole phi_n (the warp gathers anywhere), the
-    solve runs tiled, the fusion touches owned planes only.  phi_global / phi_n o psi / psi / psi^-1 live as local slabs.
+    """SobFusion::operator() (src/sobfu/sob_fusion.cpp:71-145) with the volume cut into tiles: every rank runs the depth
+    pre-steps (640 x 480: negligible), integrates ITS tile of phi_global and the whole phi_n (the warp gathers anywhere), the
+    solve runs tiled, the fusion is per cell (run on the whole local array: only owned cells are ever read back).
+    phi_global / phi_n o psi / psi / psi^-1 live as local arrays.
 
     params: dims, size (metres), trunc, eta (metres), max_weight, intr (fx, fy, cx, cy), R, t (volume -> camera), start_frame,
     bilateral (ksz, sigma_spatial, sigma_depth), trunc_depth, max_iter; `solver` is a TiledSolver / NativeTiledSolver."""
@@ -343,7 +485,7 @@ class TiledFusion:
         dists = ops.compute_dists(d, P["intr"])                                      # :91
         if self.frame == 0:                                                          # :93-123
             self.phi_global = s.new_local(2)
-            ops.tile_integrate_depth(dists, self.phi_global, L.zbase, self.vs, P["trunc"], P["eta"], P["R"], P["t"], P["intr"])
+            ops.tile3_integrate_depth(dists, self.phi_global, L.base, self.vs, P["trunc"], P["eta"], P["R"], P["t"], P["intr"])
             self.phi_n = ops.new_volume(L.dims)
             self.phi_n_psi, self.phi_global_psi_inv = s.new_local(2), s.new_local(2)
             self.psi, self.psi_inv = s.identity_psi(), s.identity_psi()
@@ -351,26 +493,31 @@ class TiledFusion:
             return None
         ops.clear_volume(self.phi_n)                                                 # :129
         ops.integrate_depth(dists, self.phi_n, self.vs, P["trunc"], P["eta"], P["R"], P["t"], P["intr"])  # :130
-        own = slice(L.own_lo, L.own_hi)
         result = None
         if self.frame < P["start_frame"]:                                            # :136-139
-            ops.integrate_fuse(self.phi_global[own], L.owned(L.take(self.phi_n)).contiguous(), P["max_weight"])
+            ops.integrate_fuse(self.phi_global, L.take(self.phi_n).contiguous(), P["max_weight"])
         else:
             result = s.estimate_psi(self.phi_global, self.phi_global_psi_inv, self.phi_n, self.phi_n_psi, self.psi, self.psi_inv,
                                     P["max_iter"], gather=self.gather)               # :141
-            ops.integrate_fuse(self.phi_global[own], self.phi_n_psi[own], P["max_weight"])  # :142 (owned planes)
+            ops.integrate_fuse(self.phi_global, self.phi_n_psi, P["max_weight"])     # :142 (halo cells come out stale; never read)
         self.frame += 1
         return result
 
 
+class TiledMsg(C.Structure):
+    """sobfu_hip_tiled_msg"""
+    _fields_ = [("peer", C.c_int), ("send_off", C.c_size_t), ("recv_off", C.c_size_t), ("count", C.c_size_t)]
+
+
 class NativeTiledSolver:
-    """The same slab loop run entirely in C++ (sobfu_amd/csrc/tiled_capi.hip): RCCL send/recv issued from the library on
-    a dedicated communication stream, overlapped with the interior compute, no Python per iteration.  torch.distributed is
+    """The same tile loop run entirely in C++ (sobfu_amd/csrc/tiled_capi.hip): RCCL send/recv issued from the library, no Python
+    per iteration (z-slabs: on a dedicated communication stream, overlapped with the interior compute).  torch.distributed is
     used once, to hand the RCCL unique id to every rank."""
 
-    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, group=None, dry=None):
-        """dry=(world, rank): a communicator-less handle with that slab layout -- every launch and stream dependency of the
-        rank's schedule without peers (halos are stale, so only its TIMING means anything; tools/slab_time_native.py)."""
+    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, group=None, dry=None, grid=None):
+        """grid: (Px, Py, Pz) tiles (default: z-slabs, 1 x 1 x world).  dry=(world, rank): a communicator-less handle with that
+        rank's layout -- every launch and stream dependency of the rank's schedule without peers (halos are stale unless a
+        transport is plugged in with set_transport; alone, only its TIMING means anything: tools/slab_time_native.py)."""
         import os
 
         from . import _lib
@@ -392,10 +539,14 @@ class NativeTiledSolver:
             box = [bytes(uid)]
             dist.broadcast_object_list(box, src=0, group=group)
             uid = (C.c_char * 128).from_buffer_copy(box[0])
+        grid = tuple(int(g) for g in grid) if grid else (1, 1, self.world)
+        if grid[0] * grid[1] * grid[2] != self.world:
+            raise ValueError(f"tile grid {grid} does not have {self.world} tiles")
+        self.grid = grid
         self.params = SolverParams(0, 0, s, max_update_norm, np.float32(lam), alpha, w_reg)
         self._h = C.c_void_p()
         X, Y, Z = (int(d) for d in dims)
-        _lib.check(L.sobfu_hip_tiled_create(C.byref(self._h), X, Y, Z, self.world, self.rank, uid, C.byref(self.params)), "tiled_create")
+        _lib.check(L.sobfu_hip_tiled_create3(C.byref(self._h), X, Y, Z, *grid, self.rank, uid, C.byref(self.params)), "tiled_create3")
         want2 = os.environ.get("SOBFU_TILED_REDUCE_COMM", "1")  # "force": also on a world of one (bring-up / tests)
         if dry is None and ((self.world > 1 and want2 == "1") or want2 == "force"):
             # a communicator of its own for the max-norm all-reduce (collective; every rank or none)
@@ -407,19 +558,30 @@ class NativeTiledSolver:
                 dist.broadcast_object_list(box, src=0, group=group)
                 uid2 = (C.c_char * 128).from_buffer_copy(box[0])
             _lib.check(L.sobfu_hip_tiled_add_reduce_comm(self._h, uid2), "tiled_add_reduce_comm")
-        self.layout = SlabLayout(dims, self.world, self.rank)
-        v = [C.c_int() for _ in range(6)]
-        _lib.check(L.sobfu_hip_tiled_layout(self._h, *[C.byref(x) for x in v]), "tiled_layout")
-        got = tuple(x.value for x in v)
-        want = (self.layout.z0, self.layout.z1, self.layout.lo, self.layout.hi, self.layout.Lz, self.layout.zbase)
-        assert got == want, (got, want)
+        self.has_comm = dry is None
+        self.schedule = 0
+        self.layout = TileLayout(dims, grid, self.rank)
+        v = (C.c_int * 24)()
+        _lib.check(L.sobfu_hip_tiled_layout3(self._h, v), "tiled_layout3")
+        lay = self.layout
+        want = lay.grid + lay.coords + lay.g0 + lay.g1 + lay.lo3 + lay.hi3 + lay.L + lay.base
+        assert tuple(v) == want, (tuple(v), want)
+        # the library's message table must be the one TileLayout.messages() describes (both sides of the C ABI build it)
+        mm, sb, rb = (TiledMsg * 18)(), (C.c_int * (6 * 18))(), (C.c_int * (6 * 18))()
+        n = L.sobfu_hip_tiled_messages(self._h, mm, sb, rb, 18)
+        mine = [] if lay.slab else lay.messages()
+        assert n == len(mine), (n, len(mine))
+        for i, (peer, sbox, rbox) in enumerate(mine):
+            assert mm[i].peer == peer and tuple(sb[6 * i:6 * i + 6]) == sbox and tuple(rb[6 * i:6 * i + 6]) == rbox, (i, peer, sbox, rbox)
 
-    EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+    EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(TiledMsg), C.c_int, C.c_void_p)
     ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
     def set_transport(self, exchange, allreduce_max):
-        """communicator-less (dry) handles only: callables (rank, field_ptr, planes, stream) / (rank, buf_ptr, n, stream) -> 0"""
-        self._cb = (self.EXCHANGE_FN(lambda ctx, r, f, p, st: exchange(r, f, p, st)),
+        """communicator-less (dry) handles only: callables exchange(rank, send_ptr, recv_ptr, [(peer, send_off, recv_off, count)],
+        stream) (offsets / counts in floats) and allreduce_max(rank, buf_ptr, n, stream) -> 0"""
+        self._cb = (self.EXCHANGE_FN(lambda ctx, r, sp, rp, m, n, st: exchange(r, sp or 0, rp or 0,
+                                                                             [(m[i].peer, m[i].send_off, m[i].recv_off, m[i].count) for i in range(n)], st)),
                     self.ALLREDUCE_FN(lambda ctx, r, b, n, st: allreduce_max(r, b, n, st)))
         self._lib.check(self._lib.lib().sobfu_hip_tiled_set_transport(self._h, self._cb[0], self._cb[1], None), "tiled_set_transport")
 
@@ -435,9 +597,8 @@ class NativeTiledSolver:
 
     def identity_psi(self):
         psi = self.new_local(4)
-        X, Y, _ = self.layout.dims
-        self._lib.check(self._lib.lib().sobfu_hip_tile_init_identity(C.c_void_p(psi.data_ptr()), X, Y, self.layout.Lz, self.layout.zbase,
-                                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tile_init_identity")
+        self._lib.check(self._lib.lib().sobfu_hip_tile3_init_identity(C.c_void_p(psi.data_ptr()), *self.layout.L, *self.layout.base,
+                                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tile3_init_identity")
         return psi
 
     def iterate(self, phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters):
@@ -451,8 +612,29 @@ class NativeTiledSolver:
             "tiled_iterate")
         return rep.iterations, np.array(hist[:rep.iterations], np.float32)
 
+    def begin(self, phi_global_local, phi_n_full, phi_n_psi_local, psi_local, max_iters):
+        """the loop in pieces (sobfu_hip_tiled_begin / step / end): step(n) ENQUEUES n iterations without synchronising"""
+        self._session = (phi_global_local, phi_n_full, phi_n_psi_local, psi_local, int(max_iters))  # keeps the buffers alive
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_begin(
+            self._h, C.c_void_p(phi_global_local.data_ptr()), C.c_void_p(phi_n_full.data_ptr()), C.c_void_p(phi_n_psi_local.data_ptr()),
+            C.c_void_p(psi_local.data_ptr()), C.c_int(int(max_iters)), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tiled_begin")
+
+    def step(self, n_iters):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_step(self._h, C.c_int(int(n_iters)), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "tiled_step")
+
+    def end(self):
+        from ._lib import SolverReport
+
+        rep = SolverReport()
+        hist = (C.c_float * max(1, self._session[4]))()
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_end(self._h, C.byref(rep), hist, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "tiled_end")
+        self._session = None
+        return rep.iterations, np.array(hist[:rep.iterations], np.float32)
+
     def gather_owned(self, local):
-        return TiledSolver.gather_owned(self, local)
+        return gather_owned(self.layout, local, self.group)
 
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)
@@ -485,131 +667,197 @@ class NativeTiledSolver:
         return times
 
 
-def _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank, reps=30, iters=60):
+class GlooTransport:
+    """Transport of a communicator-less native handle over a gloo process group, staged through host memory: lets N ranks that
+    SHARE one GPU (bench.py with SOBFU_BENCH_SHARE_GPU=1, bring-up on a machine with fewer GPUs than ranks -- RCCL refuses two
+    ranks on one device) run the real multi-process tile loop.  Not a performance path."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def _ok(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"hip call failed: {rc}")
+
+    def exchange(self, rank, send, recv, msgs, stream):
+        try:
+            self._ok(self.hip.hipStreamSynchronize(stream))
+            ops, bufs = [], []
+            for peer, soff, roff, cnt in msgs:
+                out, inn = torch.empty(cnt, dtype=torch.float32), torch.empty(cnt, dtype=torch.float32)
+                self._ok(self.hip.hipMemcpy(out.data_ptr(), send + 4 * soff, 4 * cnt, 2))
+                ops.append(dist.P2POp(dist.isend, out, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, inn, peer, self.group))
+                bufs.append((inn, roff, cnt, out))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for inn, roff, cnt, _ in bufs:
+                self._ok(self.hip.hipMemcpy(recv + 4 * roff, inn.data_ptr(), 4 * cnt, 1))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("gloo transport: exchange failed:", repr(e), file=sys.stderr, flush=True)
+            return -1
+
+    def allreduce(self, rank, buf, n, stream):
+        try:
+            self._ok(self.hip.hipStreamSynchronize(stream))
+            h = torch.empty(n, dtype=torch.int32)  # max ||u||^2 bit patterns of non-negative floats order like int32
+            self._ok(self.hip.hipMemcpy(h.data_ptr(), buf, 4 * n, 2))
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            self._ok(self.hip.hipMemcpy(buf, h.data_ptr(), 4 * n, 1))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("gloo transport: allreduce failed:", repr(e), file=sys.stderr, flush=True)
+            return -1
+
+
+def _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks, reps=30, iters=60):
     """Per-piece timings of the native loop on the machine at hand (microseconds; rank 0's view after a MAX over ranks)."""
     import os
 
     L, lib, check = solver.layout, solver._lib.lib(), solver._lib.check
-    X, Y, _ = dims
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     out = {}
 
     def timed(fn, n):
         fn()
         torch.cuda.synchronize()
-        dist.barrier()
+        ranks.barrier()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
         torch.cuda.synchronize()
-        t = torch.tensor([(time.perf_counter() - t0) / n * 1e6], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return ranks.max([(time.perf_counter() - t0) / n * 1e6])[0]
 
-    field = torch.zeros((L.Lz, Y, X, 3), dtype=torch.float32, device="cuda")
-    for planes in (1, 2, HALO):  # latency vs bandwidth of a face message: 1/4, 1/2 and all of the loop's halo
-        out[f"exchange_{planes}_planes_us"] = timed(
+    field = torch.zeros(L.local_shape(3), dtype=torch.float32, device="cuda")
+    for planes in ((1, 2, HALO) if L.slab else (HALO,)):  # latency vs bandwidth of a face message (z-slabs: 1/4, 1/2 and all of the halo)
+        out[f"exchange_{planes}_cells_us"] = timed(
             lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(planes), st), "exchange"), reps)
-    out["exchange_bytes_per_face"] = HALO * X * Y * 12
-    slots = torch.zeros(SLOTS, dtype=torch.int32, device="cuda")
-    out["allreduce_256_slots_us"] = timed(lambda: check(lib.sobfu_hip_tiled_allreduce_max_u32(solver._h, C.c_void_p(slots.data_ptr()), C.c_size_t(SLOTS), st), "allreduce"), reps)
+    msgs = L.messages()
+    out["exchange_messages"] = len(msgs)
+    out["exchange_bytes_out"] = sum((m[1][1] - m[1][0]) * (m[1][3] - m[1][2]) * (m[1][5] - m[1][4]) for m in msgs) * 12
+    out["exchange_largest_message_bytes"] = max([(m[1][1] - m[1][0]) * (m[1][3] - m[1][2]) * (m[1][5] - m[1][4]) for m in msgs] or [0]) * 12
+    if solver.has_comm:
+        slots = torch.zeros(SLOTS, dtype=torch.int32, device="cuda")
+        out["allreduce_256_slots_us"] = timed(lambda: check(lib.sobfu_hip_tiled_allreduce_max_u32(solver._h, C.c_void_p(slots.data_ptr()), C.c_size_t(SLOTS), st), "allreduce"), reps)
     pnp, psi = solver.new_local(2), solver.identity_psi()
 
     def loop(s):
         return lambda: s.iterate(pg, pn_full, pnp, psi, iters)
 
-    prev = os.environ.get("SOBFU_TILED_SPLIT_A")
-    for name, val in (("iteration_us_pass_a_unsplit", "0"), ("iteration_us_pass_a_split", "1")):
-        os.environ["SOBFU_TILED_SPLIT_A"] = val
-        out[name] = timed(loop(solver), 2) / iters
-    if prev is None:
-        os.environ.pop("SOBFU_TILED_SPLIT_A", None)
-    else:
-        os.environ["SOBFU_TILED_SPLIT_A"] = prev
-    os.environ["SOBFU_TILED_SERIAL"] = "1"  # pass A, exchange, pass B in line on one stream (no overlap, no events)
-    out["iteration_us_serial_schedule"] = timed(loop(solver), 2) / iters
-    os.environ.pop("SOBFU_TILED_SERIAL", None)
+    if L.slab:
+        prev = os.environ.get("SOBFU_TILED_SPLIT_A")
+        for name, val in (("iteration_us_pass_a_unsplit", "0"), ("iteration_us_pass_a_split", "1")):
+            os.environ["SOBFU_TILED_SPLIT_A"] = val
+            out[name] = timed(loop(solver), 2) / iters
+        if prev is None:
+            os.environ.pop("SOBFU_TILED_SPLIT_A", None)
+        else:
+            os.environ["SOBFU_TILED_SPLIT_A"] = prev
+        os.environ["SOBFU_TILED_SERIAL"] = "1"  # pass A, exchange, pass B in line on one stream (no overlap, no events)
+        out["iteration_us_serial_schedule"] = timed(loop(solver), 2) / iters
+        os.environ.pop("SOBFU_TILED_SERIAL", None)
     out["iteration_us_default_schedule"] = timed(loop(solver), 2) / iters
     lib.sobfu_hip_tiled_last_enqueue_us.restype = C.c_double
     out["host_enqueue_us_per_iteration"] = float(lib.sobfu_hip_tiled_last_enqueue_us(solver._h))
-    dry = NativeTiledSolver(dims, dry=(world, rank), **kw)  # same slab, no peers: the compute side alone
+    dry = NativeTiledSolver(dims, dry=(world, rank), grid=grid, **kw)  # same tile, no peers: the compute side alone
     out["iteration_us_compute_only"] = timed(loop(dry), 2) / iters
     dry.close()
     return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}
 
 
-def bench_tiled(P, steps, warmup, rank, world):
-    """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N z-slabs (strong scaling)."""
-    from . import ops
-
-    dims = P["dims"]
-    X, Y, Z = dims
-    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
+def bench_tiled(args, P, ranks, timed_regions):
+    """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N tiles (strong scaling; 2 x 2 x 2 at N = 8)."""
     import os
 
+    from . import ops
+
+    rank, world = ranks.rank, ranks.world
+    dims = P["dims"]
+    X, Y, Z = dims
+    grid = parse_grid(args.tiles or os.environ.get("SOBFU_TILES", ""), world)
+    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
     kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
-    # default: the native C++ loop (RCCL issued from the library, exchange overlapped with the interior compute); if ANY
-    # rank fails to set it up, every rank falls back to the torch.distributed loop (same schedule, same results)
+    K, W, R = args.steps, args.warmup, args.repeats
+    total = W + R * K
+    # default: the native C++ loop (RCCL issued from the library); if ANY rank fails to set it up, every rank falls back to
+    # the torch.distributed loop (same decomposition, same results).  Ranks that share a GPU (bring-up) run the native loop
+    # over the gloo transport.
     native = os.environ.get("SOBFU_TILED_NATIVE", "1") == "1"
-    solver = None
+    solver, transport = None, None
     if native:
         try:
-            solver = NativeTiledSolver(dims, **kw)
+            if ranks.share and world > 1:
+                solver = NativeTiledSolver(dims, dry=(world, rank), grid=grid, **kw)
+                transport = GlooTransport()
+                solver.set_transport(transport.exchange, transport.allreduce)
+            else:
+                if world == 1 and not dist.is_initialized():  # SOBFU_FORCE_TILED=1 on one GPU: a world of one
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29533")
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", ranks.device))
+                solver = NativeTiledSolver(dims, grid=grid, **kw)
         except Exception as e:  # noqa: BLE001 -- report and agree on the fallback collectively
-            print(f"[rank {rank}] native tiled loop unavailable: {e}", file=sys.stderr, flush=True)
-        ok = torch.tensor([1 if solver is not None else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+            print(f"[rank {rank}] native tiled loop unavailable: {e!r}", file=sys.stderr, flush=True)
+        ok = ranks.min([1 if solver is not None else 0])[0]
+        if ok == 0:
             if solver is not None:
                 solver.close()
             solver, native = None, False
     if solver is None:
-        solver = TiledSolver(dims, **kw)
+        solver = TiledSolver(dims, grid=grid, **kw)
     L = solver.layout
-    # every rank builds the full analytic TSDFs (replicated phi_n; phi_global is then cut to the local slab)
+    # every rank builds the full analytic TSDFs (replicated phi_n; phi_global is then cut to the local tile)
     pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
     ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
     ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
-    pg = L.take(pg_full).clone()
+    pg = L.take(pg_full).clone().contiguous()
     del pg_full
     pnp = solver.new_local(2)
     psi = solver.identity_psi()
     tuned = None
-    if native and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":  # outside the timed region: pick this machine's best schedule
-        tuned = solver.autotune(pg, pn_full)
-    if warmup > 0:
-        solver.iterate(pg, pn_full, pnp, psi, warmup)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    done, norms = solver.iterate(pg, pn_full, pnp, psi, steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    assert done == steps and np.isfinite(norms).all() and float(norms.max()) > 0
+    if native and L.slab and transport is None and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
+        tuned = solver.autotune(pg, pn_full)  # outside the timed region: this machine's best z-slab schedule
+    if native:
+        solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
+        solver.step(W)
+        secs = timed_regions(ranks, torch, lambda: solver.step(K), R)
+        done, norms = solver.end()
+        assert done == total and np.isfinite(norms).all() and float(norms.max()) > 0, (done, total)
+    else:  # the torch loop has no open-solve form: a region is a whole iterate() of K iterations
+        if W > 0:
+            solver.iterate(pg, pn_full, pnp, psi, W)
+        hist = []
+        secs = timed_regions(ranks, torch, lambda: hist.append(solver.iterate(pg, pn_full, pnp, psi, K)), R)
+        norms = np.concatenate([h[1] for h in hist])
+        assert all(h[0] == K for h in hist) and np.isfinite(norms).all()
     # self-check, outside the timed region: every rank repeats the WHOLE solve on its own GPU with the single-GPU solver
-    # handle and compares its owned planes and the max-norm history bit for bit (tiling must not change a single bit)
+    # handle and compares its owned cells and the max-norm history bit for bit (tiling must not change a single bit)
     parity = None
     if os.environ.get("SOBFU_TILED_SELFCHECK", "1") == "1":
         pg_full = ops.new_volume(dims)
         ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
         psi_full, pnp_full = ops.new_field(dims), ops.new_volume(dims)
         ops.init_identity(psi_full)
-        one = ops.Solver(dims, max_iter=max(steps, warmup, 1), **kw)
-        if warmup > 0:
-            one.iterate(pg_full, pn_full, pnp_full, psi_full, warmup)
-        _, norms_one = one.iterate(pg_full, pn_full, pnp_full, psi_full, steps)
+        one = ops.Solver(dims, max_iter=max(total, 1), **kw)
+        if native:
+            _, norms_one = one.iterate(pg_full, pn_full, pnp_full, psi_full, total)
+        else:
+            parts = [one.iterate(pg_full, pn_full, pnp_full, psi_full, n)[1] for n in ([W] if W > 0 else []) + [K] * R]
+            norms_one = np.concatenate(parts[(1 if W > 0 else 0):])
         one.close()
         same = (np.array_equal(np.asarray(norms_one, np.float32).view(np.uint32), np.asarray(norms, np.float32).view(np.uint32))
-                and torch.equal(L.owned(L.take(psi_full))[..., :3].contiguous().view(torch.int32), L.owned(psi)[..., :3].contiguous().view(torch.int32))
-                and torch.equal(L.owned(L.take(pnp_full)).contiguous().view(torch.int32), L.owned(pnp).contiguous().view(torch.int32)))
-        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        parity = bool(int(ok.item()))
+                and torch.equal(L.owned_global(psi_full)[..., :3].contiguous().view(torch.int32), L.owned(psi)[..., :3].contiguous().view(torch.int32))
+                and torch.equal(L.owned_global(pnp_full).contiguous().view(torch.int32), L.owned(pnp).contiguous().view(torch.int32)))
+        parity = bool(ranks.min([1 if same else 0])[0])
         if not parity:
-            print(f"[rank {rank}] tiled self-check: slab differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
+            print(f"[rank {rank}] tiled self-check: tile differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
+        del pg_full, psi_full, pnp_full
     # diagnostics for the next tuning round, outside the timed region (every rank takes part in the collective ones):
-    # what one halo exchange, one slot all-reduce and the compute side alone cost on THIS machine, and both pass-A schedules
+    # what one halo exchange, one slot all-reduce and the compute side alone cost on THIS machine
     diag, hung = None, False
     if native and os.environ.get("SOBFU_TILED_DIAG", "1") == "1":
         # in a worker thread with a deadline: whatever happens in there (an exception on one rank would leave the others
@@ -621,7 +869,7 @@ def bench_tiled(P, steps, warmup, rank, world):
         def work():
             try:
                 torch.cuda.set_device(dev_index)
-                box["diag"] = _tiled_diagnostics(solver, kw, dims, pg, pn_full, world, rank)
+                box["diag"] = _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks)
             except Exception as e:  # noqa: BLE001
                 box["error"] = repr(e)
 
@@ -632,8 +880,13 @@ def bench_tiled(P, steps, warmup, rank, world):
         diag = box.get("diag") or {"error": "timed out" if hung else box.get("error", "unknown")}
         if "error" in diag:
             print(f"[rank {rank}] tiled diagnostics: {diag['error']}", file=sys.stderr, flush=True)
-    return dict(diag_hung=hung, seconds=dt, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity, tiled_diag=diag,
-                parallelism=f"{world} z-slabs of {(Z + world - 1) // world} planes (+{HALO}-plane halos), RCCL halo exchange, "
+    own = tuple(L.g1[a] - L.g0[a] for a in range(3))
+    what = (f"{world} z-slabs of {own[2]} planes" if L.slab else f"{grid[0]}x{grid[1]}x{grid[2]} tiles of {own[0]}x{own[1]}x{own[2]} cells")
+    return dict(diag_hung=hung, region_seconds=secs, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
+                tiled_diag=diag, tiles={"grid": list(grid), "owned_cells_rank0": list(own), "halo": HALO,
+                                        "messages_per_exchange_rank0": len(L.messages())},
+                parallelism=f"{what} (+{HALO}-cell halos), one nabla_U halo exchange per iteration over "
+                            + ("gloo (ranks share a GPU: bring-up transport)" if transport else "RCCL send/recv") + ", "
                             + ("native C++ loop" if native else "torch.distributed loop")
-                            + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ""),
+                            + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ("" if L.slab else ", serial schedule")),
                 tiled_autotune_us={solver.SCHEDULES[k]: round(v, 2) for k, v in tuned.items()} if tuned else None)

@@ -1,6 +1,6 @@
-"""Worker for tests/test_tiled_cpu.py: runs sobfu_amd.tiled.TiledSolver over gloo with an ORACLE-backed per-slab kernel
+"""Worker for tests/test_tiled_cpu.py: runs sobfu_amd.tiled.TiledSolver over gloo with an ORACLE-backed per-tile kernel
 backend (test infrastructure: checks the decomposition / halo-exchange / reduction logic on CPU, bit for bit against the
-single-process oracle solve).  Usage: python _tiled_worker.py <rank> <world> <port> <out.npz> <thr>"""
+single-process oracle solve).  Usage: python _tiled_worker.py <rank> <world> <port> <out.npz> <thr> [PxxPyxPz]"""
 import os
 import sys
 
@@ -31,7 +31,8 @@ class OracleBackend:
     def init_identity(self, psi, layout):
         a = psi.numpy()
         O.init_identity(a)
-        a[..., 2] += np.float32(layout.zbase)
+        for k in range(3):
+            a[..., k] += np.float32(layout.base[k])
 
     def begin(self, layout, pg, pn_full, pnp, psi):
         st = _State()
@@ -46,23 +47,26 @@ class OracleBackend:
             return False
         return tiled._sqrt_rd(int(prev.numpy().view(np.uint32).max())) <= thr
 
-    def pass_a(self, st, z0, z1, w_reg, prev, thr):
-        """whole-slab oracle kernels, only planes [z0, z1) are committed (a launch of the HIP kernel produces exactly those)"""
-        if z1 <= z0 or self._gate(prev, thr):
+    @staticmethod
+    def _sl(box):
+        return (slice(box[4], box[5]), slice(box[2], box[3]), slice(box[0], box[1]))
+
+    def pass_a(self, st, box, w_reg, prev, thr, transposed=False):
+        """whole-array oracle kernels, only the cells of `box` are committed (a launch of the HIP kernel produces exactly those)"""
+        if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0 or self._gate(prev, thr):
             return
-        L = st.layout
-        dims = (L.dims[0], L.dims[1], L.Lz)
+        dims = st.layout.L
         g, Lap, out = O.new_field(dims), O.new_field(dims), O.new_field(dims)
         O.tsdf_gradient(st.pnp, g)
         O.laplacian(st.psi, Lap)
         O.potential_gradient(st.pnp, st.pg, g, Lap, out, w_reg)
-        st.nabla_U.numpy()[z0:z1] = out[z0:z1]
+        st.nabla_U.numpy()[self._sl(box)] = out[self._sl(box)]
 
-    def pass_b(self, st, z0, z1, slots, taps, alpha, prev, thr):
-        if z1 <= z0 or self._gate(prev, thr):
+    def pass_b(self, st, box, slots, taps, alpha, prev, thr, transposed=False):
+        if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0 or self._gate(prev, thr):
             return
         L = st.layout
-        dims = (L.dims[0], L.dims[1], L.Lz)
+        dims = L.L
         nU = st.nabla_U.numpy()
         nUS, upd = O.new_field(dims), O.new_field(dims)
         O.convolution_rows(nUS, nU, taps)
@@ -70,13 +74,16 @@ class OracleBackend:
         O.convolution_depth(nUS, nU, taps)
         psi_new = st.psi.copy()
         O.update_psi(psi_new, nUS, upd, alpha)
-        st.psi[z0:z1] = psi_new[z0:z1]
+        sl = self._sl(box)
+        st.psi[sl] = psi_new[sl]
         warped = O.new_volume(dims)
         O.apply_tile(st.pn, warped, psi_new)
-        st.pnp[z0:z1] = warped[z0:z1]
-        a, b = max(z0, L.own_lo), min(z1, L.own_hi)
-        if b > a:
-            u = upd[a:b]
+        st.pnp[sl] = warped[sl]
+        ob = L.own_box()
+        lo = [max(box[2 * k], ob[2 * k]) for k in range(3)]
+        hi = [min(box[2 * k + 1], ob[2 * k + 1]) for k in range(3)]
+        if all(h > l for l, h in zip(lo, hi)):
+            u = upd[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
             sq = (u[..., 0] * u[..., 0] + u[..., 1] * u[..., 1]) + u[..., 2] * u[..., 2]
             s = slots.numpy().view(np.uint32)
             s[0] = max(s[0], np.float32(sq.max()).view(np.uint32))
@@ -102,12 +109,13 @@ def inputs():
 
 def main():
     rank, world, port, out, thr = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], float(sys.argv[5])
+    grid = tiled.parse_grid(sys.argv[6], world) if len(sys.argv) > 6 else (1, 1, world)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     O.set_num_threads(1)
     torch.set_num_threads(1)
     pg, pn = inputs()
-    sv = tiled.TiledSolver(DIMS, alpha=0.05, w_reg=0.4, max_update_norm=thr, backend=OracleBackend())
+    sv = tiled.TiledSolver(DIMS, alpha=0.05, w_reg=0.4, max_update_norm=thr, backend=OracleBackend(), grid=grid)
     L = sv.layout
     pg_l = torch.from_numpy(np.ascontiguousarray(L.take(pg)))
     pn_full = torch.from_numpy(pn)

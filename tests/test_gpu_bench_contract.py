@@ -59,7 +59,24 @@ def test_config5_replicas_512():
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 512 ** 3 * 64
 
 
-def test_slab_path_line_on_one_gpu():
-    d = run_bench("--gpus", "1", "--steps", "20", "--warmup", "6", "--dim", "128", "--no-cpu-baseline", env={"SOBFU_FORCE_TILED": "1"})
+def test_tile_path_line_on_one_gpu():
+    d = run_bench("--gpus", "1", "--steps", "20", "--warmup", "6", "--dim", "128", "--repeats", "3", "--no-cpu-baseline", env={"SOBFU_FORCE_TILED": "1"})
     assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and "native C++ loop" in d["config"]["parallelism"]
-    assert d["tiled_diag"]["exchange_bytes_per_face"] == 4 * 128 * 128 * 12 and d["tiled_diag"]["iteration_us_compute_only"] > 0
+    assert d["tiled_diag"]["iteration_us_compute_only"] > 0 and d["tiles"]["grid"] == [1, 1, 1]
+
+
+@pytest.mark.parametrize("n,grid", [(8, [2, 2, 2]), (4, [1, 2, 2]), (2, [1, 1, 2])])
+def test_gpus_n_strong_scaling_self_launch(n, grid):
+    """plain `python bench.py --gpus 8`: self-launch, the default tile grid (2 x 2 x 2 at N = 8), the native loop on every rank,
+    one REAL process per rank -- on this 1-GPU box the ranks share cuda:0 and the halo messages travel over gloo instead of
+    RCCL; every rank checks its tile against the single-GPU solve bit for bit"""
+    d = run_bench("--gpus", str(n), "--steps", "6", "--warmup", "2", "--dim", "64", "--repeats", "2", env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["tiles"]["grid"] == grid
+    assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and "native C++ loop" in d["config"]["parallelism"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6 and "cpu_baseline" not in d
+
+
+def test_gpus_n_explicit_tiles_and_threshold():
+    d = run_bench("--gpus", "4", "--tiles", "2x2x1", "--steps", "5", "--warmup", "1", "--dim", "64", "--repeats", "2",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})
+    assert d["tiles"]["grid"] == [2, 2, 1] and d["tiled_parity_vs_single_gpu"] == "bit-exact"

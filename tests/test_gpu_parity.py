@@ -457,10 +457,11 @@ def test_full_size_256_fused_equals_launchers_and_properties(ops, oracle):
 # multi-GPU slab kernels (sobfu_hip_tile_*) on one GPU: slabs with exchanged halos == full volume
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("compact", [False, True])
-@pytest.mark.parametrize("world", [2, 3])
-def test_tile_kernels_match_full_volume(ops, oracle, world, compact):
-    """One iteration on every slab of a 2- / 3-way cut, with the single nabla_U exchange emulated by slicing the
-    full-volume result: owned +-1 planes of psi / phi_n o psi and the owned max must equal the full-volume kernels."""
+@pytest.mark.parametrize("grid", [(1, 1, 2), (1, 1, 3), (2, 1, 1), (1, 2, 1), (2, 2, 2), (3, 2, 1)])
+def test_tile_kernels_match_full_volume(ops, oracle, grid, compact):
+    """One iteration on every tile of a cut (z-slabs, x / y splits, 2 x 2 x 2), with the single nabla_U exchange emulated by
+    slicing the full-volume result: the owned cells and their one-cell shells of psi / phi_n o psi, and the owned max, must
+    equal the full-volume kernels.  The x shells run as transposed boxes."""
     from sobfu_amd import tiled
 
     dims = (70, 24, 36)
@@ -476,36 +477,94 @@ def test_tile_kernels_match_full_volume(ops, oracle, world, compact):
     m_full = ops.fused_smooth_update_apply(nU_f, psi_f, dev(pn), pnp_f, S, alpha)
     pn_d = dev(pn)
     m_tiles = 0.0
-    for r in range(world):
-        L = tiled.SlabLayout(dims, world, r)
+    ident = oracle.new_field(dims)
+    oracle.init_identity(ident)
+    for r in range(grid[0] * grid[1] * grid[2]):
+        L = tiled.TileLayout(dims, grid, r)
         idl = torch.zeros(L.local_shape(4), device="cuda")
         be.init_identity(idl, L)
-        ident = oracle.new_field(dims)
-        oracle.init_identity(ident)
         assert same(host(idl), L.take(ident))
         psi_l, pg_l = (L.take(t).clone().contiguous() for t in (dev(psi0), dev(pg)))
         pnp_l = torch.zeros(L.local_shape(2), device="cuda")
         st = be.begin(L, pg_l, pn_d, pnp_l, psi_l)
-        # split launches, as the overlapped schedule issues them
-        be.pass_a(st, L.own_lo, L.own_lo + 2, w_reg, None, 0.0)
-        be.pass_a(st, L.own_hi - 3, L.own_hi, w_reg, None, 0.0)
-        be.pass_a(st, L.own_lo + 2, L.own_hi - 3, w_reg, None, 0.0)
+        # pass A on the owned cells, in three z ranges (as an overlapped schedule issues them); one of them transposed
+        ob = L.own_box()
+        z0, z1 = ob[4], ob[5]
+        be.pass_a(st, ob[:4] + (z0, z0 + 2), w_reg, None, 0.0)
+        be.pass_a(st, ob[:4] + (z1 - 3, z1), w_reg, None, 0.0, transposed=True)
+        be.pass_a(st, ob[:4] + (z0 + 2, z1 - 3), w_reg, None, 0.0)
         nU_own = L.owned(st.nabla_U)[..., :3]
-        assert torch.equal(nU_own.contiguous().view(torch.int32), nU_f[L.z0:L.z1][..., :3].contiguous().view(torch.int32))
-        st.nabla_U[..., :3] = L.take(nU_f)[..., :3]  # the exchange: 4 halo planes of nabla_U from their owners
+        assert torch.equal(nU_own.contiguous().view(torch.int32), L.owned_global(nU_f)[..., :3].contiguous().view(torch.int32))
+        st.nabla_U[..., :3] = L.take(nU_f)[..., :3]  # the exchange: halo cells of nabla_U from their owners
         slots = torch.zeros(256, dtype=torch.int32, device="cuda")
-        b_first, b_last = (L.own_lo - 1 if L.lo else L.own_lo), (L.own_hi + 1 if L.hi else L.own_hi)
-        mid = (b_first + b_last) // 2
-        be.pass_b(st, mid, b_last, slots, S, alpha, None, 0.0)
-        be.pass_b(st, b_first, mid, slots, S, alpha, None, 0.0)
+        for box, tr in L.pass_b_boxes():
+            mid = (box[4] + box[5]) // 2
+            be.pass_b(st, box[:4] + (mid, box[5]), slots, S, alpha, None, 0.0, transposed=tr)
+            be.pass_b(st, box[:4] + (box[4], mid), slots, S, alpha, None, 0.0, transposed=tr)
         be.end(st)
         torch.cuda.synchronize()
-        lo, hi = max(L.z0 - 1, 0), min(L.z1 + 1, Z)
-        a, b = lo - L.zbase, hi - L.zbase
-        assert torch.equal(psi_l[a:b].view(torch.int32), psi_f[lo:hi].view(torch.int32))
-        assert torch.equal(pnp_l[a:b].view(torch.int32), pnp_f[lo:hi].view(torch.int32))
+        # owned cells and the one-cell shell along each axis (cells on tile edges / corners are not part of the contract)
+        ref_psi, ref_pnp = L.take(psi_f), L.take(pnp_f)
+        checks = [L.own_box()]
+        for a in range(3):
+            for side, has in ((0, L.lo3[a]), (1, L.hi3[a])):
+                if has:
+                    bx = list(L.own_box())
+                    bx[2 * a], bx[2 * a + 1] = (L.o0[a] - 1, L.o0[a]) if side == 0 else (L.o1[a], L.o1[a] + 1)
+                    checks.append(tuple(bx))
+        assert len(checks) == 1 + sum(1 for a in range(3) for v in (L.lo3[a], L.hi3[a]) if v)
+        for bx in checks:
+            cut = lambda t: t[bx[4]:bx[5], bx[2]:bx[3], bx[0]:bx[1]].contiguous().view(torch.int32)  # noqa: E731
+            assert torch.equal(cut(psi_l), cut(ref_psi)), (r, bx)
+            assert torch.equal(cut(pnp_l), cut(ref_pnp)), (r, bx)
         m_tiles = max(m_tiles, tiled._sqrt_rd(int(slots.max().cpu().numpy().view(np.uint32))))
     assert m_tiles == m_full
+
+
+def test_tile_message_pack_unpack(ops):
+    """sobfu_hip_tile3_pack / unpack: the send boxes of a tile, packed and scattered into the matching recv boxes of its
+    neighbours, reproduce the full field in every halo cell a message covers (2 x 2 x 2 and an interior tile of 3 x 3 x 3)"""
+    import ctypes as C
+
+    from sobfu_amd import _lib, tiled
+
+    lib = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dims, grid in (((40, 24, 36), (2, 2, 2)), ((36, 30, 33), (3, 3, 3))):
+        X, Y, Z = dims
+        full = torch.rand((Z, Y, X, 3), device="cuda")
+        lays = [tiled.TileLayout(dims, grid, r) for r in range(grid[0] * grid[1] * grid[2])]
+        for L in lays:
+            field = torch.zeros(L.local_shape(3), device="cuda")
+            L.owned(field).copy_(L.owned_global(full))
+            for peer, _, rbox in L.messages():
+                Lp = lays[peer]
+                back = [m for m in Lp.messages() if m[0] == L.rank][0]
+                src = Lp.take(full).clone().contiguous()
+                n = (back[1][1] - back[1][0]) * (back[1][3] - back[1][2]) * (back[1][5] - back[1][4])
+                buf = torch.zeros(3 * n, device="cuda")
+                _lib.check(lib.sobfu_hip_tile3_pack(C.c_void_p(src.data_ptr()), *Lp.L, C.c_void_p(buf.data_ptr()), (C.c_int * 6)(*back[1]), 1, st), "pack")
+                _lib.check(lib.sobfu_hip_tile3_unpack(C.c_void_p(field.data_ptr()), *L.L, C.c_void_p(buf.data_ptr()), (C.c_int * 6)(*rbox), 1, st), "unpack")
+            want = L.take(full)
+            covered = torch.zeros(L.local_shape(), dtype=torch.bool, device="cuda")
+            L.owned(covered)[...] = True
+            for _, _, rb in L.messages():
+                covered[rb[4]:rb[5], rb[2]:rb[3], rb[0]:rb[1]] = True
+            assert torch.equal(field[covered], want[covered])
+            assert float(field[~covered].abs().max() if (~covered).any() else 0.0) == 0.0  # corners stay untouched
+        # all messages of a tile in ONE launch, as the loop issues them
+        L = lays[len(lays) // 2]
+        msgs = L.messages()
+        field = L.take(full).clone().contiguous()
+        cells = [(m[1][1] - m[1][0]) * (m[1][3] - m[1][2]) * (m[1][5] - m[1][4]) for m in msgs]
+        buf = torch.zeros(3 * sum(cells), device="cuda")
+        boxes = (C.c_int * (6 * len(msgs)))(*[v for m in msgs for v in m[1]])
+        _lib.check(lib.sobfu_hip_tile3_pack(C.c_void_p(field.data_ptr()), *L.L, C.c_void_p(buf.data_ptr()), boxes, len(msgs), st), "pack")
+        off = 0
+        for m, n in zip(msgs, cells):
+            sb = m[1]
+            assert torch.equal(buf[3 * off:3 * (off + n)], field[sb[4]:sb[5], sb[2]:sb[3], sb[0]:sb[1]].reshape(-1))
+            off += n
 
 
 # ---------------------------------------------------------------------------------------------------

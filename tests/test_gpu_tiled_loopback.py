@@ -1,8 +1,9 @@
 """N ranks of the NATIVE tiled loop (sobfu_hip_tiled_iterate) on ONE GPU: communicator-less handles, one host thread per
-rank, and an in-process loopback transport (device-to-device copies between the ranks' slabs + a host max) plugged in
-through sobfu_hip_tiled_set_transport.  Everything but RCCL itself -- slab layout, boundary / interior plane ranges, the
-two-range boundary launches, halo widths, ungated pass A, stream and event order -- runs exactly as on N GPUs, and the
-gathered result must equal the single-GPU solve bit for bit."""
+rank, and an in-process loopback transport (device-to-device copies between the ranks' buffers + a host max) plugged in
+through sobfu_hip_tiled_set_transport.  Everything but RCCL itself -- tile layout (z-slabs, x / y splits, 2 x 2 x 2), message
+boxes and their pack / unpack kernels, boundary / interior plane ranges, the multi-box launches with the transposed x shells,
+halo widths, ungated pass A, stream and event order -- runs exactly as on N GPUs, and the gathered result must equal the
+single-GPU solve bit for bit."""
 import ctypes as C
 import threading
 
@@ -13,10 +14,13 @@ pytestmark = pytest.mark.gpu
 
 
 class Loopback:
-    def __init__(self, solvers, X, Y):
-        self.sv, self.N, self.pb = solvers, len(solvers), X * Y * 12
+    """transport of sobfu_hip_tiled_set_transport between rank threads of one process: every rank posts where its messages
+    start, a barrier, every rank copies what its peers posted for it into its receive segments, a barrier"""
+
+    def __init__(self, solvers):
+        self.sv, self.N = solvers, len(solvers)
         self.bar = threading.Barrier(self.N)
-        self.ptr, self.host = [None] * self.N, [None] * self.N
+        self.posted, self.host = [None] * self.N, [None] * self.N
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -26,23 +30,20 @@ class Loopback:
             self.bar.abort()
             raise RuntimeError(f"hip call failed: {rc}")
 
-    def exchange(self, rank, field, planes, stream):
+    def exchange(self, rank, send, recv, msgs, stream):
         try:
-            self._ok(self.hip.hipStreamSynchronize(stream))  # this rank's boundary planes are final
-            self.ptr[rank] = field
+            self._ok(self.hip.hipStreamSynchronize(stream))  # what this rank sends is final
+            self.posted[rank] = {peer: (send + 4 * soff, cnt) for peer, soff, _, cnt in msgs}
             self.bar.wait(timeout=60)
-            L, n = self.sv[rank].layout, planes * self.pb
-            if rank > 0:
-                Lp = self.sv[rank - 1].layout
-                self._ok(self.hip.hipMemcpy(field + (L.own_lo - planes) * self.pb, self.ptr[rank - 1] + (Lp.own_hi - planes) * self.pb, n, 3))
-            if rank < self.N - 1:
-                Ln = self.sv[rank + 1].layout
-                self._ok(self.hip.hipMemcpy(field + L.own_hi * self.pb, self.ptr[rank + 1] + Ln.own_lo * self.pb, n, 3))
+            for peer, _, roff, cnt in msgs:
+                src, n = self.posted[peer][rank]
+                assert n == cnt, (rank, peer, n, cnt)
+                self._ok(self.hip.hipMemcpy(recv + 4 * roff, src, 4 * cnt, 3))
             self._ok(self.hip.hipDeviceSynchronize())
-            self.bar.wait(timeout=60)  # nobody overwrites planes a peer is still copying
+            self.bar.wait(timeout=60)  # nobody overwrites data a peer is still copying
             return 0
         except Exception as e:  # noqa: BLE001
-            print("loopback exchange failed:", e, flush=True)
+            print("loopback exchange failed:", repr(e), flush=True)
             return -1
 
     def allreduce(self, rank, buf, n, stream):
@@ -57,18 +58,32 @@ class Loopback:
             self._ok(self.hip.hipMemcpy(buf, m.ctypes.data, 4 * n, 1))
             return 0
         except Exception as e:  # noqa: BLE001
-            print("loopback allreduce failed:", e, flush=True)
+            print("loopback allreduce failed:", repr(e), flush=True)
             return -1
 
 
-def run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule=None):
+def as_grid(world_or_grid):
+    return (1, 1, world_or_grid) if isinstance(world_or_grid, int) else tuple(world_or_grid)
+
+
+def assemble(solvers, parts):
+    """owned parts of every rank -> the full volume"""
+    X, Y, Z = solvers[0].layout.dims
+    full = np.zeros((Z, Y, X) + parts[0].shape[3:], parts[0].dtype)
+    for s, part in zip(solvers, parts):
+        s.layout.owned_global(full)[...] = part
+    return full
+
+
+def run_world(dims, grid, psi0, pg, pn, n_iters, thr, schedule=None):
     import torch
 
     from sobfu_amd import tiled
 
-    X, Y, Z = dims
-    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr, dry=(world, r)) for r in range(world)]
-    lb = Loopback(solvers, X, Y)
+    grid = as_grid(grid)
+    world = grid[0] * grid[1] * grid[2]
+    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr, dry=(world, r), grid=grid) for r in range(world)]
+    lb = Loopback(solvers)
     for s in solvers:
         s.set_transport(lb.exchange, lb.allreduce)
         if schedule is not None:
@@ -88,7 +103,7 @@ def run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule=None):
                 torch.cuda.current_stream().synchronize()
             out[r] = (done, hist, L.owned(psi_l).cpu().numpy(), L.owned(pnp_l).cpu().numpy())
         except Exception as e:  # noqa: BLE001
-            errs.append((r, e))
+            errs.append((r, repr(e)))
             lb.bar.abort()
 
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
@@ -98,13 +113,19 @@ def run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule=None):
         t.join(timeout=180)
     assert not errs, errs
     assert all(o is not None for o in out)
+    full = (assemble(solvers, [o[2] for o in out]), assemble(solvers, [o[3] for o in out]))
     for s in solvers:
         s.close()
-    return out
+    return out, full
 
 
 @pytest.mark.parametrize("dims,world,split", [((40, 24, 36), 3, None), ((40, 24, 36), 3, "1"), ((33, 17, 16), 4, None), ((20, 12, 120), 2, None),
-                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0"), ((40, 24, 36), 3, "serial"), ((33, 17, 16), 4, "serial")])
+                                               ((70, 33, 23), 2, "1"), ((64, 64, 64), 4, "0"), ((40, 24, 36), 3, "serial"), ((33, 17, 16), 4, "serial"),
+                                               # 3-D tile grids: BASELINE config 4's 2 x 2 x 2, the N = 4 default 1 x 2 x 2, single-axis x / y
+                                               # splits, ragged extents, an interior tile with both neighbours on every axis
+                                               ((40, 24, 36), (2, 2, 2), None), ((64, 64, 64), (2, 2, 2), None), ((33, 17, 16), (1, 2, 2), None),
+                                               ((70, 33, 23), (2, 1, 1), None), ((40, 24, 36), (1, 2, 1), None), ((40, 24, 36), (2, 2, 1), None),
+                                               ((141, 19, 17), (2, 1, 2), None), ((36, 36, 36), (3, 3, 3), None)])
 def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
     import torch
 
@@ -137,9 +158,7 @@ def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
             assert rep.iterations == expect
         else:
             psi_e, pnp_e = psi_r, pnp_r
-        out = run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule)
-        psi_t = np.concatenate([o[2] for o in out], 0)
-        pnp_t = np.concatenate([o[3] for o in out], 0)
+        out, (psi_t, pnp_t) = run_world(dims, world, psi0, pg, pn, n_iters, thr, schedule)
         for done, hist, _, _ in out:
             assert done == expect
             assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), np.asarray(hist_r[:expect], np.float32).view(np.uint32))
@@ -148,9 +167,10 @@ def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
 
 
 class LoopGather:
-    """all_gather of the owned planes between the rank threads of one process (stands in for dist.all_gather)"""
+    """all_gather of the owned cells between the rank threads of one process (stands in for dist.all_gather)"""
 
-    def __init__(self, n):
+    def __init__(self, solvers):
+        self.sv, n = solvers, len(solvers)
         self.parts, self.bar = [None] * n, threading.Barrier(n)
 
     def make(self, rank, layout):
@@ -161,17 +181,20 @@ class LoopGather:
             self.parts[rank] = layout.owned(local).contiguous()
             torch.cuda.current_stream().synchronize()
             self.bar.wait(timeout=60)
-            full = torch.cat(self.parts, 0)
+            X, Y, Z = layout.dims
+            full = torch.empty((Z, Y, X) + tuple(local.shape[3:]), dtype=local.dtype, device=local.device)
+            for s, part in zip(self.sv, self.parts):
+                s.layout.owned_global(full).copy_(part)
             torch.cuda.current_stream().synchronize()
-            self.bar.wait(timeout=60)  # nobody replaces its part while a peer is still concatenating
+            self.bar.wait(timeout=60)  # nobody replaces its part while a peer is still assembling
             return full
 
         return gather
 
 
-@pytest.mark.parametrize("dims,world", [((40, 24, 36), 3), ((33, 17, 16), 4)])
+@pytest.mark.parametrize("dims,world", [((40, 24, 36), 3), ((33, 17, 16), 4), ((40, 24, 36), (2, 2, 2)), ((33, 17, 16), (1, 2, 2))])
 def test_tiled_frame_estimate_psi_loopback(dims, world):
-    """A whole frame on slabs (iterations, all-gather psi -> 48-sweep inverse, all-gather phi_global -> canonical warp) =
+    """A whole frame on tiles (iterations, all-gather psi -> 48-sweep inverse, all-gather phi_global -> canonical warp) =
     the single-GPU Solver::estimate_psi, bit for bit, on every rank's owned planes."""
     import torch
 
@@ -191,8 +214,10 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     ref.estimate_psi(torch.from_numpy(pg).cuda(), pgi_r, torch.from_numpy(pn).cuda(), pnp_r, psi_r, inv_r)
     ref.close()
 
-    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(world, r)) for r in range(world)]
-    lb, lg = Loopback(solvers, X, Y), LoopGather(world)
+    grid = as_grid(world)
+    world = grid[0] * grid[1] * grid[2]
+    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(world, r), grid=grid) for r in range(world)]
+    lb, lg = Loopback(solvers), LoopGather(solvers)
     for s in solvers:
         s.set_transport(lb.exchange, lb.allreduce)
     pn_d = torch.from_numpy(pn).cuda()
@@ -220,9 +245,9 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     for t in th:
         t.join(timeout=180)
     assert not errs, errs
+    cat = lambda i: assemble(solvers, [o[i] for o in out])  # noqa: E731
     for s in solvers:
         s.close()
-    cat = lambda i: np.concatenate([o[i] for o in out], 0)  # noqa: E731
     assert all(o[0] == n_iters for o in out)
     assert np.array_equal(cat(1)[..., :3].view(np.uint32), psi_r.cpu().numpy()[..., :3].view(np.uint32))
     assert np.array_equal(cat(2).view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
@@ -230,9 +255,9 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     assert np.array_equal(cat(4).view(np.uint32), pgi_r.cpu().numpy().view(np.uint32))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, (2, 2, 2), (1, 2, 2)])
 def test_tiled_fusion_frames_loopback(world):
-    """BASELINE config 1 (64^3, translating sphere, three frames) through TiledFusion on N slabs = the same frames through the
+    """BASELINE config 1 (64^3, translating sphere, three frames) through TiledFusion on N tiles = the same frames through the
     single-GPU launchers: phi_global after every frame and psi at the end, bit for bit."""
     import torch
 
@@ -267,8 +292,10 @@ def test_tiled_fusion_frames_loopback(world):
         ref_pg.append(pg.cpu().numpy().copy())
     sv.close()
 
-    solvers = [tiled.NativeTiledSolver(dims, dry=(world, r), **kw) for r in range(world)]
-    lb, lg = Loopback(solvers, dims[0], dims[1]), LoopGather(world)
+    grid = as_grid(world)
+    world = grid[0] * grid[1] * grid[2]
+    solvers = [tiled.NativeTiledSolver(dims, dry=(world, r), grid=grid, **kw) for r in range(world)]
+    lb, lg = Loopback(solvers), LoopGather(solvers)
     for s in solvers:
         s.set_transport(lb.exchange, lb.allreduce)
     out, errs = [None] * world, []
@@ -294,11 +321,11 @@ def test_tiled_fusion_frames_loopback(world):
     for t in th:
         t.join(timeout=240)
     assert not errs, errs
+    for n in range(3):
+        got = assemble(solvers, [o[0][n] for o in out])
+        assert np.array_equal(got.view(np.uint32), ref_pg[n].view(np.uint32)), n
+    assert np.array_equal(assemble(solvers, [o[1] for o in out])[..., :3].view(np.uint32), psi.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(assemble(solvers, [o[2] for o in out])[..., :3].view(np.uint32), psi_inv.cpu().numpy()[..., :3].view(np.uint32))
     for s in solvers:
         s.close()
-    for n in range(3):
-        got = np.concatenate([o[0][n] for o in out], 0)
-        assert np.array_equal(got.view(np.uint32), ref_pg[n].view(np.uint32)), n
-    assert np.array_equal(np.concatenate([o[1] for o in out], 0)[..., :3].view(np.uint32), psi.cpu().numpy()[..., :3].view(np.uint32))
-    assert np.array_equal(np.concatenate([o[2] for o in out], 0)[..., :3].view(np.uint32), psi_inv.cpu().numpy()[..., :3].view(np.uint32))
     assert float(np.abs(psi.cpu().numpy()[..., 0] - np.arange(64)[None, None, :]).max()) > 1e-3  # the solves really moved psi

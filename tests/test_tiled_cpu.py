@@ -1,5 +1,6 @@
-"""Multi-GPU path on CPU: world-size-2/3 gloo runs of sobfu_amd.tiled (slab decomposition + halo exchange + max-norm
-all-reduce + device-gate semantics) must reproduce the single-process oracle solve bit for bit."""
+"""Multi-GPU path on CPU: world-size-2/3/4 gloo runs of sobfu_amd.tiled (tile decomposition -- z-slabs, x / y splits, 2-D grids
+with edge strips -- + halo exchange + max-norm all-reduce + device-gate semantics) must reproduce the single-process oracle
+solve bit for bit."""
 import os
 import socket
 import subprocess
@@ -17,10 +18,10 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, thr, tmp_path):
-    out = str(tmp_path / f"tiled_{world}_{thr}.npz")
+def _run(world, thr, tmp_path, grid=""):
+    out = str(tmp_path / f"tiled_{world}_{thr}_{grid}.npz")
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_tiled_worker.py"), str(r), str(world), port, out, str(thr)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_tiled_worker.py"), str(r), str(world), port, out, str(thr)] + ([grid] if grid else []),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
@@ -52,6 +53,29 @@ def test_slabs_match_single_process(oracle, tmp_path, world):
     assert np.array_equal(got["norms2"].view(np.uint32), np.ascontiguousarray(r2["trace"][:, 2]).view(np.uint32))
 
 
+@pytest.mark.parametrize("grid", ["2x1x1", "1x2x1", "2x2x1", "1x2x2"])
+def test_tiles_match_single_process(oracle, tmp_path, grid):
+    """x / y splits (non-contiguous faces, the transposed x shell) and 2-D grids (edge strips between diagonal neighbours)"""
+    world = int(np.prod([int(v) for v in grid.split("x")]))
+    got = _run(world, -1.0, tmp_path, grid)
+    psi, r1, r2 = _reference(oracle, -1.0)
+    assert int(got["done"]) == r1["iters"] == 6 and int(got["done2"]) == 3
+    assert np.array_equal(got["psi"].view(np.uint32), psi.view(np.uint32))
+    assert np.array_equal(got["pnp"].view(np.uint32), r2["phi_n_psi"].view(np.uint32))
+    assert np.array_equal(got["norms"].view(np.uint32), np.ascontiguousarray(r1["trace"][:, 2]).view(np.uint32))
+    assert np.array_equal(got["norms2"].view(np.uint32), np.ascontiguousarray(r2["trace"][:, 2]).view(np.uint32))
+
+
+def test_tiles_convergence_gate(oracle, tmp_path):
+    psi0, r_free, _ = _reference(oracle, -1.0)
+    tr = r_free["trace"][:, 2]
+    thr = float(np.float32((tr[2] + tr[3]) / 2)) if tr[3] < tr[2] else float(tr.min())
+    got = _run(2, thr, tmp_path, "2x1x1")
+    psi, r1, r2 = _reference(oracle, thr)
+    assert r1["iters"] < 6 and int(got["done"]) == r1["iters"] and int(got["done2"]) == r2["iters"]
+    assert np.array_equal(got["psi"].view(np.uint32), psi.view(np.uint32))
+
+
 def test_slabs_convergence_gate(oracle, tmp_path):
     """positive threshold: the all-reduced max-norm gate must stop every rank at the reference's iteration"""
     psi0, r_free, _ = _reference(oracle, -1.0)
@@ -63,6 +87,38 @@ def test_slabs_convergence_gate(oracle, tmp_path):
     assert int(got["done"]) == r1["iters"] and int(got["done2"]) == r2["iters"]
     assert np.array_equal(got["psi"].view(np.uint32), psi.view(np.uint32))
     assert np.array_equal(got["pnp"].view(np.uint32), r2["phi_n_psi"].view(np.uint32))
+
+
+def test_tile_layout_properties():
+    """every cell is owned exactly once; messages pair up (my send box has the shape of the peer's recv box for me)"""
+    from sobfu_amd.tiled import TileLayout, default_grid, parse_grid
+
+    assert default_grid(8) == (2, 2, 2) and default_grid(4) == (1, 2, 2) and default_grid(2) == (1, 1, 2) and default_grid(1) == (1, 1, 1)
+    assert default_grid(6) == (1, 2, 3) and parse_grid("2x1x4", 8) == (2, 1, 4)
+    with pytest.raises(ValueError):
+        parse_grid("2x2x2", 4)
+    dims = (21, 17, 26)
+    for grid in ((2, 2, 2), (1, 2, 2), (3, 1, 2), (2, 1, 1), (1, 1, 5)):
+        world = grid[0] * grid[1] * grid[2]
+        lays = [TileLayout(dims, grid, r) for r in range(world)]
+        count = np.zeros(dims[::-1], np.int32)
+        for L in lays:
+            L.owned_global(count)[...] += 1
+            assert all(L.L[a] == L.g1[a] - L.g0[a] + L.lo3[a] + L.hi3[a] and L.base[a] == L.g0[a] - L.lo3[a] for a in range(3))
+            assert L.take(count).shape == L.local_shape()
+        assert (count == 1).all()
+        for L in lays:
+            peers = [m[0] for m in L.messages()]
+            assert len(set(peers)) == len(peers)  # one message per neighbour
+            for peer, sb, rb in L.messages():
+                back = [m for m in lays[peer].messages() if m[0] == L.rank]
+                assert len(back) == 1
+                shape = lambda b: (b[1] - b[0], b[3] - b[2], b[5] - b[4])  # noqa: E731
+                assert shape(sb) == shape(back[0][2]) and shape(rb) == shape(back[0][1])
+    assert len(TileLayout((64, 64, 64), (2, 2, 2), 0).messages()) == 6  # 3 faces + 3 edges, no corner
+    assert len(TileLayout((64, 64, 64), (3, 3, 3), 13).messages()) == 18
+    with pytest.raises(ValueError):
+        TileLayout((6, 64, 64), (2, 1, 1), 0)
 
 
 def test_layout_properties():

@@ -1,0 +1,39 @@
+"""Compute-side cost of one rank's share of the 256^3 solve in the NATIVE tiled loop (sobfu_hip_tiled_iterate), timed on one
+GPU with communicator-less handles: every kernel launch (pass A, message pack / unpack, pass B with its shells) and stream /
+event dependency of a middle rank's schedule, no peers -- the numbers exclude the exchange and the all-reduce themselves.
+
+    python tools/tile_time_native.py                 # 1x1x1, z-slabs 1x1x{2,4,8}, 1x2x2, 2x2x2, 1x2x4
+    TILE_GRIDS=2x2x2,1x1x8 python tools/tile_time_native.py
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from sobfu_amd import ops, tiled
+dim = int(os.environ.get("TILE_DIM", "256"))
+P = bench.boxing_params(dim); dims = P["dims"]
+c0, c1, r = bench.sphere_pair(P)
+pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
+ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r); ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
+grids = os.environ.get("TILE_GRIDS", "1x1x1,1x1x2,1x1x4,1x1x8,1x2x2,2x2x2,1x2x4")
+ref = None
+for g in grids.split(","):
+    grid = tuple(int(v) for v in g.split("x"))
+    world = grid[0] * grid[1] * grid[2]
+    lays = [tiled.TileLayout(dims, grid, q) for q in range(world)]
+    rank = max(range(world), key=lambda q: (lays[q].L[0] * lays[q].L[1] * lays[q].L[2], q))  # a tile with the most halos
+    for thr in (-1.0, 1e-10):
+        for sched in ((3,) if not lays[rank].slab else (0, 3)):
+            sv = tiled.NativeTiledSolver(dims, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=thr, dry=(world, rank), grid=grid)
+            sv.set_schedule(sched)
+            L = sv.layout
+            pg = L.take(pg_full).clone().contiguous(); pnp = sv.new_local(2); psi = sv.identity_psi()
+            sv.iterate(pg, pn_full, pnp, psi, 50)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            sv.iterate(pg, pn_full, pnp, psi, 300)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 300
+            if ref is None: ref = dt
+            own = tuple(L.g1[a] - L.g0[a] for a in range(3))
+            print(f"grid {g} rank {rank} thr={thr:g} schedule={'serial' if sched == 3 else 'heuristic (overlapped)'}: owns {own}, local {L.L}: "
+                  f"{1e6 * dt:.1f} us/iteration compute side -> bound {ref / dt:.2f}x of {g.split('x')[0]}-GPU... single-GPU {1e6 * ref:.1f} us", flush=True)
+            sv.close()
