@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(256) update_psi_kernel(float4* __restrict__ ps
 // Part 2: fused two-pass iteration
 // ============================================================================================================
 
-constexpr int TX = 64;  // tile width = one wave of consecutive x
+#ifndef SOBFU_TX
+#define SOBFU_TX 64
+#endif
+constexpr int TX = SOBFU_TX;  // tile width in lanes: 64 = one wave per tile row (32: a wave covers two rows of a 32-wide tile)
 
 // --- storage formats ------------------------------------------------------------------------------------------------
 // API format (COMPACT = false): the reference's layouts -- psi / nabla_U float4 (w == 0), TSDF volumes float2.
@@ -150,6 +153,36 @@ SOBFU_DEV void stv_nt(void* base, size_t i, const float4& v) {
         __builtin_nontemporal_store(o, (v4f*) base + i);
     }
 }
+// The same accesses as (uniform plane pointer) + (32-bit byte offset of the lane's cell in the plane): the address is a scalar base
+// plus one 32-bit lane register (global_load ... v_off, s[base]) instead of a 64-bit lane address per stream.
+template <bool C>
+SOBFU_DEV float4 ldvb(const char* plane_ptr, uint32_t byte_off, bool nt = false) {
+    const char* p = plane_ptr + (size_t) byte_off;
+    if (C) {
+        v3f v = nt ? __builtin_nontemporal_load((const v3f_u*) p) : *(const v3f_u*) p;
+        return make_float4(v.x, v.y, v.z, 0.f);
+    }
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if (nt) {
+        v4f v = __builtin_nontemporal_load((const v4f*) p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *(const float4*) p;
+}
+template <bool C>
+SOBFU_DEV void stvb(char* plane_ptr, uint32_t byte_off, const float4& v, bool nt = false) {
+    char* p = plane_ptr + (size_t) byte_off;
+    if (C) {
+        v3f o = {v.x, v.y, v.z};
+        if (nt) __builtin_nontemporal_store(o, (v3f_u*) p);
+        else *(v3f_u*) p = o;
+    } else {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f o = {v.x, v.y, v.z, v.w};
+        if (nt) __builtin_nontemporal_store(o, (v4f*) p);
+        else *(v4f*) p = o;
+    }
+}
 template <bool C>
 SOBFU_DEV float ldt(const void* base, size_t i) {  // tsdf of voxel i
     return C ? ((const float*) base)[i] : ((const float2*) base)[i].x;
@@ -162,6 +195,21 @@ SOBFU_DEV float interp_tsdf_only(const float* __restrict__ v, const Dims& d, flo
     const size_t dy = (size_t) (b.h - b.g) * sy, dz = (size_t) (c.h - c.g) * sz;
     float hhh = pg[a.h + dy + dz], hhg = pg[a.h + dy], hgh = pg[a.h + dz], hgg = pg[a.h];
     float ghh = pg[a.g + dy + dz], ghg = pg[a.g + dy], ggh = pg[a.g + dz], ggg = pg[a.g];
+    return lerp1(lerp1(lerp1(hhh, hhg, c.t), lerp1(hgh, hgg, c.t), b.t), lerp1(lerp1(ghh, ghg, c.t), lerp1(ggh, ggg, c.t), b.t), a.t);
+}
+
+// The same sampler with 32-bit BYTE offsets from the (uniform) volume base: one scalar base + a 32-bit lane offset per corner
+// (global_load_dword v, v_off, s[base]) instead of eight 64-bit lane addresses -- ~20 VALU fewer per voxel.  Valid while the
+// tsdf-only volume is < 4 GiB (< 2^30 voxels); same loads, same lerp chain, same bits.
+SOBFU_DEV float interp_tsdf_only32(const float* __restrict__ v, const Dims& d, float px, float py, float pz) {
+    const Tri a = tri_setup(px, d.x), b = tri_setup(py, d.y), c = tri_setup(pz, d.z);
+    const uint32_t sy = 4u * (uint32_t) d.x, sz = sy * (uint32_t) d.y;
+    const uint32_t o  = 4u * (uint32_t) a.g + sy * (uint32_t) b.g + sz * (uint32_t) c.g;
+    const uint32_t ox = a.h != a.g ? 4u : 0u, oy = b.h != b.g ? sy : 0u, oz = c.h != c.g ? sz : 0u;
+    const char* base = (const char*) v;
+    auto at = [&](uint32_t off) { return *(const float*) (base + (size_t) off); };
+    const float hhh = at(o + ox + oy + oz), hhg = at(o + ox + oy), hgh = at(o + ox + oz), hgg = at(o + ox);
+    const float ghh = at(o + oy + oz), ghg = at(o + oy), ggh = at(o + oz), ggg = at(o);
     return lerp1(lerp1(lerp1(hhh, hhg, c.t), lerp1(hgh, hgg, c.t), b.t), lerp1(lerp1(ghh, ghg, c.t), lerp1(ggh, ggg, c.t), b.t), a.t);
 }
 
@@ -313,7 +361,7 @@ struct PassAArgs {
 template <int RPT, int WY, bool COMPACT, bool TRANSPOSABLE>
 __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
     constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
-    constexpr int NXH = (2 * TY + 63) / 64;  // wave-tasks for the two lane-halo columns
+    constexpr int NXH = (2 * TY + TX - 1) / TX;  // row-tasks for the two lane-halo columns
     constexpr int NTASK = 2 + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 t_psi[2][LH][LW + 2];  // {psi.xyz, F = (phi_n o psi).tsdf} -- psi.w is never read
 
@@ -342,7 +390,7 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
         if (task == 0) { lr = 0; lc = lx + 1; }
         else if (task == 1) { lr = LH - 1; lc = lx + 1; }
         else {
-            int e = (task - 2) * 64 + lx;  // 0 .. 2*TY-1
+            int e = (task - 2) * TX + lx;  // 0 .. 2*TY-1
             h_on[k] = h_on[k] && e < 2 * TY;
             lr = 1 + (e >> 1);
             lc = (e & 1) ? LW - 1 : 0;
@@ -491,16 +539,29 @@ struct PassBArgs {
     void* psi_out;  // where the updated psi goes: == psi (in place) or the other half of a ping-pong pair (native tiled loop)
 };
 
+#ifndef SOBFU_HLEAD
+#define SOBFU_HLEAD 3  // planes the halo requests of pass B run ahead (0: one plane ahead, straight from registers)
+#endif
+#ifndef SOBFU_IDX32
+#define SOBFU_IDX32 1  // 1: 32-bit byte offsets for the phi_n corner gather of pass B (volumes below 2^30 voxels)
+#endif
+#ifndef SOBFU_PK
+#define SOBFU_PK 1  // 1: packed-fp32 tap arithmetic (v_pk_mul_f32 / v_pk_add_f32) in pass B
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef SOBFU_MINW_B
 #define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
 #endif
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool TRANSPOSABLE>
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool TRANSPOSABLE, bool IDX32 = false>
 __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
-    constexpr int NXH = (2 * R * TY + 63) / 64;  // wave-tasks for the 2R lane-halo columns
+    constexpr int NXH = (2 * R * TY + TX - 1) / TX;  // row-tasks for the 2R lane-halo columns
     constexpr int NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 tile[2][LH][LW + 2];
     __shared__ uint32_t s_max[WY];
+#if SOBFU_HLEAD
+    __shared__ P3 hfifo[SOBFU_HLEAD][NTASK * TX];  // 12-byte entries: with the 32 KB tile, 3 workgroups still fit a CU's 160 KB
+#endif
 
     const GateRegs gate = gate_load(a.prev_slots, a.prev_rows);
 
@@ -511,13 +572,18 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
     const int u = u0 + lx, uc = min(u, tg.DU - 1);
     const size_t plane = (size_t) d.x * d.y, su = (size_t) tg.su, sv = (size_t) tg.sv;
 
-    size_t off[RPT];
+    // in-plane BYTE offsets of the lane's cells (a plane of a vector field is < 4 GiB: checked at launch); every plane base is a
+    // uniform 64-bit value, so an address costs one scalar pair + one lane register
+    constexpr uint32_t VB = COMPACT ? 12u : 16u, TB = COMPACT ? 4u : 8u;  // bytes per cell of a vector field / a TSDF volume
+    uint32_t off[RPT], offT[RPT];  // ... in a vector field / in a TSDF volume
     bool mine[RPT];  // the cell is stored by this launch / belongs to this rank (x, y part of the test)
     bool owned[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int v = v0 + wy * RPT + r;
-        off[r]      = (size_t) uc * su + sv * (size_t) min(v, tg.DV - 1);
+        const uint32_t cell = (uint32_t) ((size_t) uc * su + sv * (size_t) min(v, tg.DV - 1));
+        off[r]      = cell * VB;
+        offT[r]     = cell * TB;
         mine[r]     = u < tg.u_hi && v < tg.v_hi;
         const int x = tg.tr ? v : u, y = tg.tr ? u : v;
         owned[r]    = x >= a.own[0] && x < a.own[1] && y >= a.own[2] && y < a.own[3];
@@ -525,7 +591,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 
     // halo tasks: 0..R-1 rows above, R..2R-1 rows below, then lane-halo cells (2R per tile row)
     int h_lr[TPW], h_lc[TPW];
-    size_t h_off[TPW];
+    uint32_t h_off[TPW];
     bool h_on[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
@@ -535,7 +601,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         if (task < R) { lr = task; lc = lx + R; }
         else if (task < 2 * R) { lr = TY + task; lc = lx + R; }  // TY + R + (task - R)
         else {
-            int e = (task - 2 * R) * 64 + lx;  // 0 .. 2R*TY-1
+            int e = (task - 2 * R) * TX + lx;  // 0 .. 2R*TY-1
             h_on[k] = h_on[k] && e < 2 * R * TY;
             int row = e / (2 * R), c = e % (2 * R);
             lr = R + row;
@@ -544,46 +610,105 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         h_lr[k] = lr;
         h_lc[k] = lc;
         int gu = min(max(u0 - R + lc, 0), tg.DU - 1), gv = min(max(v0 - R + lr, 0), tg.DV - 1);
-        h_off[k] = (size_t) gu * su + (size_t) gv * sv;
+        h_off[k] = (uint32_t) ((size_t) gu * su + (size_t) gv * sv) * VB;
     }
 
+    float4 hq[TPW];
+#if SOBFU_HLEAD
+    // Halo cells run HLEAD planes ahead of the plane they are staged for, like the main cells of the z pipeline (which must be 4
+    // ahead): a neighbour tile's halo request then meets the owner's own request for the same lines in the L2 instead of coming
+    // 3 plane-steps (~5 MB of traffic through a 4 MB L2) later -- 86 of the 111 MB pass B read beyond its minimum at 256^3 were
+    // halo lines fetched twice (PMC attribution).  In between a cell waits in a per-lane LDS FIFO (only its own lane
+    // ever touches an entry: no barrier involved).  Planes zb+1 .. of the first steps are requested -- and parked -- before the
+    // z pipeline's seven planes are, so that their registers are free again by then.
+    {
+        float4 hpre[TPW][SOBFU_HLEAD - 1];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+            if (h_on[k]) {
+#pragma unroll
+                for (int p = 1; p < SOBFU_HLEAD; ++p) hpre[k][p - 1] = ldvb<COMPACT>((const char*) a.nU + (size_t) min(zb + p, d.z - 1) * plane * VB, h_off[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+            if (h_on[k]) {
+#pragma unroll
+                for (int p = 1; p < SOBFU_HLEAD; ++p) {
+                    P3& e = hfifo[(zb + p) % SOBFU_HLEAD][(wy + k * WY) * TX + lx];
+                    e.x = hpre[k][p - 1].x; e.y = hpre[k][p - 1].y; e.z = hpre[k][p - 1].z;
+                }
+            }
+    }
+#endif
     // z register pipeline q[r][0..6] = planes clamp(z-3 .. z+3)  (clamp-to-edge, solver.cu:396-424)
     float4 q[RPT][7];
-    float4 hq[TPW];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const size_t zo = (size_t) min(max(zb - 3 + k, 0), d.z - 1) * plane;
+        const char* nUz = (const char*) a.nU + (size_t) min(max(zb - 3 + k, 0), d.z - 1) * plane * VB;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) q[r][k] = ldv<COMPACT>(a.nU, zo + off[r]);
+        for (int r = 0; r < RPT; ++r) q[r][k] = ldvb<COMPACT>(nUz, off[r]);
     }
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
-        if (h_on[k]) hq[k] = ldv<COMPACT>(a.nU, (size_t) zb * plane + h_off[k]);
+        if (h_on[k]) hq[k] = ldvb<COMPACT>((const char*) a.nU + (size_t) zb * plane * VB, h_off[k]);
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
+#if SOBFU_HLEAD
+    int hslot = zb % SOBFU_HLEAD;  // FIFO slot of plane z
+#endif
 
     float msq = 0.f;
     for (int z = zb; z < ze; ++z) {
         const int buf = (z - zb) & 1;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) tile[buf][wy * RPT + r + R][lx + R] = q[r][3];
+#if SOBFU_HLEAD
+        const int hprev = hslot == 0 ? SOBFU_HLEAD - 1 : hslot - 1;  // slot of plane z-1 == slot of plane z-1+HLEAD
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+            if (h_on[k]) {
+                const int hi = (wy + k * WY) * TX + lx;
+                if (z == zb) {  // plane zb's halo came straight from the prologue's request
+                    tile[buf][h_lr[k]][h_lc[k]] = hq[k];
+                } else {
+                    const P3 e = hfifo[hslot][hi];
+                    tile[buf][h_lr[k]][h_lc[k]] = make_float4(e.x, e.y, e.z, 0.f);
+                    if (z - 1 + SOBFU_HLEAD < ze) {  // the cell requested during the previous step (plane z-1+HLEAD) takes the slot plane z-1 left
+                        P3& w = hfifo[hprev][hi];
+                        w.x = hq[k].x; w.y = hq[k].y; w.z = hq[k].z;
+                    }
+                }
+            }
+        hslot = hslot + 1 == SOBFU_HLEAD ? 0 : hslot + 1;
+#else
 #pragma unroll
         for (int k = 0; k < TPW; ++k)
             if (h_on[k]) tile[buf][h_lr[k]][h_lc[k]] = hq[k];
+#endif
 
         const size_t zcur = (size_t) z * plane;
         float4 pv[RPT], nq[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) pv[r] = SOBFU_NT >= 2 ? ldv_nt<COMPACT>(a.psi, zcur + off[r]) : ldv<COMPACT>(a.psi, zcur + off[r]);
+        for (int r = 0; r < RPT; ++r) pv[r] = ldvb<COMPACT>((const char*) a.psi + zcur * VB, off[r], SOBFU_NT >= 2);
         if (z + 1 < ze) {
-            const size_t z4 = (size_t) min(z + 4, d.z - 1) * plane, z1 = (size_t) (z + 1) * plane;
+            const char* nU4 = (const char*) a.nU + (size_t) min(z + 4, d.z - 1) * plane * VB;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) nq[r] = ldv<COMPACT>(a.nU, z4 + off[r]);
+            for (int r = 0; r < RPT; ++r) nq[r] = ldvb<COMPACT>(nU4, off[r]);
+#if !SOBFU_HLEAD
+            const char* nU1 = (const char*) a.nU + (size_t) (z + 1) * plane * VB;
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) hq[k] = ldv<COMPACT>(a.nU, z1 + h_off[k]);
+                if (h_on[k]) hq[k] = ldvb<COMPACT>(nU1, h_off[k]);
+#endif
         }
+#if SOBFU_HLEAD
+        if (z + SOBFU_HLEAD < ze) {
+            const char* nUh = (const char*) a.nU + (size_t) (z + SOBFU_HLEAD) * plane * VB;
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (h_on[k]) hq[k] = ldvb<COMPACT>(nUh, h_off[k]);
+        }
+#endif
         __syncthreads();
-
         // row-axis taps outside this lane's strip
         float4 yt[R], yb[R];
 #pragma unroll
@@ -595,6 +720,29 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         for (int r = 0; r < RPT; ++r) {
             // the lane-axis sum (l*) and the row-axis sum (r*) are the x and y convolutions, or y and x in a transposed box:
             // (Sx + Sy) is commutative, so the result is the same either way
+#if SOBFU_PK
+            // packed fp32 math: the {x, y} and {z, w} halves of a cell are adjacent register pairs (ds_read_b128), so each tap is
+            // 2 v_pk_mul_f32 + 2 v_pk_add_f32 instead of 3 + 3 scalar ops (the w lane rides along; products are not contracted)
+            v2f l01 = {0.f, 0.f}, l23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, z01 = {0.f, 0.f}, z23 = {0.f, 0.f};
+#pragma unroll
+            for (int j = -R; j <= R; ++j) {
+                const v2f s2 = {a.S.s[R - j], a.S.s[R - j]};
+                const float4 vl = (j == 0) ? q[r][3] : tile[buf][wy * RPT + r + R][lx + R + j];
+                l01 += v2f{vl.x, vl.y} * s2;
+                l23 += v2f{vl.z, vl.w} * s2;
+                const int rr = r + j;
+                const float4 vr = rr < 0 ? yt[rr + R < 0 ? 0 : (rr + R > R - 1 ? R - 1 : rr + R)]
+                                         : (rr >= RPT ? yb[rr - RPT > R - 1 ? R - 1 : (rr - RPT < 0 ? 0 : rr - RPT)]
+                                                      : q[rr < 0 ? 0 : (rr >= RPT ? RPT - 1 : rr)][3]);
+                r01 += v2f{vr.x, vr.y} * s2;
+                r23 += v2f{vr.z, vr.w} * s2;
+                const float4 vz = q[r][3 + j];
+                z01 += v2f{vz.x, vz.y} * s2;
+                z23 += v2f{vz.z, vz.w} * s2;
+            }
+            const v2f t01 = (l01 + r01) + z01;
+            float tx = t01.x, ty = t01.y, tz = (l23.x + r23.x) + z23.x;
+#else
             float slx = 0.f, sly = 0.f, slz = 0.f, srx = 0.f, sry = 0.f, srz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
 #pragma unroll
             for (int j = -R; j <= R; ++j) {
@@ -615,9 +763,9 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
                 szy += vz.y * s;
                 szz += vz.z * s;
             }
-            // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)  -- explicit v_pk_mul/add pairing of the
-            // taps was tried and is not faster (pass B 167 us either way), so the loop stays scalar
+            // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)
             float tx = (slx + srx) + szx, ty = (sly + sry) + szy, tz = (slz + srz) + szz;
+#endif
             // update_psi_kernel (solver.cu:64-67)
             float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
             float4 p  = pv[r];
@@ -626,14 +774,18 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             p.z -= uu.z;
             if (mine[r]) {
                 if (owned[r] && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
-                const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
-                if (SOBFU_NT >= 1) stv_nt<COMPACT>(a.psi_out, i, p);
-                else stv<COMPACT>(a.psi_out, i, p);
-                if (WRITE_UPDATES) a.updates[i] = uu;
+                // inside the box no clamp was active: off[r] is the cell itself
+                stvb<COMPACT>((char*) a.psi_out + zcur * VB, off[r], p, SOBFU_NT >= 1);
+                if (WRITE_UPDATES) *(float4*) ((char*) a.updates + zcur * 16 + (size_t) (offT[r] / TB * 16u)) = uu;
                 // apply_kernel (vector_fields.cu:95-98)
-                if (COMPACT && SOBFU_NT >= 1) __builtin_nontemporal_store(interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z), (float*) a.pnp + i);
-                else if (COMPACT) ((float*) a.pnp)[i] = interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
-                else ((float2*) a.pnp)[i] = interp_tsdf((const float2*) a.phi_n, a.pd, p.x, p.y, p.z);
+                if (COMPACT) {
+                    const float f = IDX32 ? interp_tsdf_only32((const float*) a.phi_n, a.pd, p.x, p.y, p.z)
+                                          : interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
+                    float* fo = (float*) ((char*) a.pnp + zcur * TB + (size_t) offT[r]);
+                    if (SOBFU_NT >= 1) __builtin_nontemporal_store(f, fo);
+                    else *fo = f;
+                }
+                else *(float2*) ((char*) a.pnp + zcur * TB + (size_t) offT[r]) = interp_tsdf((const float2*) a.phi_n, a.pd, p.x, p.y, p.z);
             }
         }
 #pragma unroll
@@ -648,7 +800,6 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             q[r][6] = nq[r];
         }
     }
-
     // max ||u||^2 over the voxels this workgroup owns
     uint32_t m = __float_as_uint(msq);
 #pragma unroll
@@ -783,17 +934,21 @@ int pick_zc(int X, int Y, int nz, int ty, int capacity, int refill, const char* 
 // and the workgroup prefix.  Returns the number of workgroups.
 static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env) {
     L.n = 0;
+    auto cells = [](const LaunchBox& s) { return (s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0) ? (double) (s.x1 - s.x0) * (s.y1 - s.y0) * (s.z1 - s.z0) : 0.0; };
     int live = 0;
-    for (int i = 0; i < n; ++i) live += (boxes[i].x1 > boxes[i].x0 && boxes[i].y1 > boxes[i].y0 && boxes[i].z1 > boxes[i].z0) ? 1 : 0;
+    for (int i = 0; i < n; ++i) live += cells(boxes[i]) > 0 ? 1 : 0;
     int total = 0;
     for (int i = 0; i < n && L.n < kMaxBoxes; ++i) {
         const LaunchBox& s = boxes[i];
-        if (!(s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0)) continue;
+        if (cells(s) == 0) continue;
         Box& b = L.b[L.n];
         b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
         b.tr = s.tr ? 1 : 0;
         const int eu = s.tr ? s.y1 - s.y0 : s.x1 - s.x0, ev = s.tr ? s.x1 - s.x0 : s.y1 - s.y0, nz = s.z1 - s.z0;
-        b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, std::max(capacity / live, 1), refill, env);
+        // the chip's workgroup slots are shared equally between the live boxes: a thin shell box is latency-critical (its march
+        // must not be longer than the big box's), so it gets as many short marches as the big one gets long ones
+        const int share = std::max(capacity / live, 1);
+        b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, share, refill, s.tr ? "SOBFU_ZC_T" : env);  // the tuning override leaves shell boxes alone
         L.first[L.n] = total;
         total += ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty) * ((nz + b.zc - 1) / b.zc);
         ++L.n;
@@ -828,6 +983,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, {}, prev_slots, max_update_norm, {pX, pY, pZ},
                 {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
+    if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
     const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 3, 6, zc, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
     if (groups == 0) return 0;
     bool tr = false;
@@ -841,8 +997,10 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
         else if (compact) SOBFU_LAUNCH_B(false, true, true);
         else SOBFU_LAUNCH_B(false, false, true);
     } else {
+        const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
         if (updates && compact) SOBFU_LAUNCH_B(true, true, false);
         else if (updates) SOBFU_LAUNCH_B(true, false, false);
+        else if (compact && idx32) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true>), grid, block, 0, stream, a);
         else if (compact) SOBFU_LAUNCH_B(false, true, false);
         else SOBFU_LAUNCH_B(false, false, false);
     }

@@ -22,8 +22,11 @@ for db in sorted(glob.glob("$O/pmc*/r_results.db")):
         k = "pass_a" if "potential" in name else "pass_b"
         rows.setdefault(k, {})[cn] = avg
 out = {"note": "rocprofv3 --pmc, one counter set per run, averages per launch at 256^3; FETCH_SIZE/WRITE_SIZE in KiB. "
-               "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of wide streaming reads -> "
-               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "counters": rows}
+               "Correction factors MEASURED on this part with streaming copies of known size in the kernels' own access widths "
+               "(12-byte dwordx3, 4-byte dword, 16-byte; plain and nontemporal -- tools/calibrate_counters.sh, "
+               "profiles/r02_counter_calibration.json): FETCH_SIZE reports exactly 1/2 of the bytes read, WRITE_SIZE the bytes "
+               "written -> bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.  These are L2 <-> fabric bytes (Infinity-Cache hits included).",
+       "counters": rows}
 for k in rows:
     if "FETCH_SIZE" in rows[k] and "WRITE_SIZE" in rows[k]:
         out[k + "_hbm_bytes_per_launch"] = (2 * rows[k]["FETCH_SIZE"] + rows[k]["WRITE_SIZE"]) * 1024
