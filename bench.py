@@ -248,7 +248,8 @@ def main():
                     help="N > 1: every rank solves its OWN grid (independent sequences, BASELINE config 5 style: no exchange, weak "
                          "scaling) instead of the default -- ONE grid cut into N tiles with RCCL halo exchange (strong scaling)")
     ap.add_argument("--tiles", type=str, default="", help="N > 1, strong scaling: tile grid PxxPyxPz (default sobfu_amd.tiled.default_grid: "
-                                                         "2x2x2 at N=8, 1x2x2 at N=4, 1x1x2 at N=2)")
+                                                         "2x2x2 at N=8, 1x2x2 at N=4, 1x1x2 at N=2), or 'auto': time every grid of N "
+                                                         "tiles on this machine before the timed region and keep the fastest")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)

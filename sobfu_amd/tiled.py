@@ -769,6 +769,50 @@ def _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks, 
     return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}
 
 
+def candidate_grids(world, dims):
+    """every (Px, Py, Pz) with Px * Py * Pz == world whose tiles keep >= HALO cells per split axis, x split last (Px <= Py <= Pz
+    is not required: 1 x 2 x 4 and 2 x 2 x 2 and 1 x 1 x 8 are all candidates at 8; permutations that split x more than z are not)"""
+    out = []
+    for px in range(1, world + 1):
+        for py in range(1, world + 1):
+            if world % (px * py):
+                continue
+            pz = world // (px * py)
+            if px <= py <= pz and all(g == 1 or dims[a] // g >= HALO for a, g in enumerate((px, py, pz))):
+                out.append((px, py, pz))
+    return out
+
+
+def autotune_grid(P, ranks, kw, iters=40):
+    """us per iteration of the native loop for every candidate tile grid on the machine at hand (MAX over ranks: all agree)"""
+    from . import ops
+
+    dims = P["dims"]
+    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
+    pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
+    ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
+    times = {}
+    for grid in candidate_grids(ranks.world, dims):
+        if ranks.share and ranks.world > 1:
+            sv = NativeTiledSolver(dims, dry=(ranks.world, ranks.rank), grid=grid, **kw)
+            tr = GlooTransport()
+            sv.set_transport(tr.exchange, tr.allreduce)
+        else:
+            sv = NativeTiledSolver(dims, grid=grid, **kw)
+        pg = sv.layout.take(pg_full).clone().contiguous()
+        pnp, psi = sv.new_local(2), sv.identity_psi()
+        sv.iterate(pg, pn_full, pnp, psi, 4)
+        torch.cuda.synchronize()
+        ranks.barrier()
+        t0 = time.perf_counter()
+        sv.iterate(pg, pn_full, pnp, psi, iters)
+        torch.cuda.synchronize()
+        times[grid] = ranks.max([(time.perf_counter() - t0) / iters * 1e6])[0]
+        sv.close()
+    return times
+
+
 def bench_tiled(args, P, ranks, timed_regions):
     """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N tiles (strong scaling; 2 x 2 x 2 at N = 8)."""
     import os
@@ -778,11 +822,17 @@ def bench_tiled(args, P, ranks, timed_regions):
     rank, world = ranks.rank, ranks.world
     dims = P["dims"]
     X, Y, Z = dims
-    grid = parse_grid(args.tiles or os.environ.get("SOBFU_TILES", ""), world)
+    spec = args.tiles or os.environ.get("SOBFU_TILES", "")
     c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
     kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
     K, W, R = args.steps, args.warmup, args.repeats
     total = W + R * K
+    grid_times = None
+    if spec == "auto":  # time every tile grid of `world` tiles on THIS machine (real exchange included) and keep the fastest
+        grid_times = autotune_grid(P, ranks, kw)
+        grid = min(grid_times, key=grid_times.get)
+    else:
+        grid = parse_grid(spec, world)
     # default: the native C++ loop (RCCL issued from the library); if ANY rank fails to set it up, every rank falls back to
     # the torch.distributed loop (same decomposition, same results).  Ranks that share a GPU (bring-up) run the native loop
     # over the gloo transport.
@@ -889,4 +939,5 @@ def bench_tiled(args, P, ranks, timed_regions):
                             + ("gloo (ranks share a GPU: bring-up transport)" if transport else "RCCL send/recv") + ", "
                             + ("native C++ loop" if native else "torch.distributed loop")
                             + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ("" if L.slab else ", serial schedule")),
-                tiled_autotune_us={solver.SCHEDULES[k]: round(v, 2) for k, v in tuned.items()} if tuned else None)
+                tiled_autotune_us=({solver.SCHEDULES[k]: round(v, 2) for k, v in tuned.items()} if tuned else None)
+                if not grid_times else {"x".join(map(str, g)): round(v, 2) for g, v in grid_times.items()})

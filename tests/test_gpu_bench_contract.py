@@ -76,6 +76,13 @@ def test_gpus_n_strong_scaling_self_launch(n, grid):
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6 and "cpu_baseline" not in d
 
 
+def test_gpus_n_tiles_auto():
+    d = run_bench("--gpus", "4", "--tiles", "auto", "--steps", "5", "--warmup", "1", "--dim", "64", "--repeats", "2",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})
+    assert set(d["tiled_autotune_us"]) == {"1x1x4", "1x2x2"} and "x".join(map(str, d["tiles"]["grid"])) in d["tiled_autotune_us"]
+    assert d["tiled_parity_vs_single_gpu"] == "bit-exact"
+
+
 def test_gpus_n_explicit_tiles_and_threshold():
     d = run_bench("--gpus", "4", "--tiles", "2x2x1", "--steps", "5", "--warmup", "1", "--dim", "64", "--repeats", "2",
                   env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})

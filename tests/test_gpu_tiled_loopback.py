@@ -329,3 +329,65 @@ def test_tiled_fusion_frames_loopback(world):
     for s in solvers:
         s.close()
     assert float(np.abs(psi.cpu().numpy()[..., 0] - np.arange(64)[None, None, :]).max()) > 1e-3  # the solves really moved psi
+
+
+def test_config4_256_cubed_on_2x2x2_tiles_loopback():
+    """BASELINE config 4 at full size: the 256^3 roofline workload (params_boxing.ini solver values, two analytic spheres) cut
+    into 2 x 2 x 2 tiles of 128^3, eight ranks of the native loop on this one GPU over the loopback transport -- everything of the
+    8-GPU run except RCCL itself.  psi, phi_n o psi and the max-norm history equal the single-GPU solve bit for bit, with the
+    ini's 1e-10 threshold live (the max-norm all-reduce and the late gate run every iteration)."""
+    import torch
+
+    import bench
+    from sobfu_amd import ops, tiled
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs ~16 GiB of HBM")
+    P = bench.boxing_params(256)
+    dims, grid, n_iters = P["dims"], (2, 2, 2), 8
+    c0, c1, r = bench.sphere_pair(P)
+    pg, pn = ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_sphere(pg, P["vs"], P["trunc"], P["eta"], c0, r)
+    ops.init_sphere(pn, P["vs"], P["trunc"], P["eta"], c1, r)
+    kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
+    ref = ops.Solver(dims, max_iter=n_iters, **kw)
+    psi_r, pnp_r = ops.new_field(dims), ops.new_volume(dims)
+    ops.init_identity(psi_r)
+    rep, hist_r = ref.iterate(pg, pn, pnp_r, psi_r, n_iters)
+    ref.close()
+    assert rep.iterations == n_iters and float(hist_r.min()) > 0
+
+    solvers = [tiled.NativeTiledSolver(dims, dry=(8, q), grid=grid, **kw) for q in range(8)]
+    assert all(tuple(s.layout.L) == (132, 132, 132) and len(s.layout.messages()) == 6 for s in solvers)
+    lb = Loopback(solvers)
+    for s in solvers:
+        s.set_transport(lb.exchange, lb.allreduce)
+    ok, errs = [None] * 8, []
+
+    def rank_main(q):
+        try:
+            s = solvers[q]
+            L = s.layout
+            with torch.cuda.stream(torch.cuda.Stream()):
+                pg_l = L.take(pg).clone().contiguous()
+                pnp_l, psi_l = s.new_local(2), s.identity_psi()
+                done, hist = s.iterate(pg_l, pn, pnp_l, psi_l, n_iters)
+                torch.cuda.current_stream().synchronize()
+                same = (done == n_iters and np.array_equal(np.asarray(hist, np.float32).view(np.uint32), np.asarray(hist_r, np.float32).view(np.uint32))
+                        and torch.equal(L.owned(psi_l)[..., :3].contiguous().view(torch.int32), L.owned_global(psi_r)[..., :3].contiguous().view(torch.int32))
+                        and torch.equal(L.owned(pnp_l).contiguous().view(torch.int32), L.owned_global(pnp_r).contiguous().view(torch.int32)))
+            ok[q] = bool(same)
+        except Exception as e:  # noqa: BLE001
+            errs.append((q, repr(e)))
+            lb.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(q,)) for q in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    for s in solvers:
+        s.close()
+    assert ok == [True] * 8, ok
