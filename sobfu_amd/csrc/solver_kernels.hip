@@ -961,7 +961,7 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
                         int n, const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
     PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, {}, prev_slots, max_update_norm};
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 4, 2, zc, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 4 * 8 / SOBFU_WY, 2, zc, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
     if (groups == 0) return 0;
     bool tr = false;
     for (int i = 0; i < a.boxes.n; ++i) tr = tr || a.boxes.b[i].tr;
@@ -984,7 +984,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
                 {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 3, 6, zc, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 32 KB LDS: 3 per CU
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 3 * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 48 KB LDS: 3 workgroups of 8 waves per CU
     if (groups == 0) return 0;
     bool tr = false;
     for (int i = 0; i < a.boxes.n; ++i) tr = tr || a.boxes.b[i].tr;

@@ -261,7 +261,7 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
-    if (rc == 0) rc = (int) hipMemsetAsync(t->nU, 0, t->NL * 12, nullptr);  // halo cells no message fills (tile corners) stay finite
+    if (rc == 0) rc = (int) hipMemset(t->nU, 0, t->NL * 12);  // halo cells no message fills (tile corners) stay finite (blocking: the loop's streams do not order against the null stream)
     if (rc == 0) {  // max-norm slot rows for 4096 iterations up front: a solve never reallocates inside a timed region
         rc = (int) hipMalloc((void**) &t->slots, (size_t) (4096 + 1) * kSlots * 4);
         if (rc == 0) t->slots_iters = 4096;
