@@ -296,8 +296,9 @@ def main():
             if os.path.exists(path):
                 with open(path) as f:
                     pmc, pmc_file = json.load(f).get("pass_b_hbm_bytes_per_launch"), "profiles/" + name
-        ach_b = gbps(N * B_PASS_B, ms_b)
-        phys_b = gbps(N * C_PASS_B, ms_b)
+        NL = res.get("launch_cells") or N  # cells one launch produces on one GPU (the largest tile's owned cells when tiled)
+        ach_b = gbps(NL * B_PASS_B, ms_b)
+        phys_b = gbps(NL * C_PASS_B, ms_b)
         out = {
             "metric": f"solver iterations/sec on {args.dim}^3 voxel grid",
             "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -312,9 +313,9 @@ def main():
             # whole-iteration view, per GPU: the 76 B/voxel the compact format must move per iteration against the HBM peak.
             # (SURVEY 8(d) prices an iteration at 112 algorithmic B/voxel; at that price the same run is
             # `iteration_algorithmic_GBps`, which can exceed the peak precisely because the format moves fewer bytes.)
-            "iteration_physical_GBps": N * C_ITER * its / mult / 1e9,
-            "iteration_hbm_frac_physical": (N * C_ITER * its / mult / 1e9) / HBM_PEAK_GBPS,
-            "iteration_algorithmic_GBps": N * B_ITER * its / mult / 1e9,
+            "iteration_physical_GBps": N * C_ITER * its / world / 1e9,
+            "iteration_hbm_frac_physical": (N * C_ITER * its / world / 1e9) / HBM_PEAK_GBPS,
+            "iteration_algorithmic_GBps": N * B_ITER * its / world / 1e9,
             "last_max_update_norm": res.get("last_norm"),
             "solver_workspace_bytes": res.get("workspace"),
         }
@@ -324,17 +325,20 @@ def main():
                           "warp + max-norm)",
                 "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBPS,
                 "traffic": None,  # PMC counters cannot be read from inside the process: see traffic_from_profiles
-                "algorithmic_bytes_per_launch": N * B_PASS_B, "avg_launch_ms": ms_b, "launches_timed": res.get("n_prof"),
-                "how": "HIP events on the solver's stream around every pass-A / pass-B launch of the profiled regions",
+                "algorithmic_bytes_per_launch": NL * B_PASS_B, "avg_launch_ms": ms_b, "launches_timed": res.get("n_prof"),
+                "how": "HIP events on the solver's stream around every pass-A / pass-B launch of the profiled regions"
+                       + ("; per GPU: one launch produces the largest tile's owned cells (MAX over ranks of the averages)" if res.get("launch_cells") else ""),
                 # the solver iterates on a compact copy of the state (12-byte psi / nabla_U, tsdf-only TSDF streams): the bytes
                 # the kernel must physically move are below the survey's algorithmic figure
-                "physical_bytes_per_launch": N * C_PASS_B, "physical_GBps": phys_b, "frac_physical": phys_b / HBM_PEAK_GBPS,
+                "physical_bytes_per_launch": NL * C_PASS_B, "physical_GBps": phys_b, "frac_physical": phys_b / HBM_PEAK_GBPS,
                 "traffic_from_profiles": {"file": pmc_file, "bytes_per_launch": pmc, "GBps": gbps(pmc, ms_b) if pmc else None,
                                           "note": "rocprofv3 PMC pass committed under profiles/, NOT measured in this run"},
-                "pass_a": {"avg_launch_ms": ms_a, "algorithmic_bytes_per_launch": N * B_PASS_A, "physical_bytes_per_launch": N * C_PASS_A,
-                           "physical_GBps": gbps(N * C_PASS_A, ms_a), "frac_physical": gbps(N * C_PASS_A, ms_a) / HBM_PEAK_GBPS},
-                "event_sum_vs_step": (ms_a + ms_b) / (1e3 * med / K),
+                "pass_a": {"avg_launch_ms": ms_a, "algorithmic_bytes_per_launch": NL * B_PASS_A, "physical_bytes_per_launch": NL * C_PASS_A,
+                           "physical_GBps": gbps(NL * C_PASS_A, ms_a), "frac_physical": gbps(NL * C_PASS_A, ms_a) / HBM_PEAK_GBPS},
+                "event_sum_vs_step": (ms_a + ms_b + (res.get("ms_exchange") or 0.0)) / (1e3 * med / K),
             }
+            if res.get("ms_exchange") is not None:  # N > 1, serial schedule: what an iteration is made of
+                out["tiled_iteration_ms"] = {"pass_a": ms_a, "exchange_incl_pack_unpack_and_peer_wait": res["ms_exchange"], "pass_b": ms_b}
         if res.get("solve50_s"):
             s50 = res["solve50_s"]
             out["per_solve"] = {"iterations": 50, "ms": 1e3 * s50, "fixed_ms": 1e3 * s50 - 50 * 1e3 * med / K,

@@ -372,6 +372,13 @@ typedef struct {
 /* The messages of one exchange of a 3-D tile and the boxes (6 ints each: x0, x1, y0, y1, z0, z1, local cells) they are packed
  * from / scattered to; returns their number (0 for z-slabs, whose messages are plane ranges of the field itself). */
 int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int* send_boxes, int* recv_boxes, int max_msgs);
+/* Timing of the SERIAL schedule's pieces with HIP events on the loop's stream around every stride-th iteration (0 = off;
+ * max_samples events sets are created here, outside any timed region): ms[0] pass A, ms[1] the exchange (pack + transfer +
+ * unpack, including the wait for the peers), ms[2] pass B -- sums over `samples` iterations since the last reset.  Call
+ * get_profile after the stream has been synchronised.  An event between two kernels drains the pipeline: time a profiled run for
+ * its split, not for its wall time. */
+int sobfu_hip_tiled_set_profiling(sobfu_hip_tiled* t, int stride, int max_samples);
+int sobfu_hip_tiled_get_profile(sobfu_hip_tiled* t, float ms[3], int* samples, int reset);
 /* Pluggable transport for communicator-less handles (MPI, an in-process loopback for tests, ...).  `exchange` must deliver every
  * message: msgs[i].count floats at d_send + msgs[i].send_off arrive at d_recv + recv_off of the message rank msgs[i].peer posts
  * for this rank (d_send == d_recv for z-slabs, which exchange planes of the field in place); `allreduce_max` must leave the

@@ -114,6 +114,10 @@ struct sobfu_hip_tiled {
     float *sendbuf = nullptr, *recvbuf = nullptr;
     int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
+    // optional timing of the serial schedule's three pieces with HIP events on the loop's stream (sobfu_hip_tiled_set_profiling)
+    int prof_stride = 0, prof_pending = 0, prof_n = 0;
+    std::vector<hipEvent_t> prof_ev;
+    double prof_ms[3] = {0, 0, 0};  // pass A, exchange (pack + transfer + unpack), pass B
     struct Session {  // an open solve (tiled_begin .. tiled_end)
         bool active = false;
         const float* pn = nullptr;
@@ -169,6 +173,7 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     for (float* q : {t->nU, t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
         if (q) (void) hipFree(q);
     if (t->slots) (void) hipFree(t->slots);
+    for (hipEvent_t e : t->prof_ev) (void) hipEventDestroy(e);
     if (t->sendbuf) (void) hipFree(t->sendbuf);
     if (t->recvbuf) (void) hipFree(t->recvbuf);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
@@ -325,6 +330,37 @@ int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule) {
 }
 
 double sobfu_hip_tiled_last_enqueue_us(const sobfu_hip_tiled* t) { return t ? t->last_enqueue_us : 0.0; }
+
+int sobfu_hip_tiled_set_profiling(sobfu_hip_tiled* t, int stride, int max_samples) {
+    SOBFU_CHECK_ARGS(t && stride >= 0 && max_samples >= 0);
+    t->prof_stride = stride;
+    while (stride > 0 && t->prof_ev.size() < (size_t) 4 * max_samples) {  // created here, never inside a timed region
+        hipEvent_t e;
+        SOBFU_HIP_TRY(hipEventCreate(&e));
+        t->prof_ev.push_back(e);
+    }
+    return 0;
+}
+
+int sobfu_hip_tiled_get_profile(sobfu_hip_tiled* t, float ms[3], int* samples, int reset) {
+    SOBFU_CHECK_ARGS(t && ms);
+    for (int k = 0; k < t->prof_pending; ++k) {  // the caller has synchronised the stream
+        for (int j = 0; j < 3; ++j) {
+            float v = 0;
+            SOBFU_HIP_TRY(hipEventElapsedTime(&v, t->prof_ev[4 * k + j], t->prof_ev[4 * k + j + 1]));
+            t->prof_ms[j] += v;
+        }
+        t->prof_n += 1;
+    }
+    t->prof_pending = 0;
+    for (int j = 0; j < 3; ++j) ms[j] = (float) t->prof_ms[j];
+    if (samples) *samples = t->prof_n;
+    if (reset) {
+        t->prof_ms[0] = t->prof_ms[1] = t->prof_ms[2] = 0;
+        t->prof_n = 0;
+    }
+    return 0;
+}
 
 int sobfu_hip_tiled_layout(const sobfu_hip_tiled* t, int* z0, int* z1, int* lo, int* hi, int* Lz, int* zbase) {
     SOBFU_CHECK_ARGS(t);
@@ -518,15 +554,19 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
         };
         auto after_b = [&]() -> int {  // row `it` is complete on `st`; it gates iteration it+2
             if (it > n_iters - 2) return 0;  // the tail rows are reduced once, by tiled_end
-            uint32_t* r_ = t->slots + (size_t) it * kSlots;
+            // every row after the last one reduced so far, up to this one (normally just this one; more after a change of schedule
+            // in mid-solve, whose reduction points differ)
+            const int first = std::min(q.red_upto + 1, it);
+            uint32_t* r_    = t->slots + (size_t) first * kSlots;
+            const size_t cnt = (size_t) (it - first + 1) * kSlots;
             if (red_mode == RED_INLINE) {
-                SOBFU_TRY(allreduce_max(t, r_, kSlots, st));
+                SOBFU_TRY(allreduce_max(t, r_, cnt, st));
                 q.red_upto = it;
             }
             if (red_mode == RED_OWN_COMM) {
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_row, st));
                 SOBFU_HIP_TRY(hipStreamWaitEvent(t->red_stream, t->ev_row, 0));
-                SOBFU_TRY(allreduce_max(t, r_, kSlots, t->red_stream, true));
+                SOBFU_TRY(allreduce_max(t, r_, cnt, t->red_stream, true));
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_red[it & 1], t->red_stream));
                 red_issued[it & 1] = true;
                 q.red_upto = it;
@@ -538,10 +578,19 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
             // no overlap, no cross-stream events: pass A, the exchange and pass B in line on `st`.  Every event record / wait
             // between two kernels costs a few microseconds of drained pipeline (~20 us per iteration for the overlapped
             // schedule's three), which a fast exchange on a thin slab does not repay.
+            const bool ev = t->prof_stride > 0 && it % t->prof_stride == 0 && (size_t) 4 * (t->prof_pending + 1) <= t->prof_ev.size();
+            hipEvent_t* e = ev ? t->prof_ev.data() + 4 * t->prof_pending : nullptr;
+            if (ev) SOBFU_HIP_TRY(hipEventRecord(e[0], st));
             SOBFU_TRY(A(lo, hi));
+            if (ev) SOBFU_HIP_TRY(hipEventRecord(e[1], st));
             if (multi) SOBFU_TRY(exchange(t, t->nU, H, st));
             SOBFU_TRY(wait_gate());
+            if (ev) SOBFU_HIP_TRY(hipEventRecord(e[2], st));
             SOBFU_TRY(B(b_first, b_last, 0, 0, true));
+            if (ev) {
+                SOBFU_HIP_TRY(hipEventRecord(e[3], st));
+                t->prof_pending += 1;
+            }
             SOBFU_TRY(after_b());
             continue;
         }
@@ -553,10 +602,11 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
             SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
-            if (red_mode == RED_COMM_STREAM && it >= 2 && it < n_iters) {
+            if (red_mode == RED_COMM_STREAM && it >= 2 && it < n_iters && q.red_upto < it - 1) {
                 // row it-1 is complete (its pass B precedes this iteration's ev_bnd, which the comm stream has waited for) and
-                // gates iteration it+1: reduce it behind this iteration's exchange
-                SOBFU_TRY(allreduce_max(t, t->slots + (size_t) (it - 1) * kSlots, kSlots, t->comm_stream));
+                // gates iteration it+1: reduce it (and any earlier row not reduced yet) behind this iteration's exchange
+                const int first = q.red_upto + 1;
+                SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (it - first) * kSlots, t->comm_stream));
                 SOBFU_HIP_TRY(hipEventRecord(t->ev_red[(it - 1) & 1], t->comm_stream));
                 red_issued[(it - 1) & 1] = true;
                 q.red_upto = it - 1;

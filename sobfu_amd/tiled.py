@@ -633,6 +633,15 @@ class NativeTiledSolver:
         self._session = None
         return rep.iterations, np.array(hist[:rep.iterations], np.float32)
 
+    def set_profiling(self, stride, max_samples=256):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_set_profiling(self._h, C.c_int(int(stride)), C.c_int(int(max_samples))), "tiled_set_profiling")
+
+    def get_profile(self, reset=True):
+        """(ms in pass A, ms in the exchange incl. pack / unpack, ms in pass B, iterations timed) -- serial schedule only"""
+        ms, n = (C.c_float * 3)(), C.c_int()
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_get_profile(self._h, ms, C.byref(n), C.c_int(1 if reset else 0)), "tiled_get_profile")
+        return ms[0], ms[1], ms[2], n.value
+
     def gather_owned(self, local):
         return gather_owned(self.layout, local, self.group)
 
@@ -825,8 +834,8 @@ def bench_tiled(args, P, ranks, timed_regions):
     spec = args.tiles or os.environ.get("SOBFU_TILES", "")
     c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
     kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
-    K, W, R = args.steps, args.warmup, args.repeats
-    total = W + R * K
+    K, W, R, PR = args.steps, args.warmup, args.repeats, args.profile_repeats
+    total = W + (R + PR) * K
     grid_times = None
     if spec == "auto":  # time every tile grid of `world` tiles on THIS machine (real exchange included) and keep the fastest
         grid_times = autotune_grid(P, ranks, kw)
@@ -875,9 +884,26 @@ def bench_tiled(args, P, ranks, timed_regions):
         solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
         solver.step(W)
         secs = timed_regions(ranks, torch, lambda: solver.step(K), R)
+        prof = None
+        if PR > 0:  # the split of an iteration (serial schedule: pass A / exchange / pass B), outside the timed regions
+            sched = getattr(solver, "schedule", 0)
+            if L.slab:
+                solver.set_schedule(3)  # the split is measured on the serial schedule (same results whatever the schedule)
+            solver.set_profiling(1, PR * K)
+            solver.get_profile(reset=True)
+            for _ in range(PR):
+                solver.step(K)
+            torch.cuda.synchronize()
+            pa, px, pb, n = solver.get_profile()
+            solver.set_profiling(0)
+            if L.slab:
+                solver.set_schedule(sched)
+            if n > 0:
+                prof = ranks.max([pa / n, px / n, pb / n]) + [n]
         done, norms = solver.end()
         assert done == total and np.isfinite(norms).all() and float(norms.max()) > 0, (done, total)
     else:  # the torch loop has no open-solve form: a region is a whole iterate() of K iterations
+        prof, total = None, W + R * K
         if W > 0:
             solver.iterate(pg, pn_full, pnp, psi, W)
         hist = []
@@ -932,7 +958,9 @@ def bench_tiled(args, P, ranks, timed_regions):
             print(f"[rank {rank}] tiled diagnostics: {diag['error']}", file=sys.stderr, flush=True)
     own = tuple(L.g1[a] - L.g0[a] for a in range(3))
     what = (f"{world} z-slabs of {own[2]} planes" if L.slab else f"{grid[0]}x{grid[1]}x{grid[2]} tiles of {own[0]}x{own[1]}x{own[2]} cells")
-    return dict(diag_hung=hung, region_seconds=secs, N=X * Y * Z, ms_a=None, ms_b=None, last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
+    return dict(diag_hung=hung, region_seconds=secs, N=X * Y * Z, ms_a=(prof[0] if prof else None), ms_b=(prof[2] if prof else None),
+                ms_exchange=(prof[1] if prof else None), n_prof=(prof[3] if prof else None),
+                launch_cells=max((l.g1[0] - l.g0[0]) * (l.g1[1] - l.g0[1]) * (l.g1[2] - l.g0[2]) for l in (TileLayout(dims, grid, q) for q in range(world))), last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
                 tiled_diag=diag, tiles={"grid": list(grid), "owned_cells_rank0": list(own), "halo": HALO,
                                         "messages_per_exchange_rank0": len(L.messages())},
                 parallelism=f"{what} (+{HALO}-cell halos), one nabla_U halo exchange per iteration over "

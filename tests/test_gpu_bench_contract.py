@@ -74,6 +74,9 @@ def test_gpus_n_strong_scaling_self_launch(n, grid):
     assert d["n_gpus"] == n and d["scaling"] == "strong" and d["tiles"]["grid"] == grid
     assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and "native C++ loop" in d["config"]["parallelism"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6 and "cpu_baseline" not in d
+    t = d["tiled_iteration_ms"]
+    assert t["pass_a"] > 0 and t["pass_b"] > 0 and t["exchange_incl_pack_unpack_and_peer_wait"] > 0
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 64 ** 3 // n * 64 and d["roofline"]["launches_timed"] == 2 * 6
 
 
 def test_gpus_n_tiles_auto():
