@@ -540,7 +540,10 @@ struct PassBArgs {
 };
 
 #ifndef SOBFU_HLEAD
-#define SOBFU_HLEAD 3  // planes the halo requests of pass B run ahead (0: one plane ahead, straight from registers)
+#define SOBFU_HLEAD 3  // planes the halo requests of pass B run ahead on long marches (0: never; one plane ahead, straight from registers)
+#endif
+#ifndef SOBFU_HLEAD_MIN_ZC
+#define SOBFU_HLEAD_MIN_ZC 24  // shortest march (planes) that uses the halo lead
 #endif
 #ifndef SOBFU_IDX32
 #define SOBFU_IDX32 1  // 1: 32-bit byte offsets for the phi_n corner gather of pass B (volumes below 2^30 voxels)
@@ -552,16 +555,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef SOBFU_MINW_B
 #define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
 #endif
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool TRANSPOSABLE, bool IDX32 = false>
+// HL: planes the halo requests run ahead of the plane they are staged for (0: one plane ahead, straight from registers -- short
+// marches, where the extra prologue round trip costs more than the re-fetched halo lines).
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool TRANSPOSABLE, bool IDX32 = false, int HL = 0>
 __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
     constexpr int NXH = (2 * R * TY + TX - 1) / TX;  // row-tasks for the 2R lane-halo columns
     constexpr int NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 tile[2][LH][LW + 2];
     __shared__ uint32_t s_max[WY];
-#if SOBFU_HLEAD
-    __shared__ P3 hfifo[SOBFU_HLEAD][NTASK * TX];  // 12-byte entries: with the 32 KB tile, 3 workgroups still fit a CU's 160 KB
-#endif
+    __shared__ P3 hfifo[HL > 0 ? HL : 1][HL > 0 ? NTASK * TX : 1];  // 12-byte entries: with the 32 KB tile, 3 workgroups still fit a CU's 160 KB
 
     const GateRegs gate = gate_load(a.prev_slots, a.prev_rows);
 
@@ -614,32 +617,30 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
     }
 
     float4 hq[TPW];
-#if SOBFU_HLEAD
-    // Halo cells run HLEAD planes ahead of the plane they are staged for, like the main cells of the z pipeline (which must be 4
+    // Halo cells run HL planes ahead of the plane they are staged for, like the main cells of the z pipeline (which must be 4
     // ahead): a neighbour tile's halo request then meets the owner's own request for the same lines in the L2 instead of coming
     // 3 plane-steps (~5 MB of traffic through a 4 MB L2) later -- 86 of the 111 MB pass B read beyond its minimum at 256^3 were
     // halo lines fetched twice (PMC attribution).  In between a cell waits in a per-lane LDS FIFO (only its own lane
     // ever touches an entry: no barrier involved).  Planes zb+1 .. of the first steps are requested -- and parked -- before the
     // z pipeline's seven planes are, so that their registers are free again by then.
-    {
-        float4 hpre[TPW][SOBFU_HLEAD - 1];
+    if (HL > 0) {
+        float4 hpre[TPW][HL > 1 ? HL - 1 : 1];
 #pragma unroll
         for (int k = 0; k < TPW; ++k)
             if (h_on[k]) {
 #pragma unroll
-                for (int p = 1; p < SOBFU_HLEAD; ++p) hpre[k][p - 1] = ldvb<COMPACT>((const char*) a.nU + (size_t) min(zb + p, d.z - 1) * plane * VB, h_off[k]);
+                for (int p = 1; p < HL; ++p) hpre[k][p - 1] = ldvb<COMPACT>((const char*) a.nU + (size_t) min(zb + p, d.z - 1) * plane * VB, h_off[k]);
             }
 #pragma unroll
         for (int k = 0; k < TPW; ++k)
             if (h_on[k]) {
 #pragma unroll
-                for (int p = 1; p < SOBFU_HLEAD; ++p) {
-                    P3& e = hfifo[(zb + p) % SOBFU_HLEAD][(wy + k * WY) * TX + lx];
+                for (int p = 1; p < HL; ++p) {
+                    P3& e = hfifo[(zb + p) % (HL > 0 ? HL : 1)][(wy + k * WY) * TX + lx];
                     e.x = hpre[k][p - 1].x; e.y = hpre[k][p - 1].y; e.z = hpre[k][p - 1].z;
                 }
             }
     }
-#endif
     // z register pipeline q[r][0..6] = planes clamp(z-3 .. z+3)  (clamp-to-edge, solver.cu:396-424)
     float4 q[RPT][7];
 #pragma unroll
@@ -652,17 +653,15 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
     for (int k = 0; k < TPW; ++k)
         if (h_on[k]) hq[k] = ldvb<COMPACT>((const char*) a.nU + (size_t) zb * plane * VB, h_off[k]);
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
-#if SOBFU_HLEAD
-    int hslot = zb % SOBFU_HLEAD;  // FIFO slot of plane z
-#endif
+    int hslot = HL > 0 ? zb % (HL > 0 ? HL : 1) : 0;  // FIFO slot of plane z
 
     float msq = 0.f;
     for (int z = zb; z < ze; ++z) {
         const int buf = (z - zb) & 1;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) tile[buf][wy * RPT + r + R][lx + R] = q[r][3];
-#if SOBFU_HLEAD
-        const int hprev = hslot == 0 ? SOBFU_HLEAD - 1 : hslot - 1;  // slot of plane z-1 == slot of plane z-1+HLEAD
+        if (HL > 0) {
+        const int hprev = hslot == 0 ? HL - 1 : hslot - 1;  // slot of plane z-1 == slot of plane z-1+HL
 #pragma unroll
         for (int k = 0; k < TPW; ++k)
             if (h_on[k]) {
@@ -672,18 +671,18 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
                 } else {
                     const P3 e = hfifo[hslot][hi];
                     tile[buf][h_lr[k]][h_lc[k]] = make_float4(e.x, e.y, e.z, 0.f);
-                    if (z - 1 + SOBFU_HLEAD < ze) {  // the cell requested during the previous step (plane z-1+HLEAD) takes the slot plane z-1 left
+                    if (z - 1 + HL < ze) {  // the cell requested during the previous step (plane z-1+HL) takes the slot plane z-1 left
                         P3& w = hfifo[hprev][hi];
                         w.x = hq[k].x; w.y = hq[k].y; w.z = hq[k].z;
                     }
                 }
             }
-        hslot = hslot + 1 == SOBFU_HLEAD ? 0 : hslot + 1;
-#else
+        hslot = hslot + 1 == HL ? 0 : hslot + 1;
+        } else {
 #pragma unroll
         for (int k = 0; k < TPW; ++k)
             if (h_on[k]) tile[buf][h_lr[k]][h_lc[k]] = hq[k];
-#endif
+        }
 
         const size_t zcur = (size_t) z * plane;
         float4 pv[RPT], nq[RPT];
@@ -693,21 +692,19 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             const char* nU4 = (const char*) a.nU + (size_t) min(z + 4, d.z - 1) * plane * VB;
 #pragma unroll
             for (int r = 0; r < RPT; ++r) nq[r] = ldvb<COMPACT>(nU4, off[r]);
-#if !SOBFU_HLEAD
-            const char* nU1 = (const char*) a.nU + (size_t) (z + 1) * plane * VB;
+            if (HL == 0) {
+                const char* nU1 = (const char*) a.nU + (size_t) (z + 1) * plane * VB;
 #pragma unroll
-            for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) hq[k] = ldvb<COMPACT>(nU1, h_off[k]);
-#endif
+                for (int k = 0; k < TPW; ++k)
+                    if (h_on[k]) hq[k] = ldvb<COMPACT>(nU1, h_off[k]);
+            }
         }
-#if SOBFU_HLEAD
-        if (z + SOBFU_HLEAD < ze) {
-            const char* nUh = (const char*) a.nU + (size_t) (z + SOBFU_HLEAD) * plane * VB;
+        if (HL > 0 && z + HL < ze) {
+            const char* nUh = (const char*) a.nU + (size_t) (z + HL) * plane * VB;
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
                 if (h_on[k]) hq[k] = ldvb<COMPACT>(nUh, h_off[k]);
         }
-#endif
         __syncthreads();
         // row-axis taps outside this lane's strip
         float4 yt[R], yb[R];
@@ -1000,7 +997,15 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
         const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
         if (updates && compact) SOBFU_LAUNCH_B(true, true, false);
         else if (updates) SOBFU_LAUNCH_B(true, false, false);
-        else if (compact && idx32) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true>), grid, block, 0, stream, a);
+        else if (compact && idx32) {
+            // long marches (big grids): halo requests run SOBFU_HLEAD planes ahead; short ones (small grids, multi-GPU tiles) skip
+            // the extra prologue round trip
+            int zc_max = 0;
+            for (int i = 0; i < a.boxes.n; ++i) zc_max = std::max(zc_max, a.boxes.b[i].zc);
+            if (SOBFU_HLEAD > 0 && zc_max >= SOBFU_HLEAD_MIN_ZC)
+                hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, SOBFU_HLEAD>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, 0>), grid, block, 0, stream, a);
+        }
         else if (compact) SOBFU_LAUNCH_B(false, true, false);
         else SOBFU_LAUNCH_B(false, false, false);
     }
