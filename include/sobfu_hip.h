@@ -54,12 +54,6 @@ int sobfu_hip_integrate_depth(const float* d_dists, int dists_step_bytes, int ro
                               int Y, int Z, const float voxel_size[3], float trunc_dist, float eta,
                               const float R[9], const float t[3], float fx, float fy, float cx, float cy,
                               void* stream);
-/* The same on a z-slab of a larger volume (multi-GPU tiles): local planes [0, Lz) are global planes [zbase, zbase + Lz);
- * the per-slice accumulation of the camera-frame z (tsdf_volume.cu:76) is replayed from global plane 0, so the slab holds
- * exactly the planes the whole-volume call would produce. */
-int sobfu_hip_tile_integrate_depth(const float* d_dists, int dists_step_bytes, int rows, int cols, float* d_vol_local, int X,
-                                   int Y, int Lz, int zbase, const float voxel_size[3], float trunc_dist, float eta,
-                                   const float R[9], const float t[3], float fx, float fy, float cx, float cy, void* stream);
 /* integrate(phi_global, phi_n_psi) (tsdf_volume.cu:103-130,164-173): running weighted average fusion. */
 int sobfu_hip_integrate_fuse(float* d_phi_global, const float* d_phi_n_psi, int X, int Y, int Z, float max_weight,
                              void* stream);
@@ -162,43 +156,20 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
                                         float* d_phi_n_psi, float* d_updates, uint32_t* d_max_sq_slots,
                                         const float taps[7], float alpha, int X, int Y, int Z, void* stream);
 
-/* Slab-tile variants for the multi-GPU path: every field argument is a LOCAL slab
- * (X, Y, Lz) that carries halo planes along z; d_phi_n is the WHOLE (X, Y, Zg) volume (the warp gathers at absolute
- * coordinates); only planes [z_own_lo, z_own_hi) enter the max-norm.  Clamp / mirror rules apply at the slab's array
- * edges, which coincide with the volume boundary exactly where a slab has no halo.  d_prev_slots (may be NULL) and
- * max_update_norm form the device-side convergence gate (see the solver handle). */
-int sobfu_hip_tile_init_identity(float* d_psi, int X, int Y, int Lz, int zbase, void* stream); /* psi.z = z + zbase */
-/* d_phi / d_psi (of estimate_inverse) are WHOLE (X, Y, Zg) volumes; outputs are local slabs whose plane 0 is global
- * plane zbase. */
-int sobfu_hip_tile_apply(const float* d_phi, int Zg, float* d_phi_warped, const float* d_psi, int X, int Y, int Lz,
-                         void* stream);
-int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv, int X, int Y, int Lz, int zbase,
-                                    int n_sweeps, void* stream);
-/* compact != 0: the field arguments are in the compact iteration format -- psi / nabla_U 12-byte xyz triples, phi_n o
- * psi / phi_global / phi_n tsdf-only floats (built with the conversion entry points below). */
-/* [z_begin, z_end): the planes this launch produces (the arrays are always the whole slab) -- lets the driver compute
- * boundary planes first, start the halo exchange, and compute the interior while it is in flight. */
-int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
-                                      float* d_nabla_U, float w_reg, int X, int Y, int Lz, int z_begin, int z_end,
-                                      const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
-int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
-                                       float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha,
-                                       int X, int Y, int Lz, int Zg, int z_own_lo, int z_own_hi, int z_begin, int z_end,
-                                       const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
-/* Compact-format conversions (n = number of voxels): float4 <-> packed xyz (unpack leaves .w untouched), float2
- * {tsdf, weight} -> tsdf, and the tsdf-only warp of a slab (phi: whole (X, Y, Zg) tsdf-only volume). */
+/* Compact-format conversions (n = number of voxels; the format the multi-GPU tile entry points below accept with compact != 0):
+ * float4 <-> packed xyz (unpack leaves .w untouched) and float2 {tsdf, weight} -> tsdf. */
 int sobfu_hip_pack_vec3(const float* d_src4, float* d_dst3, size_t n, void* stream);
 int sobfu_hip_unpack_vec3(const float* d_src3, float* d_dst4, size_t n, void* stream);
 int sobfu_hip_extract_tsdf(const float* d_src2, float* d_dst1, size_t n, void* stream);
-int sobfu_hip_tile_apply_tsdf_only(const float* d_phi1, int Zg, float* d_out1, const float* d_psi3, int X, int Y, int Lz,
-                                   void* stream);
 
-/* 3-D tiles (the 2x2x2 split of BASELINE config 4): every field argument is a LOCAL array (Lx, Ly, Lz) whose cell (0, 0, 0) is
- * global cell (xb, yb, zb) of the (Xg, Yg, Zg) volume and that carries halo cells on every side that faces a neighbour tile;
+/* Multi-GPU tiles (the 2x2x2 split of BASELINE config 4, z-slabs as 1x1xN): every field argument is a LOCAL
+ * array (Lx, Ly, Lz) whose cell (0, 0, 0) is global cell (xb, yb, zb) of the (Xg, Yg, Zg) volume and that carries halo cells on every side that faces a neighbour tile;
  * d_phi_n / d_phi / the d_psi of estimate_inverse are WHOLE volumes.  `box` = (x0, x1, y0, y1, z0, z1): the cells a launch produces;
  * `own`: the cells that belong to this rank (they alone enter the max-norm).  transposed != 0 maps the 64 lanes of a wave onto y
  * instead of x -- for boxes that are thin in x (same results).  Boundary rules apply at array edges, which are volume boundaries
- * exactly where a tile has no halo. */
+ * exactly where a tile has no halo.  compact != 0: the field arguments are in the compact iteration format -- psi / nabla_U 12-byte
+ * xyz triples, phi_n o psi / phi_global / phi_n tsdf-only floats.  d_prev_slots (may be NULL) and max_update_norm form the
+ * device-side convergence gate (see the solver handle). */
 int sobfu_hip_tile3_init_identity(float* d_psi, int Lx, int Ly, int Lz, int xb, int yb, int zb, void* stream);
 int sobfu_hip_tile3_apply(const float* d_phi, int Xg, int Yg, int Zg, float* d_phi_warped, const float* d_psi, int Lx, int Ly, int Lz,
                           void* stream);

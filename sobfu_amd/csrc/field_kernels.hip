@@ -149,12 +149,6 @@ int sobfu_hip_init_identity(float* d_psi, int X, int Y, int Z, void* stream) {
     return (int) hipGetLastError();
 }
 
-int sobfu_hip_tile_init_identity(float* d_psi, int X, int Y, int Lz, int zbase, void* stream) {
-    SOBFU_CHECK_ARGS(d_psi && X > 0 && Y > 0 && Lz > 0 && zbase >= 0);
-    LAUNCH_VOXEL(init_identity_kernel, X, Y, Lz, stream, (float4*) d_psi, Dims{X, Y, Lz}, Dims{0, 0, zbase});
-    return (int) hipGetLastError();
-}
-
 // 3-D tiles: local arrays (Lx, Ly, Lz) whose cell (0, 0, 0) is global cell (xb, yb, zb) of the (Xg, Yg, Zg) volume
 int sobfu_hip_tile3_init_identity(float* d_psi, int Lx, int Ly, int Lz, int xb, int yb, int zb, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && Lx > 0 && Ly > 0 && Lz > 0 && xb >= 0 && yb >= 0 && zb >= 0);
@@ -177,22 +171,6 @@ int sobfu_hip_tile3_estimate_inverse(const float* d_psi, int Xg, int Yg, int Zg,
     if (n_sweeps == 0) return 0;
     LAUNCH_VOXEL(inverse_fixed_point_kernel, Lx, Ly, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{Lx, Ly, Lz},
                  Dims{Xg, Yg, Zg}, Dims{xb, yb, zb}, n_sweeps);
-    return (int) hipGetLastError();
-}
-
-int sobfu_hip_tile_apply(const float* d_phi, int Zg, float* d_phi_warped, const float* d_psi, int X, int Y, int Lz, void* stream) {
-    SOBFU_CHECK_ARGS(d_phi && d_phi_warped && d_psi && X > 0 && Y > 0 && Lz > 0 && Zg > 0 && d_phi != d_phi_warped);
-    LAUNCH_VOXEL(apply_kernel, X, Y, Lz, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{X, Y, Lz},
-                 Dims{X, Y, Zg});
-    return (int) hipGetLastError();
-}
-
-int sobfu_hip_tile_estimate_inverse(const float* d_psi, int Zg, float* d_psi_inv, int X, int Y, int Lz, int zbase, int n_sweeps,
-                                    void* stream) {
-    SOBFU_CHECK_ARGS(d_psi && d_psi_inv && X > 0 && Y > 0 && Lz > 0 && Zg > 0 && zbase >= 0 && n_sweeps >= 0 && d_psi != d_psi_inv);
-    if (n_sweeps == 0) return 0;
-    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Lz},
-                 Dims{X, Y, Zg}, Dims{0, 0, zbase}, n_sweeps);
     return (int) hipGetLastError();
 }
 

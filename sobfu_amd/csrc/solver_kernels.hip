@@ -1138,17 +1138,6 @@ int sobfu_hip_fused_smooth_update_apply(const float* d_nabla_U, float* d_psi, co
                                     nullptr, 0.f, 0, (hipStream_t) stream, 0, 0, 0, false, 0, 0);
 }
 
-int sobfu_hip_tile_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
-                                      float w_reg, int X, int Y, int Lz, int z_begin, int z_end, const uint32_t* d_prev_slots,
-                                      float max_update_norm, int compact, void* stream) {
-    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && X > 1 && Y > 1 && Lz > 1 && z_begin >= 0 && z_begin <= z_end &&
-                     z_end <= Lz);
-    if (z_begin == z_end) return 0;
-    if ((size_t) X * Y * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
-    return sobfu_hip::launch_pass_a(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, X, Y, Lz, d_prev_slots, max_update_norm, 0,
-                                    (hipStream_t) stream, compact != 0, z_begin, z_end);
-}
-
 int sobfu_hip_pack_vec3(const float* d_src4, float* d_dst3, size_t n, void* stream) {
     SOBFU_CHECK_ARGS(d_src4 && d_dst3 && n > 0);
     return sobfu_hip::launch_pack_vec(d_src4, d_dst3, n, (hipStream_t) stream);
@@ -1161,23 +1150,6 @@ int sobfu_hip_extract_tsdf(const float* d_src2, float* d_dst1, size_t n, void* s
     SOBFU_CHECK_ARGS(d_src2 && d_dst1 && n > 0);
     return sobfu_hip::launch_extract_tsdf(d_src2, d_dst1, n, (hipStream_t) stream);
 }
-int sobfu_hip_tile_apply_tsdf_only(const float* d_phi1, int Zg, float* d_out1, const float* d_psi3, int X, int Y, int Lz, void* stream) {
-    SOBFU_CHECK_ARGS(d_phi1 && d_out1 && d_psi3 && X > 0 && Y > 0 && Lz > 0 && Zg > 0);
-    return sobfu_hip::launch_apply_tsdf_only(d_phi1, d_out1, d_psi3, X, Y, Lz, (hipStream_t) stream, Zg);
-}
-
-int sobfu_hip_tile_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi,
-                                       float* d_updates, uint32_t* d_max_sq_slots, const float taps[7], float alpha, int X, int Y,
-                                       int Lz, int Zg, int z_own_lo, int z_own_hi, int z_begin, int z_end,
-                                       const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream) {
-    SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && X > 0 && Y > 0 && Lz > 0 && Zg >= 1 &&
-                     z_own_lo >= 0 && z_own_lo <= z_own_hi && z_own_hi <= Lz && z_begin >= 0 && z_begin <= z_end && z_end <= Lz);
-    if (z_begin == z_end) return 0;
-    if ((size_t) X * Y * Lz > (size_t) 0x7fffffff || (size_t) X * Y * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
-    return sobfu_hip::launch_pass_b(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, X, Y, Lz,
-                                    d_prev_slots, max_update_norm, 0, (hipStream_t) stream, Zg, z_own_lo, z_own_hi, compact != 0, z_begin, z_end);
-}
-
 // ---- 3-D tiles (sobfu_hip_tile3_*): local arrays (Lx, Ly, Lz) with halo cells on every side that faces a neighbour ----
 static bool box_ok(const int b[6], int Lx, int Ly, int Lz) {
     return b[0] >= 0 && b[0] <= b[1] && b[1] <= Lx && b[2] >= 0 && b[2] <= b[3] && b[3] <= Ly && b[4] >= 0 && b[4] <= b[5] && b[5] <= Lz;

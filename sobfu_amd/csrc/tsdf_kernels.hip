@@ -205,17 +205,6 @@ int sobfu_hip_integrate_depth(const float* d_dists, int step, int rows, int cols
     return (int) hipGetLastError();
 }
 
-int sobfu_hip_tile_integrate_depth(const float* d_dists, int step, int rows, int cols, float* d_vol_local, int X, int Y, int Lz, int zbase,
-                                   const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx, float fy,
-                                   float cx, float cy, void* stream) {
-    SOBFU_CHECK_ARGS(d_dists && d_vol_local && vs && R && t && X > 0 && Y > 0 && Lz > 0 && zbase >= 0 && rows > 0 && cols > 0 && step >= cols * 4);
-    IntegrateArgs a{d_dists, step, rows, cols, (float2*) d_vol_local, {X, Y, Lz}, vs[0], vs[1], vs[2], trunc, eta, {}, {}, fx, fy, cx, cy, zbase, 0, 0};
-    for (int i = 0; i < 9; ++i) a.R[i] = R[i];
-    for (int i = 0; i < 3; ++i) a.t[i] = t[i];
-    hipLaunchKernelGGL(integrate_depth_kernel, chunk_grid(X, Y, Lz), voxel_block(), 0, (hipStream_t) stream, a);
-    return (int) hipGetLastError();
-}
-
 int sobfu_hip_tile3_integrate_depth(const float* d_dists, int step, int rows, int cols, float* d_vol_local, int Lx, int Ly, int Lz, int xb,
                                     int yb, int zb, const float vs[3], float trunc, float eta, const float R[9], const float t[3], float fx,
                                     float fy, float cx, float cy, void* stream) {

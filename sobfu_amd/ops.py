@@ -76,17 +76,6 @@ def integrate_depth(dists, vol, voxel_size, trunc, eta, R, t, intr):
           "integrate_depth")
 
 
-def tile_integrate_depth(dists, vol_local, zbase, voxel_size, trunc, eta, R, t, intr):
-    """integrate(depth) into a z-slab whose local plane 0 is global plane `zbase` (multi-GPU tiles)"""
-    Rm = _F9(*[float(v) for v in np.asarray(R, np.float32).reshape(9)])
-    tv = _F3(*[float(v) for v in np.asarray(t, np.float32).reshape(3)])
-    assert dists.is_cuda and dists.dtype == torch.float32 and dists.stride(1) == 1
-    check(_lib.lib().sobfu_hip_tile_integrate_depth(C.c_void_p(dists.data_ptr()), C.c_int(dists.stride(0) * 4), C.c_int(dists.shape[0]),
-                                                    C.c_int(dists.shape[1]), _ptr(vol_local), *_xyz(vol_local), C.c_int(int(zbase)),
-                                                    _F3(*[float(v) for v in voxel_size]), _f(trunc), _f(eta), Rm, tv, _f(intr[0]),
-                                                    _f(intr[1]), _f(intr[2]), _f(intr[3]), _stream()), "tile_integrate_depth")
-
-
 def tile3_integrate_depth(dists, vol_local, base, voxel_size, trunc, eta, R, t, intr):
     """integrate(depth) into a tile whose local cell (0, 0, 0) is global cell `base` = (xb, yb, zb) (multi-GPU tiles)"""
     Rm = _F9(*[float(v) for v in np.asarray(R, np.float32).reshape(9)])
