@@ -130,6 +130,13 @@ def test_hip_matches_oracle(oracle, case):
         assert np.array_equal(occ_d[2, :count_d].cpu().numpy(), occ_o[2, :count_o])
     v_d, n_d = ops.marching_cubes(d, size, R, t, **kw)
     assert v_d.shape[0] == v_o.shape[0]
+    # with a caller-kept workspace (no allocation inside the scan steps; what kfusion::cuda::MarchingCubes passes): same mesh
+    ws = ops.mc_workspace(d)
+    for _ in range(2):  # reused across calls
+        v_w, n_w = ops.marching_cubes(d, size, R, t, workspace=ws, **kw)
+        assert torch.equal(v_w.view(torch.int32), v_d.view(torch.int32)) and torch.equal(n_w.view(torch.int32), n_d.view(torch.int32))
+    v_w, _ = ops.marching_cubes(d, size, R, t, workspace=ws[:16], **kw)  # too small: falls back to per-call scratch
+    assert torch.equal(v_w.view(torch.int32), v_d.view(torch.int32))
     assert np.array_equal(v_d.cpu().numpy().view(np.uint32), v_o.view(np.uint32))
     assert np.array_equal(n_d.cpu().numpy(), n_o, equal_nan=True)  # degenerate triangles carry NaN normals on both sides
     if case == "capped":
