@@ -125,7 +125,9 @@ def run_world(dims, grid, psi0, pg, pn, n_iters, thr, schedule=None):
                                                # splits, ragged extents, an interior tile with both neighbours on every axis
                                                ((40, 24, 36), (2, 2, 2), None), ((64, 64, 64), (2, 2, 2), None), ((33, 17, 16), (1, 2, 2), None),
                                                ((70, 33, 23), (2, 1, 1), None), ((40, 24, 36), (1, 2, 1), None), ((40, 24, 36), (2, 2, 1), None),
-                                               ((141, 19, 17), (2, 1, 2), None), ((36, 36, 36), (3, 3, 3), None)])
+                                               ((141, 19, 17), (2, 1, 2), None), ((36, 36, 36), (3, 3, 3), None),
+                                               # the smallest tiles the layout allows (4 owned cells per split axis: a message is the whole tile)
+                                               ((8, 9, 10), (2, 2, 2), None), ((12, 8, 8), (3, 2, 1), None)])
 def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
     import torch
 
