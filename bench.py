@@ -79,7 +79,7 @@ def cpu_baseline(P, budget_s=12.0):
     import oracle as O
 
     O.build()
-    all_cores = O.num_threads()
+    all_cores = O.num_threads()  # the affinity mask capped by the container's cgroup CPU quota (oracle.usable_cpus)
     dim = P["dims"][0]
     one = _cpu_rate(O, P, all_cores, 1, 0)  # sizes the sample (and warms the pages)
     n = int(max(2, min(20, budget_s * one)))
@@ -92,7 +92,8 @@ def cpu_baseline(P, budget_s=12.0):
     c1_all = _cpu_rate(O, P1, all_cores, 10, 2)
     c1_one = _cpu_rate(O, P1, 1, 10, 2)
     O.set_num_threads(all_cores)
-    what = "oracle/sobfu_oracle.c, OpenMP over z-planes, -O3 -ffp-contract=off, Jacobian pass skipped"
+    what = (f"oracle/sobfu_oracle.c, OpenMP over z-planes on the {all_cores} CPUs the container may use (affinity mask "
+            f"{len(os.sched_getaffinity(0))}, capped by its cgroup CPU quota), -O3 -ffp-contract=off, Jacobian pass skipped")
     return {"value": v_all, "unit": "iterations/s", "cores": all_cores, "kind": "port",
             "sample": f"{n} solver iterations of the same {dim}^3 workload after 1 warm-up iteration ({what})",
             "one_core": {"value": v_one, "unit": "iterations/s", "cores": 1, "sample": f"{n1} solver iterations of the same {dim}^3 workload"},

@@ -48,6 +48,25 @@ class SolverParams(C.Structure):
 _lib = None
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  A container that shows 256 CPUs but
+    is throttled to 16 runs the OpenMP loops on all of them several times slower than on 16."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -61,6 +80,7 @@ def lib():
         _lib.so_estimate_psi.restype = C.c_int
         _lib.so_sobolev_filter.restype = C.c_int
         _lib.so_num_threads.restype = C.c_int
+        _lib.so_set_num_threads(C.c_int(min(int(_lib.so_num_threads()), usable_cpus())))
     return _lib
 
 
