@@ -988,13 +988,14 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
 #define SOBFU_LAUNCH_B(UPD, CMP, TRN) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, TRN>), grid, block, 0, stream, a)
+    const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
     if (tr) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);
+        else if (compact && idx32) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, true, true, 0>), grid, block, 0, stream, a);
         else if (compact) SOBFU_LAUNCH_B(false, true, true);
         else SOBFU_LAUNCH_B(false, false, true);
     } else {
-        const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
         if (updates && compact) SOBFU_LAUNCH_B(true, true, false);
         else if (updates) SOBFU_LAUNCH_B(true, false, false);
         else if (compact && idx32) {
