@@ -358,6 +358,24 @@ struct PassAArgs {
     float max_update_norm;
 };
 
+#ifndef SOBFU_PIN
+#define SOBFU_PIN 2  // bit 0: pass A, bit 1: pass B
+#endif
+// The marching loops store under a per-lane "this cell is mine" test, and the compiler sinks everything that consumes the step's
+// loads into that branch with the stores.  On the path around the branch it must then assume the loads still in flight, so at
+// the join -- the pipeline shift, the next step's halo staging -- it waits for vmcnt(0), which on the path that DID store also
+// waits for the stores' acknowledgement: once per plane per wave, on the critical chain.  Pinning the value about to be stored
+// in front of the branch makes the wait for its loads unconditional (same place: behind the arithmetic), the join then knows
+// that every load has landed, and the stores drain behind the next plane's work.
+template <int BIT>
+SOBFU_DEV void pin3(const float4& v) {
+    if (SOBFU_PIN & BIT) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z));
+}
+template <int BIT>
+SOBFU_DEV void loads_landed() {
+    if (SOBFU_PIN & BIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched (gfx9 encoding)
+}
+
 template <int RPT, int WY, bool COMPACT, bool TRANSPOSABLE>
 __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
     constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
@@ -425,6 +443,7 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
 
     const bool ulo = (u == 0), uhi = (u == tg.DU - 1);
+    loads_landed<1>();  // the prologue's requests: the loop header then has nothing to wait for on the back edge either
     for (int z = zb; z < ze; ++z) {
         const int buf = (z - zb) & 1;
         // stage plane z
@@ -500,6 +519,7 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
             // calculate_potential_gradient_kernel (solver.cu:28-31)
             float diff = fc[r] - bg[r];
             float4 o   = add4(mul4(g, diff), mul4(L, a.w_reg));
+            pin3<1>(o);
             if (u < tg.u_hi && v < tg.v_hi) {
                 const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
                 if (SOBFU_NT >= 4) stv_nt<COMPACT>(a.nU, i, o);
@@ -769,6 +789,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             p.x -= uu.x;
             p.y -= uu.y;
             p.z -= uu.z;
+            pin3<2>(p);
             if (mine[r]) {
                 if (owned[r] && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
                 // inside the box no clamp was active: off[r] is the cell itself
