@@ -745,6 +745,26 @@ def test_native_tiled_loop_comm_choreography_on_one_rank(ops, oracle, monkeypatc
 
 
 # ---------------------------------------------------------------------------------------------------
+# long marches on a small grid: the pass-B variant big grids run (halo requests three planes ahead through the LDS FIFO) is
+# picked when a z-chunk has >= 24 planes -- forced here with the tuning override, on grids the oracle finishes in seconds,
+# including chunk lengths that leave a short last chunk and a chunk that is the whole volume
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims,zc", [((70, 33, 80), 24), ((70, 33, 80), 31), ((40, 24, 96), 96), ((65, 9, 50), 27)])
+def test_long_march_variant_on_small_grids(ops, oracle, dims, zc, monkeypatch):
+    monkeypatch.setenv("SOBFU_ZC_B", str(zc))
+    pg, pn = rand_volume(dims, 91), rand_volume(dims, 92)
+    psi = warped_identity(oracle, dims, 93, 0.9)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=4, alpha=0.05, w_reg=0.4, inverse_iters=0, compute_jacobian=False)
+    sv = ops.Solver(dims, max_iter=4, alpha=0.05, w_reg=0.4)
+    psi_d, pnp_d = dev(warped_identity(oracle, dims, 93, 0.9)), ops.new_volume(dims)
+    _, hist = sv.iterate(dev(pg), dev(pn), pnp_d, psi_d, 4)
+    assert nmis(host(psi_d), psi) == 0
+    assert nmis(host(pnp_d), r["phi_n_psi"]) == 0
+    assert same(hist, r["trace"][:, 2])
+    sv.close()
+
+
+# ---------------------------------------------------------------------------------------------------
 # the loop in pieces (sobfu_hip_solver_begin / step / end): same bits as iterate(), whatever the step sizes
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dims", [(64, 64, 64), (40, 24, 20), (17, 9, 5), (70, 33, 19), (2, 2, 2), (65, 9, 2)])
