@@ -121,6 +121,49 @@ def test_tile_layout_properties():
         TileLayout((6, 64, 64), (2, 1, 1), 0)
 
 
+def test_tile_messages_carry_the_right_cells():
+    """random extents and grids: what a rank sends are cells it OWNS, they land on the SAME global cells in the peer's halo, and
+    together the messages a rank receives cover exactly the face and edge halo cells pass B's stencils reach (4 cells along one
+    axis, or along two -- never all three)"""
+    from sobfu_amd.tiled import HALO, TileLayout
+
+    rng = np.random.default_rng(7)
+    cases = 0
+    while cases < 40:
+        grid = tuple(int(g) for g in rng.integers(1, 4, 3))
+        dims = tuple(int(d) for d in rng.integers(9, 40, 3))
+        try:
+            lays = [TileLayout(dims, grid, r) for r in range(grid[0] * grid[1] * grid[2])]
+        except ValueError:
+            continue  # a tile thinner than the halo: refused (covered above)
+        cases += 1
+        for L in lays:
+            got = np.zeros(L.local_shape()[:3], np.int32)  # (Lz, Ly, Lx)
+            for peer, sb, rb in L.messages():
+                P = lays[peer]
+                back = [m for m in P.messages() if m[0] == L.rank][0]
+                # my send box, in global cells, is the peer's receive box for me, in global cells
+                mine = tuple(sb[2 * a + k] + L.base[a] for a in range(3) for k in range(2))
+                theirs = tuple(back[2][2 * a + k] + P.base[a] for a in range(3) for k in range(2))
+                assert mine == theirs, (dims, grid, L.rank, peer)
+                # ... cells I own ...
+                assert all(L.g0[a] <= mine[2 * a] and mine[2 * a + 1] <= L.g1[a] for a in range(3))
+                # ... and what I receive lies in my halo, outside the cells I own
+                g = tuple(rb[2 * a + k] + L.base[a] for a in range(3) for k in range(2))
+                assert any(g[2 * a + 1] <= L.g0[a] or g[2 * a] >= L.g1[a] for a in range(3))
+                got[rb[4]:rb[5], rb[2]:rb[3], rb[0]:rb[1]] += 1
+            # cells of the local array outside the owned box, by the number of axes along which they are outside
+            out = [np.zeros(L.L[a], bool) for a in range(3)]
+            for a in range(3):
+                o0 = L.g0[a] - L.base[a]
+                out[a][:o0] = True
+                out[a][o0 + (L.g1[a] - L.g0[a]):] = True
+            n_out = out[2][:, None, None].astype(np.int32) + out[1][None, :, None] + out[0][None, None, :]
+            assert ((got == 1) == ((n_out == 1) | (n_out == 2))).all(), (dims, grid, L.rank)
+            assert (got <= 1).all()
+            assert all(L.lo3[a] in (0, HALO) and L.hi3[a] in (0, HALO) for a in range(3))
+
+
 def test_layout_properties():
     from sobfu_amd.tiled import SlabLayout
 
