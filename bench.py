@@ -89,8 +89,11 @@ def cpu_baseline(P, budget_s=12.0):
     # BASELINE config 1: 64^3, params_advent.ini solver values, 10 iterations
     vs = np.array([np.float32(0.5) / np.float32(64)] * 3, np.float32)
     P1 = dict(dims=(64, 64, 64), vs=vs, trunc=np.float32(5) * vs[0], eta=np.float32(2) * vs[0], alpha=0.1, w_reg=0.2)
-    c1_all = _cpu_rate(O, P1, all_cores, 10, 2)
-    c1_one = _cpu_rate(O, P1, 1, 10, 2)
+    # sized to >= ~0.5 s each: 10 iterations (27 ms on 16 threads) swung 2x between boxes
+    n_all = int(max(10, min(2000, 0.6 * _cpu_rate(O, P1, all_cores, 10, 2))))
+    c1_all = _cpu_rate(O, P1, all_cores, n_all, 0)
+    n_one = int(max(10, min(400, 0.6 * _cpu_rate(O, P1, 1, 10, 2))))
+    c1_one = _cpu_rate(O, P1, 1, n_one, 0)
     O.set_num_threads(all_cores)
     what = (f"oracle/sobfu_oracle.c, OpenMP over z-planes on the {all_cores} CPUs the container may use (affinity mask "
             f"{len(os.sched_getaffinity(0))}, capped by its cgroup CPU quota), -O3 -ffp-contract=off, Jacobian pass skipped")
@@ -99,8 +102,8 @@ def cpu_baseline(P, budget_s=12.0):
             "one_core": {"value": v_one, "unit": "iterations/s", "cores": 1, "sample": f"{n1} solver iterations of the same {dim}^3 workload"},
             "config1_64": {"all_cores": {"value": c1_all, "cores": all_cores}, "one_core": {"value": c1_one, "cores": 1},
                            "unit": "iterations/s",
-                           "sample": "10 solver iterations on BASELINE config 1's grid (64^3, alpha 0.1, w_reg 0.2, S=7, lambda 0.1, two "
-                                     "analytic spheres) after 2 warm-up iterations"}}
+                           "sample": f"{n_all} (all cores) / {n_one} (one core) solver iterations on BASELINE config 1's grid (64^3, alpha 0.1, "
+                                     "w_reg 0.2, S=7, lambda 0.1, two analytic spheres) after 12 warm-up iterations: >= 0.5 s each"}}
 
 
 def _free_port():
@@ -307,7 +310,7 @@ def main():
             "metric": f"solver iterations/sec on {args.dim}^3 voxel grid",
             "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * med / K, "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and not replicas) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": ("strong" if not replicas else "weak") if world > 1 else "single", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.dim}^3 TSDF, params_boxing.ini solver values (alpha 0.001, w_reg 0.6, S=7, "
                                    f"lambda 0.1, max_update_norm 1e-10), two analytic spheres 1.3 voxels apart; a step = one solver "
                                    f"iteration of an open solve",
@@ -342,27 +345,31 @@ def main():
                 "event_sum_vs_step": (ms_a + ms_b + (res.get("ms_exchange") or 0.0)) / (1e3 * med / K),
             }
             if res.get("ms_exchange") is not None:  # N > 1, serial schedule: what an iteration is made of
-                out["tiled_iteration_ms"] = {"pass_a": ms_a, "exchange_incl_pack_unpack_and_peer_wait": res["ms_exchange"], "pass_b": ms_b}
+                out["tiled_iteration_ms"] = {"pass_a_incl_message_stores" + ("_and_peer_wait" if res.get("transport") == "direct" else ""): ms_a,
+                                             "exchange_transfer_and_scatter": res["ms_exchange"], "pass_b": ms_b}
         if res.get("solve50_s"):
             s50 = res["solve50_s"]
             out["per_solve"] = {"iterations": 50, "ms": 1e3 * s50, "fixed_ms": 1e3 * s50 - 50 * 1e3 * med / K,
                                 "iterations_per_s_incl_fixed": 50 / s50,
                                 "note": "one whole sobfu_hip_solver_iterate call of 50 iterations (BASELINE config 3's frame): enter the "
                                         "compact format + 50 iterations + max-norm rows to the host + leave, host-synchronised"}
-        for k in ("tiles", "tiled_autotune_us", "tiled_diag"):
+        for k in ("tiles", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback"):
             if res.get(k):
                 out[k] = res[k]
         if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise
             out["tiled_parity_vs_single_gpu"] = "bit-exact" if res["tiled_parity"] else "MISMATCH"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P)
-    if res.get("diag_hung"):  # a diagnostics collective never returned on this rank: report what was measured and leave
+    mismatch = res.get("tiled_parity") is False  # every rank holds the same verdict (MIN over ranks)
+    if res.get("diag_hung_any"):
+        # a diagnostics collective never returned on SOME rank (the verdict was agreed over a side channel that is not the
+        # wedged communicator): nobody enters another collective -- every rank reports what was measured and leaves
         if rank == 0:
             import ctypes
 
             ctypes.CDLL(None).fflush(None)
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3 if mismatch else 0)
     ranks.close()
     if rank == 0:  # after the process group is gone, and after flushing C stdio (RCCL's version banner sits in libc's stdout
         # buffer until exit when stdout is a pipe), so that the JSON is the LAST line on stdout
@@ -374,6 +381,8 @@ def main():
         # nothing may follow the line on stdout (RCCL writes banners from destructors / at exit): point fd 1 at /dev/null for the
         # rest of the process instead of killing it -- exit hooks (rocprofv3 writing its results) must still run
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if mismatch:  # the line above says MISMATCH; the exit code says so too
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

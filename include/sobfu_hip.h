@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SOBFU_HIP_ABI_VERSION 2
+#define SOBFU_HIP_ABI_VERSION 3
 
 #define SOBFU_E_BADARG (-1)      /* null pointer, non-positive dims, ... */
 #define SOBFU_E_FILTER (-2)      /* (s, lambda) not in the reference's Sobolev filter table */
@@ -165,8 +165,9 @@ int sobfu_hip_extract_tsdf(const float* d_src2, float* d_dst1, size_t n, void* s
 /* Multi-GPU tiles (the 2x2x2 split of BASELINE config 4, z-slabs as 1x1xN): every field argument is a LOCAL
  * array (Lx, Ly, Lz) whose cell (0, 0, 0) is global cell (xb, yb, zb) of the (Xg, Yg, Zg) volume and that carries halo cells on every side that faces a neighbour tile;
  * d_phi_n / d_phi / the d_psi of estimate_inverse are WHOLE volumes.  `box` = (x0, x1, y0, y1, z0, z1): the cells a launch produces;
- * `own`: the cells that belong to this rank (they alone enter the max-norm).  transposed != 0 maps the 64 lanes of a wave onto y
- * instead of x -- for boxes that are thin in x (same results).  Boundary rules apply at array edges, which are volume boundaries
+ * `own`: the cells that belong to this rank (they alone enter the max-norm).  thin != 0 evaluates the box DIRECTLY -- one lane per
+ * cell, every tap read through the caches -- instead of by a z-march: for boxes a few cells thick (the one-cell shells of a tile,
+ * halo faces), same results.  A thin pass-A launch is never gated (it writes scratch only).  Boundary rules apply at array edges, which are volume boundaries
  * exactly where a tile has no halo.  compact != 0: the field arguments are in the compact iteration format -- psi / nabla_U 12-byte
  * xyz triples, phi_n o psi / phi_global / phi_n tsdf-only floats.  d_prev_slots (may be NULL) and max_update_norm form the
  * device-side convergence gate (see the solver handle). */
@@ -179,11 +180,11 @@ int sobfu_hip_tile3_integrate_depth(const float* d_dists, int dists_step_bytes, 
                                     int Lz, int xb, int yb, int zb, const float voxel_size[3], float trunc_dist, float eta,
                                     const float R[9], const float t[3], float fx, float fy, float cx, float cy, void* stream);
 int sobfu_hip_tile3_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U,
-                                       float w_reg, int Lx, int Ly, int Lz, const int box[6], int transposed,
+                                       float w_reg, int Lx, int Ly, int Lz, const int box[6], int thin,
                                        const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
 int sobfu_hip_tile3_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi, float* d_updates,
                                         uint32_t* d_max_sq_slots, const float taps[7], float alpha, int Lx, int Ly, int Lz, int Xg,
-                                        int Yg, int Zg, const int own[6], const int box[6], int transposed,
+                                        int Yg, int Zg, const int own[6], const int box[6], int thin,
                                         const uint32_t* d_prev_slots, float max_update_norm, int compact, void* stream);
 int sobfu_hip_tile3_apply_tsdf_only(const float* d_phi1, int Xg, int Yg, int Zg, float* d_out1, const float* d_psi3, int Lx, int Ly, int Lz,
                                     void* stream);
@@ -340,8 +341,8 @@ typedef struct {
     int peer;
     size_t send_off, recv_off, count; /* in floats */
 } sobfu_hip_tiled_msg;
-/* The messages of one exchange of a 3-D tile and the boxes (6 ints each: x0, x1, y0, y1, z0, z1, local cells) they are packed
- * from / scattered to; returns their number (0 for z-slabs, whose messages are plane ranges of the field itself). */
+/* The messages of one exchange and the boxes (6 ints each: x0, x1, y0, y1, z0, z1, local cells) they are packed from / scattered
+ * to; returns their number (z-slabs on the RCCL transport send the same cells as plane ranges of the field itself). */
 int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int* send_boxes, int* recv_boxes, int max_msgs);
 /* Timing of the SERIAL schedule's pieces with HIP events on the loop's stream around every stride-th iteration (0 = off;
  * max_samples events sets are created here, outside any timed region): ms[0] pass A, ms[1] the exchange (pack + transfer +
@@ -360,6 +361,31 @@ typedef int (*sobfu_hip_tiled_exchange_fn)(void* ctx, int rank, const float* d_s
 typedef int (*sobfu_hip_tiled_allreduce_fn)(void* ctx, int rank, uint32_t* d_buf, size_t n, void* stream);
 int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_fn exchange, sobfu_hip_tiled_allreduce_fn allreduce_max,
                                   void* ctx);
+/* DIRECT transport (communicator-less handles): the halo cells travel as plain stores from pass A's launch into the neighbours'
+ * own nabla_U arrays, peer-mapped over xGMI -- no pack / unpack kernels, no communication launch, no collective in the loop; arrival
+ * flags and the max-norm rows travel the same way (see sobfu_amd/csrc/tiled_capi.hip).  Every rank exports four device
+ * allocations (sobfu_hip_tiled_exports_get; across processes: sobfu_hip_ipc_export -> 64-byte handles -> sobfu_hip_ipc_open on the
+ * other side), hands the pointers of ALL other ranks -- valid in ITS process -- to sobfu_hip_tiled_connect, and every rank must have
+ * connected (a barrier of the caller's) before any begins a solve.  A peer whose flag does not arrive within
+ * SOBFU_TILED_DEADLINE_S (default 30 s) is recorded instead of waited for: _end / _status return SOBFU_E_TIMEOUT. */
+#define SOBFU_E_TIMEOUT (-5) /* a peer did not answer within the deadline; the handle is dead (destroy it) */
+typedef struct {
+    void* nabla_u[2]; /* the two halves of the double-buffered nabla_U tile (12-byte cells, local extents) */
+    void* flags;      /* arrival flags, one uint32 per rank */
+    void* rows;       /* global max-norm rows, 256 uint32 per iteration */
+} sobfu_hip_tiled_exports;
+int sobfu_hip_tiled_exports_get(const sobfu_hip_tiled* t, sobfu_hip_tiled_exports* out);
+int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ranks, const sobfu_hip_tiled_exports* peers);
+int sobfu_hip_ipc_export(const void* d_ptr, char handle[64]);
+int sobfu_hip_ipc_open(const char handle[64], void** d_ptr);
+int sobfu_hip_ipc_close(void* d_ptr);
+/* 0, or SOBFU_E_TIMEOUT with the rank that was missing (-1: unknown) */
+int sobfu_hip_tiled_status(sobfu_hip_tiled* t, int* missing_peer);
+/* test hooks: wait = 0 turns the in-kernel wait for the peers' flags off (a harness that drives N ranks from ONE process steps
+ * them phase by phase with host barriers instead: phase 0 = pass A incl. the pushes, phase 1 = pass B; after the last iteration
+ * phase 2 = the end-of-solve handshake, then sobfu_hip_tiled_end) */
+int sobfu_hip_tiled_set_wait(sobfu_hip_tiled* t, int wait);
+int sobfu_hip_tiled_step_phase(sobfu_hip_tiled* t, int phase, void* stream);
 /* bring-up helpers: the loop's halo exchange on a caller-provided 12-byte tile field (planes < 4: z-slabs only); a self
  * send/recv and a MAX all-reduce through the same RCCL entry points (usable with a single rank) */
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream);

@@ -6,16 +6,44 @@
 #include <cstdint>
 
 namespace sobfu_hip {
-// A box of cells [x0, x1) x [y0, y1) x [z0, z1) of the (local) array a fused pass produces; tr: the 64 lanes of a wave run
-// along y instead of x (boxes that are thin in x).  Up to 6 boxes per launch; empty boxes are skipped.
+// A box of cells [x0, x1) x [y0, y1) x [z0, z1) of the (local) array a fused pass produces; direct: a THIN box, evaluated one
+// lane per cell straight from the caches instead of by a z-march (the one-cell shells of a tile, halo messages).  Up to 6 boxes
+// per launch; empty boxes are skipped.
 struct LaunchBox {
     int x0, x1, y0, y1, z0, z1;
-    bool tr;
+    bool direct;
+};
+// A box of a tile's pass A.  dst != null: a PUSH box (direct) -- the cells of one halo message, whose results go to
+// dst + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz))) only: the neighbour's halo cells (peer-mapped) or a packed send buffer.
+struct TileLaunchBox {
+    LaunchBox box;
+    float* dst;
+    int ox, oy, oz, px, py;
 };
 // (X, Y, Z): extents of the field arrays; (pX, pY, pZ): extents of phi_n (the whole volume); own: the cells that enter the
 // max-norm (x0, x1, y0, y1, z0, z1).
 int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const LaunchBox* boxes,
                         int n, const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact);
+// Signalling state of the direct transport (device memory, one per tiled handle; filled by sobfu_hip_tiled_connect and read by
+// the tail of tile_potential_gradient_kernel).
+constexpr int kMaxSync = 64;
+struct TileSync {
+    uint32_t ticket_push, ticket_all;  // 0 at rest
+    uint32_t err;                      // 0, or 1 + the rank whose flag did not arrive before the deadline
+    uint32_t n_sync;                   // ranks this rank signals and waits for
+    uint32_t my_rank, world;
+    uint64_t timeout_ticks;            // wall_clock64 ticks (100 MHz)
+    uint32_t* my_flags;                // [world] arrival flags, written by the peers
+    uint32_t* my_grows;                // global max-norm rows [iteration][256], entry q written by rank q
+    int sync_rank[kMaxSync];
+    uint32_t* peer_flags[kMaxSync];    // the flags array of sync_rank[i]
+    uint32_t* peer_grows[kMaxSync];    // its global rows
+};
+// sync: device pointer to the handle's TileSync (null: no signalling); seq / wait / row / row_index: see TilePassAArgs
+int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
+                       int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact);
+// end of a solve on the direct transport: push the last max-norm row (row may be null), raise the flags with `seq`, wait
+int launch_tile_flush(TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream);
 int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots, const float taps[7],
                         float alpha, int X, int Y, int Z, int pX, int pY, int pZ, const int own[6], const LaunchBox* boxes, int n,
                         const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact,

@@ -176,9 +176,8 @@ int ensure_events(sobfu_hip_solver* s, size_t n) {
 //        rebuilds the caller's buffers.  sobfu_hip_solver_iterate / estimate_psi are begin + enqueue(max_iter) + end;
 //        the session entry points of the C ABI expose the pieces (a frame loop that interleaves other work, bench.py's
 //        timed region of exactly K iterations).
-int session_begin(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int cap, hipStream_t st) {
+int session_begin_impl(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int cap, hipStream_t st) {
     sobfu_hip_solver::Session& q = s->q;
-    if (q.active) return SOBFU_E_BADARG;
     const int X = s->X, Y = s->Y, Z = s->Z;
     q = sobfu_hip_solver::Session{};
     q.pg = pg; q.pn = pn; q.pnp = pnp; q.psi = psi;
@@ -186,7 +185,6 @@ int session_begin(sobfu_hip_solver* s, const float* pg, const float* pn, float* 
     q.compact = s->compact && cap > 0;
     q.last_norm = NAN;
     if (!q.compact) SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
-    q.active = true;
     if (cap <= 0) return 0;
     SOBFU_TRY(ensure_slots(s, cap));
     SOBFU_HIP_TRY(hipMemsetAsync(s->slots, 0, (size_t) (cap + 1) * kSlots * 4, st));
@@ -205,6 +203,14 @@ int session_begin(sobfu_hip_solver* s, const float* pg, const float* pn, float* 
     if (s->p.max_update_norm >= 0.f) SOBFU_TRY(ensure_poll(s, cap));
     if (s->prof_stride > 0) SOBFU_TRY(ensure_events(s, (size_t) 3 * (cap / s->prof_stride + 1)));
     return 0;
+}
+// the session is open only once every allocation and launch of begin has succeeded: a failed begin (out of memory at 512^3,
+// say) leaves the handle usable instead of rejecting every later call with "session open"
+int session_begin(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int cap, hipStream_t st) {
+    if (s->q.active) return SOBFU_E_BADARG;
+    const int rc = session_begin_impl(s, pg, pn, pnp, psi, cap, st);
+    s->q.active = rc == 0;
+    return rc;
 }
 
 // examine the rows [q.checked, upto) that sit in the pinned mirror
@@ -405,6 +411,7 @@ const char* sobfu_hip_error_string(int code) {
         case SOBFU_E_FILTER: return "sobfu_hip: (s, lambda) not in the Sobolev filter table";
         case SOBFU_E_UNSUPPORTED: return "sobfu_hip: unsupported configuration";
         case SOBFU_E_RCCL: return "sobfu_hip: RCCL not loaded or an RCCL call failed (see stderr)";
+        case SOBFU_E_TIMEOUT: return "sobfu_hip: a peer rank did not answer within the deadline (see stderr); the tiled handle is dead";
         default: return code > 0 ? hipGetErrorString((hipError_t) code) : "sobfu_hip: unknown error";
     }
 }

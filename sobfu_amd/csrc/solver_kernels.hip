@@ -13,6 +13,7 @@
 // Arithmetic is op-for-op the reference's (see sobfu_device.hpp): results are bit-identical to Part 1.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "sobfu_device.hpp"
 #include "sobfu_hip.h"
@@ -216,11 +217,15 @@ SOBFU_DEV float interp_tsdf_only32(const float* __restrict__ v, const Dims& d, f
 // --- workgroup -> tile map ---------------------------------------------------------------------------------------
 // A launch produces up to kMaxBoxes BOXES of cells of the (local) array: the whole volume on a single GPU; on a multi-GPU
 // tile, the owned cells (plus the one-cell shells pass B refreshes) or the boundary / interior regions of an overlapped
-// schedule.  Workgroups are numbered box after box; inside a box x-tile (64 lanes) fastest, then y-tile, then z-chunk.
-// A TRANSPOSED box maps the 64 lanes of a wave onto y and the workgroup's rows onto x -- for regions that are thin in x
-// (the one-column x shell of a tile, 4-column x faces), where x-major lanes would leave all but a few lanes of every
-// wave idle.  Its global accesses are strided instead of coalesced; such boxes hold a few per cent of the cells.
-// (u, v) below are the lane-axis and row-axis coordinates: (x, y), or (y, x) in a transposed box.
+// schedule.  Workgroups are numbered box after box.
+//   MARCHING box (kind 0): x-tile (64 lanes) fastest, then y-tile, then z-chunk; a workgroup marches its z-chunk with the
+//       register / LDS pipeline described above.
+//   DIRECT box (kind 1): one lane per cell, every tap read straight from the L1 / L2 -- for THIN regions (the one-cell x / y
+//       shells of a tile, the 4-cell faces and 4 x 4 edge strips that travel to the neighbours), where a march would either
+//       leave 63 of 64 lanes idle (regions thin in x), waste most of an 8-row tile (thin in y) or be all prologue (thin in
+//       z).  A wave covers a (wx x 64/wx) patch of an x-y plane, wx = min(64, pow2ceil(x extent)): coalesced along x as far
+//       as the box allows; no LDS, no barrier, one round trip.  Such boxes hold a few per cent of the cells, so the ~20
+//       cached loads a cell costs this way do not matter; the arithmetic is op for op the marching path's.
 //
 // With the XCD swizzle the linear id is first remapped so that each XCD (workgroup b runs on XCD b % 8 -- observed, used
 // for speed only) owns a contiguous run of tiles and serves neighbour-tile halos from its own L2.  PMC (256^3): fabric
@@ -228,8 +233,8 @@ SOBFU_DEV float interp_tsdf_only32(const float* __restrict__ v, const Dims& d, f
 constexpr int kMaxBoxes = 6;
 struct Box {
     int x0, x1, y0, y1, z0, z1;  // cells [x0, x1) x [y0, y1) x [z0, z1)
-    int zc;                      // planes per march (z-chunk)
-    int tr;                      // transposed
+    int zc;                      // marching: planes per march (z-chunk); direct: wx, the lanes of a wave that run along x
+    int kind;                    // 0 marching, 1 direct
 };
 struct BoxList {
     int n;
@@ -237,43 +242,51 @@ struct BoxList {
     int first[kMaxBoxes + 1];  // first workgroup of box i; first[n] = workgroups in the launch
 };
 struct TileGeom {
-    int u0, v0, zb, ze;  // tile origin along the lane / row axes, planes [zb, ze) of this march
-    int u_hi, v_hi;      // cells with u >= u_hi or v >= v_hi are outside the box (computed, not stored)
-    int DU, DV;          // array extents along the lane / row axes
-    int su, sv;          // element strides of the lane / row axes
-    bool tr;
+    int u0, v0, zb, ze;  // tile origin along x / y, planes [zb, ze) of this march
+    int u_hi, v_hi;      // cells with x >= u_hi or y >= v_hi are outside the box (computed, not stored)
+    int DU, DV;          // array extents along x / y
 };
-template <bool TRANSPOSABLE, bool XCD_SWIZZLE>
-SOBFU_DEV TileGeom tile_geom(const BoxList& L, const Dims& d, int ty) {
-    unsigned t = blockIdx.x;
-    if (XCD_SWIZZLE) {
-        const unsigned nb = (unsigned) L.first[L.n], q = nb / 8u, rem = nb % 8u, xcd = t % 8u, slot = t / 8u;
-        t = xcd * q + min(xcd, rem) + slot;  // bijective for any nb
-    }
-    Box b     = L.b[0];  // constant indices only: a dynamically indexed by-value argument would be copied to scratch
-    int first = 0;
+SOBFU_DEV unsigned xcd_swizzle(unsigned t, unsigned nb) {
+    const unsigned q = nb / 8u, rem = nb % 8u, xcd = t % 8u, slot = t / 8u;
+    return xcd * q + min(xcd, rem) + slot;  // bijective for any nb
+}
+// marching geometry of workgroup t inside box b whose first workgroup is `first` (all scalar)
+SOBFU_DEV TileGeom geom_in_box(const Box& b, unsigned t, int first, const Dims& d, int ty) {
+    t -= (unsigned) first;
+    TileGeom g;
+    g.u_hi = b.x1;
+    g.v_hi = b.y1;
+    g.DU   = d.x;
+    g.DV   = d.y;
+    const unsigned ntu = (unsigned) ((b.x1 - b.x0 + TX - 1) / TX), ntv = (unsigned) ((b.y1 - b.y0 + ty - 1) / ty);
+    g.u0 = b.x0 + (int) (t % ntu) * TX;
+    g.v0 = b.y0 + (int) ((t / ntu) % ntv) * ty;
+    g.zb = b.z0 + (int) (t / (ntu * ntv)) * b.zc;
+    g.ze = min(g.zb + b.zc, b.z1);
+    return g;
+}
+// the cell of this lane in a DIRECT box; false: the lane has none
+SOBFU_DEV bool direct_cell(const Box& b, unsigned t, int first, int& x, int& y, int& z) {
+    const int wx = b.zc, wyl = 64 / wx;
+    const unsigned ntx = (unsigned) ((b.x1 - b.x0 + wx - 1) / wx), nty = (unsigned) ((b.y1 - b.y0 + wyl - 1) / wyl);
+    const unsigned w = (t - (unsigned) first) * (unsigned) blockDim.y + (unsigned) __builtin_amdgcn_readfirstlane((int) threadIdx.y);  // wave of the box
+    const int lane = threadIdx.x;
+    x = b.x0 + (int) (w % ntx) * wx + (lane & (wx - 1));
+    y = b.y0 + (int) ((w / ntx) % nty) * wyl + lane / wx;
+    z = b.z0 + (int) (w / (ntx * nty));
+    return z < b.z1 && x < b.x1 && y < b.y1;
+}
+// box of workgroup t (constant indices only: a dynamically indexed by-value argument would be copied to scratch)
+SOBFU_DEV Box find_box(const BoxList& L, unsigned t, int& first) {
+    Box b = L.b[0];
+    first = 0;
 #pragma unroll
     for (int k = 1; k < kMaxBoxes; ++k)
         if (k < L.n && (int) t >= L.first[k]) {
             b     = L.b[k];
             first = L.first[k];
         }
-    t -= (unsigned) first;
-    TileGeom g;
-    g.tr          = TRANSPOSABLE && b.tr != 0;
-    const int ulo = g.tr ? b.y0 : b.x0, vlo = g.tr ? b.x0 : b.y0;
-    g.u_hi        = g.tr ? b.y1 : b.x1;
-    g.v_hi        = g.tr ? b.x1 : b.y1;
-    g.DU          = g.tr ? d.y : d.x;
-    g.DV          = g.tr ? d.x : d.y;
-    g.su          = g.tr ? d.x : 1;
-    g.sv          = g.tr ? 1 : d.x;
-    const unsigned ntu = (unsigned) ((g.u_hi - ulo + TX - 1) / TX), ntv = (unsigned) ((g.v_hi - vlo + ty - 1) / ty);
-    g.u0 = ulo + (int) (t % ntu) * TX;
-    g.v0 = vlo + (int) ((t / ntu) % ntv) * ty;
-    g.zb = b.z0 + (int) (t / (ntu * ntv)) * b.zc;
-    g.ze = min(g.zb + b.zc, b.z1);
-    return g;
+    return b;
 }
 
 // --- convergence gate ----------------------------------------------------------------------------------------
@@ -346,16 +359,19 @@ SOBFU_DEV bool gate_decide(const GateRegs& g, const uint32_t* __restrict__ prev_
 }
 
 // --- pass A ----------------------------------------------------------------------------------------------------
-struct PassAArgs {
+struct PassACore {
     const void* pnp;  // phi_n o psi
     const void* pg;   // phi_global
     const void* psi;
     void* nU;
     Dims d;  // extents of the (local) arrays
     float w_reg;
-    BoxList boxes;  // the cells this launch produces
     const uint32_t* prev_slots;
     float max_update_norm;
+};
+struct PassAArgs {
+    PassACore c;
+    BoxList boxes;  // the cells this launch produces
 };
 
 #ifndef SOBFU_PIN
@@ -376,26 +392,69 @@ SOBFU_DEV void loads_landed() {
     if (SOBFU_PIN & BIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched (gfx9 encoding)
 }
 
-template <int RPT, int WY, bool COMPACT, bool TRANSPOSABLE>
-__global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
+// One cell of pass A from its centre c = psi, fc = (phi_n o psi).tsdf, bg = phi_global.tsdf and the six RAW neighbours of psi
+// (p**) and of F (f**) along x (l), y (r), z -- loaded with clamped indices; the boundary rules are applied here.  Shared by
+// the marching and the direct path: the same operations in the same order.
+SOBFU_DEV float4 potential_gradient_cell(const float4& c, float fc, float bg, float4 plp, float4 plm, float4 prp, float4 prm, float4 pzp,
+                                         float4 pzm, float flp, float flm, float frp, float frm, float fzp, float fzm, bool ulo, bool uhi,
+                                         bool vlo, bool vhi, bool zlo, bool zhi, float w_reg) {
+    // TsdfDifferentiator boundary rule (vector_fields.cu:165-191): mirror the missing neighbour
+    const float gl1 = uhi ? flm : flp, gl2 = ulo ? flp : flm;
+    const float gr1 = vhi ? frm : frp, gr2 = vlo ? frp : frm;
+    const float gz1 = zhi ? fzm : fzp, gz2 = zlo ? fzp : fzm;
+    const float4 g = f4((gl1 - gl2) / 2.f, (gr1 - gr2) / 2.f, (gz1 - gz2) / 2.f);
+    // SecondOrderDifferentiator boundary rule (vector_fields.cu:299-331): both neighbours <- centre
+    if (ulo || uhi) { plp = c; plm = c; }
+    if (vlo || vhi) { prp = c; prm = c; }
+    if (zlo || zhi) { pzp = c; pzm = c; }
+    // the reference adds x+, x-, y+, y-, z+, z- in that order
+    float4 vv = mul4(c, -6.f);
+    vv = add4(vv, plp);
+    vv = add4(vv, plm);
+    vv = add4(vv, prp);
+    vv = add4(vv, prm);
+    vv = add4(vv, pzp);
+    vv = add4(vv, pzm);
+    const float4 L = mul4(vv, -1.f);
+    // calculate_potential_gradient_kernel (solver.cu:28-31)
+    const float diff = fc - bg;
+    return add4(mul4(g, diff), mul4(L, w_reg));
+}
+
+// DIRECT evaluation of one cell of pass A (thin boxes): 7 psi + 7 F + 1 G loads, all but a few of them cache hits
+template <bool COMPACT>
+SOBFU_DEV float4 pass_a_direct_cell(const PassACore& a, int x, int y, int z) {
+    const Dims d = a.d;
+    const int xm = max(x - 1, 0), xp = min(x + 1, d.x - 1), ym = max(y - 1, 0), yp = min(y + 1, d.y - 1), zm = max(z - 1, 0), zp = min(z + 1, d.z - 1);
+    const size_t i = vidx(d, x, y, z), ixm = vidx(d, xm, y, z), ixp = vidx(d, xp, y, z), iym = vidx(d, x, ym, z), iyp = vidx(d, x, yp, z),
+                 izm = vidx(d, x, y, zm), izp = vidx(d, x, y, zp);
+    const float4 c = ldv<COMPACT>(a.psi, i);
+    const float4 plp = ldv<COMPACT>(a.psi, ixp), plm = ldv<COMPACT>(a.psi, ixm), prp = ldv<COMPACT>(a.psi, iyp), prm = ldv<COMPACT>(a.psi, iym),
+                 pzp = ldv<COMPACT>(a.psi, izp), pzm = ldv<COMPACT>(a.psi, izm);
+    const float fc = ldt<COMPACT>(a.pnp, i), flp = ldt<COMPACT>(a.pnp, ixp), flm = ldt<COMPACT>(a.pnp, ixm), frp = ldt<COMPACT>(a.pnp, iyp),
+                frm = ldt<COMPACT>(a.pnp, iym), fzp = ldt<COMPACT>(a.pnp, izp), fzm = ldt<COMPACT>(a.pnp, izm);
+    const float bg = ldt<COMPACT>(a.pg, i);
+    return potential_gradient_cell(c, fc, bg, plp, plm, prp, prm, pzp, pzm, flp, flm, frp, frm, fzp, fzm, x == 0, x == d.x - 1, y == 0,
+                                   y == d.y - 1, z == 0, z == d.z - 1, a.w_reg);
+}
+
+// the MARCHING path of pass A for the tile tg (a z-chunk of a 64 x TY tile)
+template <int RPT, int WY, bool COMPACT>
+SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRegs& gate) {
     constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
     constexpr int NXH = (2 * TY + TX - 1) / TX;  // row-tasks for the two lane-halo columns
     constexpr int NTASK = 2 + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 t_psi[2][LH][LW + 2];  // {psi.xyz, F = (phi_n o psi).tsdf} -- psi.w is never read
 
-    const GateRegs gate = gate_load(a.prev_slots, 1);
-
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileGeom tg = tile_geom<TRANSPOSABLE, true>(a.boxes, d, TY);
     const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
-    const bool tr = tg.tr;
     const int u = u0 + lx, uc = min(u, tg.DU - 1);
-    const size_t plane = (size_t) d.x * d.y, su = (size_t) tg.su, sv = (size_t) tg.sv;
+    const size_t plane = (size_t) d.x * d.y, sv = (size_t) d.x;
 
     size_t off[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) off[r] = (size_t) uc * su + sv * (size_t) min(v0 + wy * RPT + r, tg.DV - 1);
+    for (int r = 0; r < RPT; ++r) off[r] = (size_t) uc + sv * (size_t) min(v0 + wy * RPT + r, tg.DV - 1);
     // halo tasks: task 0 = row above the tile, task 1 = row below, tasks 2.. = lane-halo cells (col -1 / col TX)
     int h_lr[TPW], h_lc[TPW];  // LDS cell
     size_t h_off[TPW];
@@ -416,7 +475,7 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
         h_lr[k] = lr;
         h_lc[k] = lc;
         int gu = min(max(u0 - 1 + lc, 0), tg.DU - 1), gv = min(max(v0 - 1 + lr, 0), tg.DV - 1);
-        h_off[k] = (size_t) gu * su + (size_t) gv * sv;
+        h_off[k] = (size_t) gu + (size_t) gv * sv;
     }
 
     // z register pipeline: m = z-1, c = z, n = z+1 (clamped loads; boundary rules applied at use)
@@ -484,41 +543,16 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
             const int v  = v0 + wy * RPT + r;
             const int lr = wy * RPT + r + 1;
             const bool vlo = (v == 0), vhi = (v == tg.DV - 1);
-            // raw neighbours along the lane axis (l*) and the row axis (r*)
-            float4 plp = t_psi[buf][lr][lx + 2], plm = t_psi[buf][lr][lx];
-            float flp = plp.w, flm = plm.w;
+            // raw neighbours along x (l*) and y (r*)
+            const float4 plp = t_psi[buf][lr][lx + 2], plm = t_psi[buf][lr][lx];
             float4 prp, prm;
             float frp, frm;
             if (r + 1 < RPT) { prp = pc[r + 1 < RPT ? r + 1 : r]; frp = fc[r + 1 < RPT ? r + 1 : r]; }
             else { prp = t_psi[buf][lr + 1][lx + 1]; frp = prp.w; }
             if (r > 0) { prm = pc[r > 0 ? r - 1 : r]; frm = fc[r > 0 ? r - 1 : r]; }
             else { prm = t_psi[buf][lr - 1][lx + 1]; frm = prm.w; }
-            float4 pzp = pn[r], pzm = pm[r];
-            float fzp = fn[r], fzm = fm[r];
-            const float4 c = pc[r];
-            // TsdfDifferentiator boundary rule (vector_fields.cu:165-191): mirror the missing neighbour
-            float gl1 = uhi ? flm : flp, gl2 = ulo ? flp : flm;
-            float gr1 = vhi ? frm : frp, gr2 = vlo ? frp : frm;
-            float gz1 = zhi ? fzm : fzp, gz2 = zlo ? fzp : fzm;
-            const float gl = (gl1 - gl2) / 2.f, gr = (gr1 - gr2) / 2.f;
-            float4 g = f4(tr ? gr : gl, tr ? gl : gr, (gz1 - gz2) / 2.f);
-            // SecondOrderDifferentiator boundary rule (vector_fields.cu:299-331): both neighbours <- centre
-            if (ulo || uhi) { plp = c; plm = c; }
-            if (vlo || vhi) { prp = c; prm = c; }
-            if (zlo || zhi) { pzp = c; pzm = c; }
-            // the reference adds x+, x-, y+, y-, z+, z- in that order: a transposed box swaps the roles of lanes and rows
-            const float4 pxp = tr ? prp : plp, pxm = tr ? prm : plm, pyp = tr ? plp : prp, pym = tr ? plm : prm;
-            float4 vv = mul4(c, -6.f);
-            vv = add4(vv, pxp);
-            vv = add4(vv, pxm);
-            vv = add4(vv, pyp);
-            vv = add4(vv, pym);
-            vv = add4(vv, pzp);
-            vv = add4(vv, pzm);
-            float4 L = mul4(vv, -1.f);
-            // calculate_potential_gradient_kernel (solver.cu:28-31)
-            float diff = fc[r] - bg[r];
-            float4 o   = add4(mul4(g, diff), mul4(L, a.w_reg));
+            const float4 o = potential_gradient_cell(pc[r], fc[r], bg[r], plp, plm, prp, prm, pn[r], pm[r], plp.w, plm.w, frp, frm, fn[r], fm[r], ulo,
+                                                     uhi, vlo, vhi, zlo, zhi, a.w_reg);
             pin3<1>(o);
             if (u < tg.u_hi && v < tg.v_hi) {
                 const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
@@ -534,6 +568,151 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
             fm[r] = fc[r];
             fc[r] = fn[r];
         }
+    }
+}
+
+template <int RPT, int WY, bool COMPACT>
+__global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
+    const GateRegs gate = gate_load(a.c.prev_slots, 1);
+    const unsigned t    = xcd_swizzle(blockIdx.x, (unsigned) a.boxes.first[a.boxes.n]);
+    int first;
+    const Box b = find_box(a.boxes, t, first);
+    pass_a_march<RPT, WY, COMPACT>(a.c, geom_in_box(b, t, first, a.c.d, RPT * WY), gate);
+}
+
+// ---- pass A of a multi-GPU TILE: the halo exchange is part of the launch ---------------------------------------------------
+// Boxes of a tile launch, in workgroup order:
+//   PUSH boxes (direct): the cells of one halo message (a 4-cell face or a 4 x 4 edge strip of the owned block) are evaluated
+//       a second time, lane per cell, and stored STRAIGHT INTO THE DESTINATION -- the halo cells of the neighbour's nabla_U
+//       array, peer-mapped over xGMI (direct transport), or this rank's packed send buffer (RCCL / callback transports): no
+//       pack kernel, no unpack kernel and, with the direct transport, no communication launch at all.  They are numbered
+//       first, so they leave while the owned block is still being computed.
+//   the owned block (marching), stored locally.
+// Synchronisation of the direct transport, in the kernel's tail (TileSync): every workgroup that pushed fences at system
+// scope and takes a ticket; the LAST of them writes this rank's arrival flag (= the iteration's sequence number) at every
+// rank of the sync set (release, system scope).  The last workgroup of the WHOLE launch then waits until the flags of all
+// those ranks have reached the sequence number (with a deadline), so that when the launch retires every halo cell of this
+// iteration has landed and pass B -- a separate launch, whose start invalidates the caches -- reads it.  nabla_U is
+// double-buffered by iteration parity, which orders a neighbour's stores of iteration k+1 behind this rank's reads of
+// iteration k without a second handshake (see tiled_capi.hip).
+constexpr int kMaxTileBoxes = 20;  // 18 messages + the owned block + one spare
+struct PushDst {
+    float* base;             // null: the box is stored locally
+    int ox, oy, oz, px, py;  // cell (x, y, z) -> base + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz)))
+};
+struct TileBox {
+    Box b;
+    PushDst push;
+};
+struct TileBoxList {
+    int n, n_push_wgs;  // workgroups [0, n_push_wgs) belong to push boxes
+    TileBox b[kMaxTileBoxes];
+    int first[kMaxTileBoxes + 1];
+};
+struct TilePassAArgs {
+    PassACore c;
+    TileBoxList boxes;
+    TileSync* sync;          // null: no signalling (single-box launches, RCCL / callback transports)
+    uint32_t seq;            // sequence number of this iteration
+    int wait;                // the last workgroup waits for the peers' flags
+    const uint32_t* row;     // this rank's max-norm slot row of the PREVIOUS iteration (null: none) ...
+    uint32_t row_index;      // ... which is row `row_index` of the global rows
+};
+
+// wave 0 of one workgroup: the maximum of this rank's slot row -> entry `my_rank` of that row at every rank of the sync set (and
+// here); the next signal covers these stores
+SOBFU_DEV void tile_row_push(const TileSync* sy, const uint32_t* row, uint32_t row_index) {
+    const int l = threadIdx.x;
+    uint32_t m = max(max(row[l], row[l + 64]), max(row[l + 128], row[l + 192]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
+    const size_t e = (size_t) row_index * 256u + sy->my_rank;
+    if (l == 0) sy->my_grows[e] = m;
+    for (int q = l; q < (int) sy->n_sync; q += 64) __hip_atomic_store(sy->peer_grows[q] + e, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one lane: raise this rank's arrival flag at every rank of the sync set (everything stored before is released system-wide)
+SOBFU_DEV void tile_signal(const TileSync* sy, uint32_t seq) {
+    for (uint32_t q = 0; q < sy->n_sync; ++q) __hip_atomic_store(sy->peer_flags[q] + sy->my_rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one lane: wait until every rank of the sync set has raised its flag to `seq` -- with a deadline: a missing peer is recorded
+// (err = 1 + its rank) and every later wait returns at once, so a wedged neighbour never hangs this GPU
+SOBFU_DEV void tile_wait(TileSync* sy, uint32_t seq) {
+    if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const uint64_t t0 = wall_clock64();
+    for (uint32_t q = 0; q < sy->n_sync; ++q) {
+        const uint32_t* f = sy->my_flags + sy->sync_rank[q];
+        while ((int32_t) (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > sy->timeout_ticks) {
+                __hip_atomic_store(&sy->err, 1u + (uint32_t) sy->sync_rank[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(64) tile_flush_kernel(TileSync* sy, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index) {
+    if (row != nullptr) tile_row_push(sy, row, row_index);
+    __threadfence_system();
+    if (threadIdx.x != 0) return;
+    tile_signal(sy, seq);
+    if (wait) tile_wait(sy, seq);
+}
+
+template <int RPT, int WY, bool COMPACT>
+__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePassAArgs a) {
+    const TileBoxList& L = a.boxes;
+    const unsigned nb = (unsigned) L.first[L.n];
+    // push workgroups keep their launch order (they go out first); the others are XCD-swizzled among themselves
+    unsigned t = blockIdx.x;
+    const bool push_wg = (int) t < L.n_push_wgs;
+    if (!push_wg) t = (unsigned) L.n_push_wgs + xcd_swizzle(t - (unsigned) L.n_push_wgs, nb - (unsigned) L.n_push_wgs);
+    Box b     = L.b[0].b;
+    PushDst pd = L.b[0].push;
+    int first = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxTileBoxes; ++k)
+        if (k < L.n && (int) t >= L.first[k]) {
+            b     = L.b[k].b;
+            pd    = L.b[k].push;
+            first = L.first[k];
+        }
+    const int tid = threadIdx.x + blockDim.x * threadIdx.y;
+    // the max-norm of the previous iteration, made global without a collective (workgroup 0 is a push workgroup: the signal
+    // below covers these stores)
+    if (a.sync != nullptr && a.row != nullptr && blockIdx.x == 0 && threadIdx.y == 0) tile_row_push(a.sync, a.row, a.row_index);
+    if (b.kind != 0) {
+        int x, y, z;
+        if (direct_cell(b, t, first, x, y, z)) {
+            const float4 o = pass_a_direct_cell<COMPACT>(a.c, x, y, z);
+            if (pd.base != nullptr) {
+                const size_t i = (size_t) (x + pd.ox) + (size_t) pd.px * ((size_t) (y + pd.oy) + (size_t) pd.py * (size_t) (z + pd.oz));
+                stv<true>(pd.base, i, o);  // messages are always 12-byte cells
+            } else {
+                stv<COMPACT>(a.c.nU, vidx(a.c.d, x, y, z), o);
+            }
+        }
+    } else {
+        GateRegs gate;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gate.v[k] = 0xffffffffu;  // pass A of a tile writes scratch only: never gated
+        pass_a_march<RPT, WY, COMPACT>(a.c, geom_in_box(b, t, first, a.c.d, RPT * WY), gate);
+    }
+    if (a.sync == nullptr) return;
+    TileSync* sy = a.sync;
+    if (push_wg) __threadfence_system();  // every lane: its stores to the peers are visible system-wide ...
+    __syncthreads();                      // ... before lane 0 takes the workgroup's ticket
+    if (tid != 0) return;
+    if (push_wg) {
+        const uint32_t k = __hip_atomic_fetch_add(&sy->ticket_push, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == (uint32_t) L.n_push_wgs - 1u) {  // the last push workgroup: everything this rank sends has left
+            __hip_atomic_store(&sy->ticket_push, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tile_signal(sy, a.seq);
+        }
+    }
+    const uint32_t k2 = __hip_atomic_fetch_add(&sy->ticket_all, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (k2 == nb - 1u) {  // the last workgroup of the launch
+        __hip_atomic_store(&sy->ticket_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.wait) tile_wait(sy, a.seq);
     }
 }
 
@@ -577,9 +756,72 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #endif
 // HL: planes the halo requests run ahead of the plane they are staged for (0: one plane ahead, straight from registers -- short
 // marches, where the extra prologue round trip costs more than the re-fetched halo lines).
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool TRANSPOSABLE, bool IDX32 = false, int HL = 0>
+// max ||u||^2 over the voxels a workgroup owns -> one atomicMax on one of 256 slots
+template <int WY>
+SOBFU_DEV void maxnorm_tail(float msq, uint32_t* slots, uint32_t* s_max) {
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    uint32_t m = __float_as_uint(msq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
+    if (lx == 0) s_max[wy] = m;
+    __syncthreads();
+    if (lx == 0 && wy == 0) {
+#pragma unroll
+        for (int w = 1; w < WY; ++w) m = max(m, s_max[w]);
+        atomicMax(slots + (blockIdx.x & 255u), m);
+    }
+}
+
+// DIRECT evaluation of one cell of pass B (thin boxes: the one-cell x / y shells of a tile): 19 nabla_U loads + psi + the
+// phi_n gather, op for op the marching path's arithmetic (sum = 0; taps ascending j; (Sx + Sy) + Sz)
+template <bool WRITE_UPDATES, bool COMPACT, bool IDX32>
+SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
+    const Dims d = a.d;
+    float slx = 0.f, sly = 0.f, slz = 0.f, srx = 0.f, sry = 0.f, srz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
+#pragma unroll
+    for (int j = -3; j <= 3; ++j) {
+        const float s = a.S.s[3 - j];
+        const float4 vl = ldv<COMPACT>(a.nU, vidx(d, min(max(x + j, 0), d.x - 1), y, z));
+        slx += vl.x * s;
+        sly += vl.y * s;
+        slz += vl.z * s;
+    }
+#pragma unroll
+    for (int j = -3; j <= 3; ++j) {
+        const float s = a.S.s[3 - j];
+        const float4 vr = ldv<COMPACT>(a.nU, vidx(d, x, min(max(y + j, 0), d.y - 1), z));
+        srx += vr.x * s;
+        sry += vr.y * s;
+        srz += vr.z * s;
+    }
+#pragma unroll
+    for (int j = -3; j <= 3; ++j) {
+        const float s = a.S.s[3 - j];
+        const float4 vz = ldv<COMPACT>(a.nU, vidx(d, x, y, min(max(z + j, 0), d.z - 1)));
+        szx += vz.x * s;
+        szy += vz.y * s;
+        szz += vz.z * s;
+    }
+    const float tx = (slx + srx) + szx, ty = (sly + sry) + szy, tz = (slz + srz) + szz;
+    const size_t i = vidx(d, x, y, z);
+    const float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
+    float4 p = ldv<COMPACT>(a.psi, i);
+    p.x -= uu.x;
+    p.y -= uu.y;
+    p.z -= uu.z;
+    stv<COMPACT>(a.psi_out, i, p);
+    if (WRITE_UPDATES) a.updates[i] = uu;
+    if (COMPACT) ((float*) a.pnp)[i] = IDX32 ? interp_tsdf_only32((const float*) a.phi_n, a.pd, p.x, p.y, p.z) : interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
+    else ((float2*) a.pnp)[i] = interp_tsdf((const float2*) a.phi_n, a.pd, p.x, p.y, p.z);
+    const bool owned = x >= a.own[0] && x < a.own[1] && y >= a.own[2] && y < a.own[3] && z >= a.own[4] && z < a.own[5];
+    return owned ? norm_sq4(uu) : 0.f;
+}
+
+// DIRECT_OK: the launch may hold direct boxes (multi-GPU tiles)
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0>
 __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
+    static_assert(HL == 0 || HL >= 2, "the halo-lead FIFO needs a lead of >= 2 planes (a lead of 1 is the register path, HL = 0)");
     constexpr int NXH = (2 * R * TY + TX - 1) / TX;  // row-tasks for the 2R lane-halo columns
     constexpr int NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
     __shared__ float4 tile[2][LH][LW + 2];
@@ -590,10 +832,21 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const TileGeom tg = tile_geom<TRANSPOSABLE, SOBFU_SWIZZLE_B>(a.boxes, d, TY);
+    const unsigned wg = SOBFU_SWIZZLE_B ? xcd_swizzle(blockIdx.x, (unsigned) a.boxes.first[a.boxes.n]) : blockIdx.x;
+    int first_wg;
+    const Box box = find_box(a.boxes, wg, first_wg);
+    if (DIRECT_OK && box.kind != 0) {  // a thin box: one lane per cell
+        if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
+        int x, y, z;
+        float msq = 0.f;
+        if (direct_cell(box, wg, first_wg, x, y, z)) msq = pass_b_direct_cell<WRITE_UPDATES, COMPACT, IDX32>(a, x, y, z);
+        maxnorm_tail<WY>(msq, a.slots, s_max);
+        return;
+    }
+    const TileGeom tg = geom_in_box(box, wg, first_wg, d, TY);
     const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
     const int u = u0 + lx, uc = min(u, tg.DU - 1);
-    const size_t plane = (size_t) d.x * d.y, su = (size_t) tg.su, sv = (size_t) tg.sv;
+    const size_t plane = (size_t) d.x * d.y, sv = (size_t) d.x;
 
     // in-plane BYTE offsets of the lane's cells (a plane of a vector field is < 4 GiB: checked at launch); every plane base is a
     // uniform 64-bit value, so an address costs one scalar pair + one lane register
@@ -604,12 +857,11 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int v = v0 + wy * RPT + r;
-        const uint32_t cell = (uint32_t) ((size_t) uc * su + sv * (size_t) min(v, tg.DV - 1));
+        const uint32_t cell = (uint32_t) ((size_t) uc + sv * (size_t) min(v, tg.DV - 1));
         off[r]      = cell * VB;
         offT[r]     = cell * TB;
         mine[r]     = u < tg.u_hi && v < tg.v_hi;
-        const int x = tg.tr ? v : u, y = tg.tr ? u : v;
-        owned[r]    = x >= a.own[0] && x < a.own[1] && y >= a.own[2] && y < a.own[3];
+        owned[r]    = u >= a.own[0] && u < a.own[1] && v >= a.own[2] && v < a.own[3];
     }
 
     // halo tasks: 0..R-1 rows above, R..2R-1 rows below, then lane-halo cells (2R per tile row)
@@ -633,7 +885,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         h_lr[k] = lr;
         h_lc[k] = lc;
         int gu = min(max(u0 - R + lc, 0), tg.DU - 1), gv = min(max(v0 - R + lr, 0), tg.DV - 1);
-        h_off[k] = (uint32_t) ((size_t) gu * su + (size_t) gv * sv) * VB;
+        h_off[k] = (uint32_t) ((size_t) gu + (size_t) gv * sv) * VB;
     }
 
     float4 hq[TPW];
@@ -735,8 +987,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            // the lane-axis sum (l*) and the row-axis sum (r*) are the x and y convolutions, or y and x in a transposed box:
-            // (Sx + Sy) is commutative, so the result is the same either way
+            // the lane-axis sum (l*) and the row-axis sum (r*) are the x and y convolutions
 #if SOBFU_PK
             // packed fp32 math: the {x, y} and {z, w} halves of a cell are adjacent register pairs (ds_read_b128), so each tap is
             // 2 v_pk_mul_f32 + 2 v_pk_add_f32 instead of 3 + 3 scalar ops (the w lane rides along; products are not contracted)
@@ -818,17 +1069,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             q[r][6] = nq[r];
         }
     }
-    // max ||u||^2 over the voxels this workgroup owns
-    uint32_t m = __float_as_uint(msq);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
-    if (lx == 0) s_max[wy] = m;
-    __syncthreads();
-    if (lx == 0 && wy == 0) {
-#pragma unroll
-        for (int w = 1; w < WY; ++w) m = max(m, s_max[w]);
-        atomicMax(a.slots + (blockIdx.x & 255u), m);
-    }
+    maxnorm_tail<WY>(msq, a.slots, s_max);  // max ||u||^2 over the voxels this workgroup owns
 }
 
 // --- compact-format conversions (once per solve, not per iteration) ----------------------------------------------
@@ -948,27 +1189,45 @@ int pick_zc(int X, int Y, int nz, int ty, int capacity, int refill, const char* 
     return best_zc;
 }
 
-// Fills the launch geometry of a box list: z-chunk per box (cost model above, the chip's capacity shared between the boxes)
-// and the workgroup prefix.  Returns the number of workgroups.
+// direct boxes: lanes of a wave that run along x, and the workgroups (of WY waves) the box needs
+static int direct_wx(int ex) {
+    int wx = 1;
+    while (wx < ex && wx < 64) wx *= 2;
+    return wx;
+}
+static int direct_groups(const LaunchBox& s, int wx) {
+    const int wyl = 64 / wx;
+    const long waves = (long) ((s.x1 - s.x0 + wx - 1) / wx) * ((s.y1 - s.y0 + wyl - 1) / wyl) * (s.z1 - s.z0);
+    return (int) ((waves + SOBFU_WY - 1) / SOBFU_WY);
+}
+static double box_cells(const LaunchBox& s) {
+    return (s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0) ? (double) (s.x1 - s.x0) * (s.y1 - s.y0) * (s.z1 - s.z0) : 0.0;
+}
+// geometry of one live box; returns its workgroups
+static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env) {
+    b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
+    b.kind = s.direct ? 1 : 0;
+    if (s.direct) {
+        b.zc = direct_wx(s.x1 - s.x0);
+        return direct_groups(s, b.zc);
+    }
+    const int eu = s.x1 - s.x0, ev = s.y1 - s.y0, nz = s.z1 - s.z0;
+    b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, share, refill, env);
+    return ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty) * ((nz + b.zc - 1) / b.zc);
+}
+// Fills the launch geometry of a box list: z-chunk per marching box (cost model above, the chip's capacity shared between the
+// marching boxes; direct boxes are one short round trip and take no share) and the workgroup prefix.  Returns the workgroups.
 static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env) {
     L.n = 0;
-    auto cells = [](const LaunchBox& s) { return (s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0) ? (double) (s.x1 - s.x0) * (s.y1 - s.y0) * (s.z1 - s.z0) : 0.0; };
     int live = 0;
-    for (int i = 0; i < n; ++i) live += cells(boxes[i]) > 0 ? 1 : 0;
+    for (int i = 0; i < n; ++i) live += (box_cells(boxes[i]) > 0 && !boxes[i].direct) ? 1 : 0;
     int total = 0;
     for (int i = 0; i < n && L.n < kMaxBoxes; ++i) {
-        const LaunchBox& s = boxes[i];
-        if (cells(s) == 0) continue;
-        Box& b = L.b[L.n];
-        b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
-        b.tr = s.tr ? 1 : 0;
-        const int eu = s.tr ? s.y1 - s.y0 : s.x1 - s.x0, ev = s.tr ? s.x1 - s.x0 : s.y1 - s.y0, nz = s.z1 - s.z0;
-        // the chip's workgroup slots are shared equally between the live boxes: a thin shell box is latency-critical (its march
-        // must not be longer than the big box's), so it gets as many short marches as the big one gets long ones
-        const int share = std::max(capacity / live, 1);
-        b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, share, refill, s.tr ? "SOBFU_ZC_T" : env);  // the tuning override leaves shell boxes alone
+        if (box_cells(boxes[i]) == 0) continue;
+        // the chip's workgroup slots are shared equally between the marching boxes (the two plane ranges of an overlapped slab
+        // schedule): a thin range is latency-critical, so it gets as many short marches as the big one gets long ones
         L.first[L.n] = total;
-        total += ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty) * ((nz + b.zc - 1) / b.zc);
+        total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env);
         ++L.n;
     }
     for (int k = L.n; k <= kMaxBoxes; ++k) L.first[k] = total;
@@ -978,19 +1237,56 @@ static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int c
 int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const LaunchBox* boxes,
                         int n, const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    PassAArgs a{pnp, pg, psi, nU, {X, Y, Z}, w_reg, {}, prev_slots, max_update_norm};
+    bool direct = false;
+    for (int i = 0; i < n; ++i) direct = direct || (boxes[i].direct && box_cells(boxes[i]) > 0);
+    if (direct) {  // thin boxes: the tile kernel (no messages, no signalling)
+        std::vector<TileLaunchBox> tb((size_t) n);
+        for (int i = 0; i < n; ++i) tb[(size_t) i] = TileLaunchBox{boxes[i], nullptr, 0, 0, 0, 0, 0};
+        return launch_tile_pass_a(pnp, pg, psi, nU, w_reg, X, Y, Z, tb.data(), n, (TileSync*) nullptr, 0, 0, nullptr, 0, zc, stream, compact);
+    }
+    PassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, prev_slots, max_update_norm}, {}};
     const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 4 * 8 / SOBFU_WY, 2, zc, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
     if (groups == 0) return 0;
-    bool tr = false;
-    for (int i = 0; i < a.boxes.n; ++i) tr = tr || a.boxes.b[i].tr;
     const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
-    if (tr) {  // only launches that hold a transposed box pay for the lane / row role selects
-        if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, true>), grid, block, 0, stream, a);
-    } else {
-        if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, false>), grid, block, 0, stream, a);
+    if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, block, 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+// Pass A of a multi-GPU tile (see tile_potential_gradient_kernel): the boxes with a destination (push boxes: direct, their
+// result goes to `dst` only) are numbered first, then the others.  sync / seq / wait / row: the direct transport's signalling.
+int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
+                       int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact) {
+    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    TilePassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, nullptr, 0.f}, {}, sync, seq, wait, row, row_index};
+    TileBoxList& L = a.boxes;
+    L.n = 0;
+    int live = 0, total = 0;
+    for (int i = 0; i < n; ++i) live += (box_cells(boxes[i].box) > 0 && !boxes[i].box.direct) ? 1 : 0;
+    for (int pass = 0; pass < 2; ++pass) {  // push boxes first
+        for (int i = 0; i < n; ++i) {
+            const TileLaunchBox& s = boxes[i];
+            if ((s.dst != nullptr) != (pass == 0) || box_cells(s.box) == 0) continue;
+            if (L.n >= kMaxTileBoxes || (s.dst != nullptr && !s.box.direct)) return SOBFU_E_BADARG;
+            TileBox& t = L.b[L.n];
+            L.first[L.n] = total;
+            total += finish_box(t.b, s.box, TY, std::max(256 * 4 * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc, "SOBFU_ZC_A");
+            t.push = PushDst{s.dst, s.ox, s.oy, s.oz, s.px, s.py};
+            ++L.n;
+        }
+        if (pass == 0) L.n_push_wgs = total;
     }
+    for (int k = L.n; k <= kMaxTileBoxes; ++k) L.first[k] = total;
+    for (int k = L.n; k < kMaxTileBoxes; ++k) L.b[k] = TileBox{};
+    if (total == 0) return 0;
+    const dim3 grid((unsigned) total), block(TX, SOBFU_WY);
+    if (compact) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false>), grid, block, 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+int launch_tile_flush(TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_flush_kernel, dim3(1), dim3(64), 0, stream, sync, seq, wait, row, row_index);
     return (int) hipGetLastError();
 }
 
@@ -1004,13 +1300,13 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
     const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 3 * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 48 KB LDS: 3 workgroups of 8 waves per CU
     if (groups == 0) return 0;
-    bool tr = false;
-    for (int i = 0; i < a.boxes.n; ++i) tr = tr || a.boxes.b[i].tr;
+    bool direct = false;
+    for (int i = 0; i < a.boxes.n; ++i) direct = direct || a.boxes.b[i].kind != 0;
     const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
-#define SOBFU_LAUNCH_B(UPD, CMP, TRN) \
-    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, TRN>), grid, block, 0, stream, a)
+#define SOBFU_LAUNCH_B(UPD, CMP, DIR) \
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, DIR>), grid, block, 0, stream, a)
     const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
-    if (tr) {
+    if (direct) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);
         else if (compact && idx32) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, true, true, 0>), grid, block, 0, stream, a);
@@ -1178,23 +1474,23 @@ static bool box_ok(const int b[6], int Lx, int Ly, int Lz) {
 }
 
 int sobfu_hip_tile3_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi, float* d_nabla_U, float w_reg,
-                                       int Lx, int Ly, int Lz, const int box[6], int transposed, const uint32_t* d_prev_slots,
+                                       int Lx, int Ly, int Lz, const int box[6], int thin, const uint32_t* d_prev_slots,
                                        float max_update_norm, int compact, void* stream) {
     SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_psi && d_nabla_U && Lx > 1 && Ly > 1 && Lz > 1 && box && box_ok(box, Lx, Ly, Lz));
     if ((size_t) Lx * Ly * Lz > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
-    const sobfu_hip::LaunchBox b{box[0], box[1], box[2], box[3], box[4], box[5], transposed != 0};
+    const sobfu_hip::LaunchBox b{box[0], box[1], box[2], box[3], box[4], box[5], thin != 0};
     return sobfu_hip::launch_pass_a_boxes(d_phi_n_psi, d_phi_global, d_psi, d_nabla_U, w_reg, Lx, Ly, Lz, &b, 1, d_prev_slots, max_update_norm, 0,
                                           (hipStream_t) stream, compact != 0);
 }
 
 int sobfu_hip_tile3_smooth_update_apply(const float* d_nabla_U, float* d_psi, const float* d_phi_n, float* d_phi_n_psi, float* d_updates,
                                         uint32_t* d_max_sq_slots, const float taps[7], float alpha, int Lx, int Ly, int Lz, int Xg, int Yg,
-                                        int Zg, const int own[6], const int box[6], int transposed, const uint32_t* d_prev_slots,
+                                        int Zg, const int own[6], const int box[6], int thin, const uint32_t* d_prev_slots,
                                         float max_update_norm, int compact, void* stream) {
     SOBFU_CHECK_ARGS(d_nabla_U && d_psi && d_phi_n && d_phi_n_psi && d_max_sq_slots && taps && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 &&
                      Zg > 0 && own && box && box_ok(own, Lx, Ly, Lz) && box_ok(box, Lx, Ly, Lz));
     if ((size_t) Lx * Ly * Lz > (size_t) 0x7fffffff || (size_t) Xg * Yg * Zg > (size_t) 0x7fffffff) return SOBFU_E_UNSUPPORTED;
-    const sobfu_hip::LaunchBox b{box[0], box[1], box[2], box[3], box[4], box[5], transposed != 0};
+    const sobfu_hip::LaunchBox b{box[0], box[1], box[2], box[3], box[4], box[5], thin != 0};
     return sobfu_hip::launch_pass_b_boxes(d_nabla_U, d_psi, d_phi_n, d_phi_n_psi, d_updates, d_max_sq_slots, taps, alpha, Lx, Ly, Lz, Xg, Yg, Zg,
                                           own, &b, 1, d_prev_slots, max_update_norm, 0, (hipStream_t) stream, compact != 0);
 }

@@ -1,25 +1,36 @@
 // Native multi-GPU solver loop: one rank (process, GPU) per volume TILE -- a Px x Py x Pz grid of tiles (2 x 2 x 2 on 8 GPUs,
-// BASELINE config 4; 1 x 1 x N = z-slabs), halo exchange by RCCL send/recv over xGMI issued from C++.
+// BASELINE config 4; 1 x 1 x N = z-slabs).
 //
 // Every field of a rank is a local array = owned cells + 4 halo cells on each side that faces a neighbour.  One iteration needs
 // ONE exchange (Option B): pass A produces nabla_U on the owned cells, the 4-cell faces (and the 4 x 4 edge strips:
 // the one-cell shells below read nabla_U diagonally across a tile edge, never across a corner) travel to the 3 face + 3 edge
-// neighbours of a 2 x 2 x 2 tile in one grouped send/recv, and pass B then updates psi / phi_n o psi on owned +- 1 along each axis
-// -- the radius-3 convolution is exact there, so the values the next pass A reads are never exchanged.  phi_n is replicated.
-// Messages of a 3-D tile are packed into / scattered from contiguous buffers by one small kernel each; z-slabs exchange whole
-// planes in place.  The x shell (one column) runs as a TRANSPOSED box of the pass-B launch (lanes along y).
+// neighbours of a 2 x 2 x 2 tile, and pass B then updates psi / phi_n o psi on owned +- 1 along each axis -- the radius-3
+// convolution is exact there, so the values the next pass A reads are never exchanged.  phi_n is replicated.
 //
-// Schedules: serial (pass A, exchange, pass B in line) for any tile grid; for z-slabs also the overlapped ones of
-// sobfu_amd/tiled.py (which documents the invariants), without a Python round trip per iteration:
+// The exchange is PART OF PASS A's LAUNCH (solver_kernels.hip, tile_potential_gradient_kernel): the cells of every message
+// are evaluated by "push boxes" -- lane per cell, numbered first -- that store straight into the destination.  Transports:
+//   DIRECT    the destination is the neighbour's own nabla_U array, peer-mapped over xGMI (hipIpc; sobfu_hip_tiled_connect).
+//             No pack, no unpack, no communication launch: the last push workgroup raises this rank's arrival flag at its
+//             neighbours, the last workgroup of the launch waits for theirs (with a deadline), so the transfers overlap the
+//             owned block's compute inside ONE launch and an iteration is two launches, as on a single GPU.  nabla_U is
+//             double-buffered by iteration parity: a neighbour's pass A of iteration k+1 stores into the half this rank's
+//             pass B of iteration k does not read; its pass A of k+2 cannot start before this rank's flag of k+1, which this
+//             rank raises after its pass B of k has retired.  The max-norm rows become global the same way (every rank stores
+//             its row maximum into entry `rank` of that row at every other rank): no collective anywhere in the loop.
+//   RCCL      the destination is the packed send buffer; one grouped ncclSend / ncclRecv per exchange and one scatter kernel
+//             (z-slabs: whole planes in place, and the overlapped schedules of round 1).
+//   CALLBACK  the same buffers handed to a user function (in-process loopback and gloo bring-up transports of the tests).
+// The one-cell x / y shells of pass B are DIRECT boxes of its launch (lane per cell), the z shells extra planes of the march.
+//
+// Schedules of the RCCL z-slab path: serial (pass A, exchange, pass B in line), or overlapped as in sobfu_amd/tiled.py:
 //     A_bnd (planes next to an interior face)  ->  event  ->  [comm stream] group{send, recv} of 4 nabla_U planes / face
 //     A_int, B_int (planes whose +-3 taps are owned)            ... run while the exchange is in flight
 //     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)
-// (both boundary regions of a pass are ONE two-range launch; thin slabs keep pass A unsplit).  When a non-negative threshold
-// can fire the device-side gate needs the GLOBAL max-norm: see sobfu_hip_tiled_iterate for the ping-pong / late-gate scheme
-// that keeps that all-reduce off the critical path.
+// When a non-negative threshold can fire the device-side gate needs the GLOBAL max-norm: see tiled_step for the ping-pong /
+// late-gate scheme that keeps that reduction off the critical path.
 //
 // RCCL is not a link-time dependency: the host process (PyTorch) has already loaded librccl.so; sobfu_hip_tiled_load_rccl
-// dlopen()s that same file and resolves the nine entry points used here, so libsobfu_hip.so still loads on a machine
+// dlopen()s that same file and resolves the entry points used here, so libsobfu_hip.so still loads on a machine
 // without RCCL and a process never holds two copies of the library.
 #include <dlfcn.h>
 
@@ -29,6 +40,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "sobfu_device.hpp"
@@ -54,6 +66,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -65,6 +78,7 @@ struct Rccl {
 
 constexpr int kHalo = 4, kSlots = 256;
 constexpr int kSplitAMaxPlanes = 64;  // owned planes up to which pass A is split into boundary + interior launches
+constexpr int kMaxSync = sobfu_hip::kMaxSync;
 
 #define RCCL_TRY(expr)                                                                          \
     do {                                                                                        \
@@ -82,6 +96,67 @@ float host_sqrt_rd(float s) {
     return r;
 }
 
+// The layout of ANY rank's tile (a rank also needs its neighbours': where their halo cells sit in their arrays).
+struct AxisLay {
+    int g0, g1, lo, hi, L, o0, o1, base;
+};
+struct MsgGeom {
+    int peer, dir[3];
+    int sb[6], rb[6];  // cells sent / halo cells received (local cells of THIS rank)
+    size_t cells;
+};
+struct TileLay {
+    int P[3], c[3];
+    AxisLay a[3];
+    std::vector<MsgGeom> msgs;
+    bool ok = true;
+};
+TileLay make_layout(const int dims[3], const int P[3], int rank) {
+    TileLay t;
+    const int c[3] = {rank % P[0], (rank / P[0]) % P[1], rank / (P[0] * P[1])};  // x fastest
+    for (int k = 0; k < 3; ++k) {
+        t.P[k] = P[k];
+        t.c[k] = c[k];
+        const int base = dims[k] / P[k], rem = dims[k] % P[k];  // the cells of an axis are split as evenly as possible
+        AxisLay& a = t.a[k];
+        a.g0   = c[k] * base + std::min(c[k], rem);
+        a.g1   = a.g0 + base + (c[k] < rem ? 1 : 0);
+        a.lo   = c[k] > 0 ? kHalo : 0;
+        a.hi   = c[k] < P[k] - 1 ? kHalo : 0;
+        a.L    = (a.g1 - a.g0) + a.lo + a.hi;
+        a.o0   = a.lo;
+        a.o1   = a.lo + (a.g1 - a.g0);
+        a.base = a.g0 - a.lo;
+        if (P[k] > 1 && base < kHalo) t.ok = false;  // a tile must own at least a halo's worth of cells per split axis
+    }
+    // halo messages: every face neighbour (one non-zero offset) and edge neighbour (two); corners are never read.  Along an
+    // axis with offset +1 the 4 owned cells next to that face are sent and the 4 halo cells beyond it received; along an
+    // axis with offset 0 the owned range (the same on both sides, as the neighbour shares this coordinate).
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int dl[3] = {dx, dy, dz};
+                const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
+                if (nnz < 1 || nnz > 2) continue;
+                bool inside = true;
+                for (int k = 0; k < 3; ++k) inside = inside && c[k] + dl[k] >= 0 && c[k] + dl[k] < P[k];
+                if (!inside) continue;
+                MsgGeom m;
+                m.cells = 1;
+                for (int k = 0; k < 3; ++k) {
+                    const AxisLay& a = t.a[k];
+                    m.dir[k] = dl[k];
+                    if (dl[k] > 0) { m.sb[2 * k] = a.o1 - kHalo; m.sb[2 * k + 1] = a.o1; m.rb[2 * k] = a.o1; m.rb[2 * k + 1] = a.o1 + kHalo; }
+                    else if (dl[k] < 0) { m.sb[2 * k] = a.o0; m.sb[2 * k + 1] = a.o0 + kHalo; m.rb[2 * k] = a.o0 - kHalo; m.rb[2 * k + 1] = a.o0; }
+                    else { m.sb[2 * k] = m.rb[2 * k] = a.o0; m.sb[2 * k + 1] = m.rb[2 * k + 1] = a.o1; }
+                    m.cells *= (size_t) (m.sb[2 * k + 1] - m.sb[2 * k]);
+                }
+                m.peer = (c[0] + dx) + P[0] * ((c[1] + dy) + P[1] * (c[2] + dz));
+                t.msgs.push_back(m);
+            }
+    return t;
+}
+
 }  // namespace
 
 struct sobfu_hip_tiled {
@@ -89,7 +164,7 @@ struct sobfu_hip_tiled {
     // tile grid P, this rank's tile coordinates c; per axis: owned global range [g0, g1), halo cells lo / hi, local extent L,
     // owned local range [o0, o1), global coordinate `base` of local cell 0
     int P[3], c[3], g0[3], g1[3], lo[3], hi[3], L[3], o0[3], o1[3], base[3];
-    bool slab;  // Px == Py == 1: halos are whole planes and travel in place (no pack / unpack)
+    bool slab;  // Px == Py == 1: on the RCCL transport halos are whole planes and travel in place (no pack / unpack)
     int z0, z1, Lz, own_lo, own_hi, zbase;  // the z entries again, under the names the slab schedules use
     sobfu_hip_solver_params p;
     float taps[7];
@@ -98,35 +173,97 @@ struct sobfu_hip_tiled {
     sobfu_hip_tiled_allreduce_fn rfn = nullptr;
     void* tctx = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_row = nullptr, ev_red[2] = {nullptr, nullptr};
+    hipEvent_t ev_bnd = nullptr, ev_xchg = nullptr, ev_row = nullptr, ev_red[2] = {nullptr, nullptr}, ev_first = nullptr;
     // optional second communicator + stream for the max-norm all-reduce (sobfu_hip_tiled_add_reduce_comm): it then never queues
     // behind (or in front of) a halo exchange on the main communicator
     ncclComm_t comm2 = nullptr;
     hipStream_t red_stream = nullptr;
-    // compact tile state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n
-    float *nU = nullptr, *c_psi = nullptr, *c_psi2 = nullptr, *c_f = nullptr, *c_f2 = nullptr, *c_g = nullptr, *c_n = nullptr;
+    // compact tile state (see sobfu_hip_solver_set_compact): 12-byte psi / nabla_U, tsdf-only F / G / phi_n.  nabla_U is
+    // double-buffered by iteration parity on the tile path (see the top of the file); the slab schedules use nUb[0].
+    float *nUb[2] = {nullptr, nullptr}, *c_psi = nullptr, *c_psi2 = nullptr, *c_f = nullptr, *c_f2 = nullptr, *c_g = nullptr, *c_n = nullptr;
     uint32_t* slots = nullptr;
     int slots_iters = 0;
     size_t NL, NF;
-    // halo messages of a 3-D tile: one per face / edge neighbour, packed one after the other (same offsets on both sides)
+    // halo messages: one per face / edge neighbour, packed one after the other (same offsets on both sides)
     std::vector<sobfu_hip_tiled_msg> msgs;
+    std::vector<MsgGeom> geom;
     std::vector<int> sboxes, rboxes;  // 6 ints per message: the cells sent / the halo cells received
     float *sendbuf = nullptr, *recvbuf = nullptr;
+    // direct transport (sobfu_hip_tiled_connect): push destinations in the peers, signalling state
+    bool direct = false, dead = false, first_checked = false, dry_packed = false;
+    int wait_enabled = 1;
+    sobfu_hip::TileSync* sync_d = nullptr;
+    uint32_t *flags = nullptr, *grows = nullptr;  // arrival flags [kMaxSync] (uncached), global max-norm rows [(slots_iters + 1) x 256]
+    uint32_t seq_total = 0;                        // sequence numbers used so far (every rank counts the same)
+    uint64_t timeout_ticks = 0;                    // deadline of the in-kernel waits (100 MHz ticks; SOBFU_TILED_DEADLINE_S at create)
+    std::vector<sobfu_hip::TileLaunchBox> a_boxes[2];  // pass A's boxes per nabla_U half: one push box per message + the owned block
     int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
     // optional timing of the serial schedule's three pieces with HIP events on the loop's stream (sobfu_hip_tiled_set_profiling)
     int prof_stride = 0, prof_pending = 0, prof_n = 0;
     std::vector<hipEvent_t> prof_ev;
-    double prof_ms[3] = {0, 0, 0};  // pass A, exchange (pack + transfer + unpack), pass B
+    double prof_ms[3] = {0, 0, 0};  // pass A, exchange (transfer + unpack; the direct transport has none), pass B
     struct Session {  // an open solve (tiled_begin .. tiled_end)
         bool active = false;
         const float* pn = nullptr;
         float *pnp = nullptr, *psi = nullptr;
         int cap = 0, launched = 0;
+        bool flushed = false;  // the direct transport's end-of-solve handshake has been issued (test harnesses issue it as a phase)
         bool red_issued[2] = {false, false};
         int red_upto = 0;  // rows 1 .. red_upto have been (or are being) all-reduced
+        uint32_t seq_base = 0;
     } q;
 };
+
+namespace {
+
+double deadline_seconds() {
+    const char* e = std::getenv("SOBFU_TILED_DEADLINE_S");
+    const double v = e ? std::atof(e) : 0.0;
+    return v > 0.0 ? v : 30.0;
+}
+
+// (re)builds pass A's box lists: one push box per message, then the owned block.  Destinations: the peers' halo cells when
+// connected (dst[half][i] != null), else the packed send buffer.
+void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, const TileLay* peers) {
+    for (int h = 0; h < 2; ++h) {
+        std::vector<sobfu_hip::TileLaunchBox>& v = t->a_boxes[h];
+        v.clear();
+        for (size_t i = 0; i < t->geom.size(); ++i) {
+            const MsgGeom& m = t->geom[i];
+            sobfu_hip::TileLaunchBox b{};
+            b.box = sobfu_hip::LaunchBox{m.sb[0], m.sb[1], m.sb[2], m.sb[3], m.sb[4], m.sb[5], true};
+            float* const* dst = h ? dst1 : dst0;
+            if (dst && dst[i]) {  // the matching message of the peer: direction -dir; its receive box is where these cells live there
+                const TileLay& pl = peers[i];
+                const MsgGeom* pm = nullptr;
+                for (const MsgGeom& g : pl.msgs)
+                    if (g.dir[0] == -m.dir[0] && g.dir[1] == -m.dir[1] && g.dir[2] == -m.dir[2]) pm = &g;
+                b.dst = dst[i];
+                b.ox = pm->rb[0] - m.sb[0]; b.oy = pm->rb[2] - m.sb[2]; b.oz = pm->rb[4] - m.sb[4];
+                b.px = pl.a[0].L; b.py = pl.a[1].L;
+            } else {
+                b.dst = t->sendbuf + t->msgs[i].send_off;
+                b.ox = -m.sb[0]; b.oy = -m.sb[2]; b.oz = -m.sb[4];
+                b.px = m.sb[1] - m.sb[0]; b.py = m.sb[3] - m.sb[2];
+            }
+            v.push_back(b);
+        }
+        sobfu_hip::TileLaunchBox own{};
+        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], false};
+        v.push_back(own);
+    }
+}
+
+void abort_comms(sobfu_hip_tiled* t) {
+    if (g_rccl.ok() && g_rccl.CommAbort) {
+        if (t->comm2) { (void) g_rccl.CommAbort(t->comm2); t->comm2 = nullptr; }
+        if (t->comm) { (void) g_rccl.CommAbort(t->comm); t->comm = nullptr; }
+    }
+    t->dead = true;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -147,6 +284,7 @@ int sobfu_hip_tiled_load_rccl(const char* librccl_path) {
     SYM(GetUniqueId, "ncclGetUniqueId")
     SYM(CommInitRank, "ncclCommInitRank")
     SYM(CommDestroy, "ncclCommDestroy")
+    SYM(CommAbort, "ncclCommAbort")
     SYM(GroupStart, "ncclGroupStart")
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(Send, "ncclSend")
@@ -170,15 +308,18 @@ int sobfu_hip_tiled_unique_id(char out[128]) {
 
 int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (!t) return 0;
-    for (float* q : {t->nU, t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
+    for (float* q : {t->nUb[0], t->nUb[1], t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
         if (q) (void) hipFree(q);
     if (t->slots) (void) hipFree(t->slots);
+    if (t->grows) (void) hipFree(t->grows);
+    if (t->flags) (void) hipFree(t->flags);
+    if (t->sync_d) (void) hipFree(t->sync_d);
     for (hipEvent_t e : t->prof_ev) (void) hipEventDestroy(e);
     if (t->sendbuf) (void) hipFree(t->sendbuf);
     if (t->recvbuf) (void) hipFree(t->recvbuf);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
-    for (hipEvent_t e : {t->ev_red[0], t->ev_red[1], t->ev_row})
+    for (hipEvent_t e : {t->ev_red[0], t->ev_red[1], t->ev_row, t->ev_first})
         if (e) (void) hipEventDestroy(e);
     if (t->red_stream) (void) hipStreamDestroy(t->red_stream);
     if (t->comm2 && g_rccl.ok()) (void) g_rccl.CommDestroy(t->comm2);
@@ -193,29 +334,22 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     SOBFU_CHECK_ARGS(out && params && unique_id && X > 1 && Y > 1 && Z > 1 && Px >= 1 && Py >= 1 && Pz >= 1 && rank >= 0 &&
                      rank < Px * Py * Pz);
     bool dry = true;  // an all-zero id asks for a communicator-less handle: tile layout, kernels and stream choreography of
-    for (int i = 0; i < 128; ++i) dry = dry && unique_id[i] == 0;  // (grid, rank); transport: sobfu_hip_tiled_set_transport
+    for (int i = 0; i < 128; ++i) dry = dry && unique_id[i] == 0;  // (grid, rank); transport: sobfu_hip_tiled_set_transport / _connect
     if (!dry && !g_rccl.ok()) return SOBFU_E_RCCL;
     if (params->s < 7) return SOBFU_E_UNSUPPORTED;
     auto* t = new sobfu_hip_tiled();
     t->X = X; t->Y = Y; t->Z = Z; t->world = Px * Py * Pz; t->rank = rank;
     const int dims[3] = {X, Y, Z}, P[3] = {Px, Py, Pz};
-    const int c[3] = {rank % Px, (rank / Px) % Py, rank / (Px * Py)};  // x fastest
-    int rc = 0;
+    const TileLay lay = make_layout(dims, P, rank);
+    int rc = lay.ok ? 0 : SOBFU_E_UNSUPPORTED;
     for (int a = 0; a < 3; ++a) {
-        t->P[a] = P[a];
-        t->c[a] = c[a];
-        const int base = dims[a] / P[a], rem = dims[a] % P[a];  // the cells of an axis are split as evenly as possible
-        t->g0[a]   = c[a] * base + std::min(c[a], rem);
-        t->g1[a]   = t->g0[a] + base + (c[a] < rem ? 1 : 0);
-        t->lo[a]   = c[a] > 0 ? kHalo : 0;
-        t->hi[a]   = c[a] < P[a] - 1 ? kHalo : 0;
-        t->L[a]    = (t->g1[a] - t->g0[a]) + t->lo[a] + t->hi[a];
-        t->o0[a]   = t->lo[a];
-        t->o1[a]   = t->lo[a] + (t->g1[a] - t->g0[a]);
-        t->base[a] = t->g0[a] - t->lo[a];
-        if (P[a] > 1 && base < kHalo) rc = SOBFU_E_UNSUPPORTED;  // a tile must own at least a halo's worth of cells per split axis
+        t->P[a] = P[a]; t->c[a] = lay.c[a];
+        t->g0[a] = lay.a[a].g0; t->g1[a] = lay.a[a].g1; t->lo[a] = lay.a[a].lo; t->hi[a] = lay.a[a].hi; t->L[a] = lay.a[a].L;
+        t->o0[a] = lay.a[a].o0; t->o1[a] = lay.a[a].o1; t->base[a] = lay.a[a].base;
     }
     t->slab = Px == 1 && Py == 1;
+    const char* dp = std::getenv("SOBFU_TILED_DRY_PACKED");
+    t->dry_packed = dp && dp[0] == '1';
     t->z0 = t->g0[2]; t->z1 = t->g1[2]; t->Lz = t->L[2]; t->own_lo = t->o0[2]; t->own_hi = t->o1[2]; t->zbase = t->base[2];
     t->NL = (size_t) t->L[0] * t->L[1] * t->L[2];
     t->NF = (size_t) X * Y * Z;
@@ -223,57 +357,65 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     float h[16];
     if (rc == 0) rc = sobfu_hip_sobolev_filter(params->s, params->lambda, h);
     for (int i = 0; i < 7; ++i) t->taps[i] = h[i];
-    if (rc == 0 && !t->slab) {
-        // halo messages: every face neighbour (one non-zero offset) and edge neighbour (two); corners are never read.  Along an
-        // axis with offset +1 the 4 owned cells next to that face are sent and the 4 halo cells beyond it received; along an
-        // axis with offset 0 the owned range (the same on both sides, as the neighbour shares this coordinate).
+    if (rc == 0) {
         size_t off = 0;
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int dl[3] = {dx, dy, dz};
-                    const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
-                    if (nnz < 1 || nnz > 2) continue;
-                    bool inside = true;
-                    for (int a = 0; a < 3; ++a) inside = inside && c[a] + dl[a] >= 0 && c[a] + dl[a] < P[a];
-                    if (!inside) continue;
-                    int sb[6], rb[6];
-                    size_t cells = 1;
-                    for (int a = 0; a < 3; ++a) {
-                        if (dl[a] > 0) { sb[2 * a] = t->o1[a] - kHalo; sb[2 * a + 1] = t->o1[a]; rb[2 * a] = t->o1[a]; rb[2 * a + 1] = t->o1[a] + kHalo; }
-                        else if (dl[a] < 0) { sb[2 * a] = t->o0[a]; sb[2 * a + 1] = t->o0[a] + kHalo; rb[2 * a] = t->o0[a] - kHalo; rb[2 * a + 1] = t->o0[a]; }
-                        else { sb[2 * a] = rb[2 * a] = t->o0[a]; sb[2 * a + 1] = rb[2 * a + 1] = t->o1[a]; }
-                        cells *= (size_t) (sb[2 * a + 1] - sb[2 * a]);
-                    }
-                    sobfu_hip_tiled_msg m;
-                    m.peer     = (c[0] + dx) + Px * ((c[1] + dy) + Py * (c[2] + dz));
-                    m.send_off = m.recv_off = off;
-                    m.count    = cells * 3;
-                    off += m.count;
-                    t->msgs.push_back(m);
-                    t->sboxes.insert(t->sboxes.end(), sb, sb + 6);
-                    t->rboxes.insert(t->rboxes.end(), rb, rb + 6);
-                }
+        t->geom = lay.msgs;
+        for (const MsgGeom& g : lay.msgs) {
+            sobfu_hip_tiled_msg m;
+            m.peer     = g.peer;
+            m.send_off = m.recv_off = off;
+            m.count    = g.cells * 3;
+            off += m.count;
+            t->msgs.push_back(m);
+            t->sboxes.insert(t->sboxes.end(), g.sb, g.sb + 6);
+            t->rboxes.insert(t->rboxes.end(), g.rb, g.rb + 6);
+        }
         if (off > 0) {
             rc = (int) hipMalloc((void**) &t->sendbuf, off * sizeof(float));
             if (rc == 0) rc = (int) hipMalloc((void**) &t->recvbuf, off * sizeof(float));
         }
     }
-    if (rc == 0) rc = (int) hipMalloc((void**) &t->nU, t->NL * 12);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->nUb[0], t->NL * 12);
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->nUb[1], t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi2, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
-    if (rc == 0) rc = (int) hipMemset(t->nU, 0, t->NL * 12);  // halo cells no message fills (tile corners) stay finite (blocking: the loop's streams do not order against the null stream)
+    // halo cells no message fills (tile corners) stay finite (blocking: the loop's streams do not order against the null stream)
+    if (rc == 0) rc = (int) hipMemset(t->nUb[0], 0, t->NL * 12);
+    if (rc == 0) rc = (int) hipMemset(t->nUb[1], 0, t->NL * 12);
     if (rc == 0) {  // max-norm slot rows for 4096 iterations up front: a solve never reallocates inside a timed region
         rc = (int) hipMalloc((void**) &t->slots, (size_t) (4096 + 1) * kSlots * 4);
+        if (rc == 0) rc = (int) hipMalloc((void**) &t->grows, (size_t) (4096 + 2) * kSlots * 4);
+        if (rc == 0) rc = (int) hipMemset(t->grows, 0, (size_t) (4096 + 2) * kSlots * 4);
         if (rc == 0) t->slots_iters = 4096;
     }
+    if (rc == 0) {
+        // arrival flags: written by the peers over xGMI, polled here -- uncached memory, so that neither side's L2 sits between
+        // a store and the poll (plain device memory if the runtime refuses)
+        if (hipExtMallocWithFlags((void**) &t->flags, kMaxSync * sizeof(uint32_t), hipDeviceMallocUncached) != hipSuccess) {
+            (void) hipGetLastError();
+            t->flags = nullptr;
+            rc = (int) hipMalloc((void**) &t->flags, kMaxSync * sizeof(uint32_t));
+        }
+        if (rc == 0) rc = (int) hipMemset(t->flags, 0, kMaxSync * sizeof(uint32_t));
+    }
+    if (rc == 0) rc = (int) hipMalloc((void**) &t->sync_d, sizeof(sobfu_hip::TileSync));
+    if (rc == 0) {
+        sobfu_hip::TileSync sy{};
+        sy.my_rank = (uint32_t) rank; sy.world = (uint32_t) t->world;
+        t->timeout_ticks = (uint64_t) (deadline_seconds() * 1e8);
+        sy.timeout_ticks = t->timeout_ticks;
+        sy.my_flags = t->flags; sy.my_grows = t->grows;
+        rc = (int) hipMemcpy(t->sync_d, &sy, sizeof sy, hipMemcpyHostToDevice);
+    }
+    if (rc == 0) build_a_boxes(t, nullptr, nullptr, nullptr);
     if (rc == 0) rc = (int) hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_bnd, hipEventDisableTiming);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_xchg, hipEventDisableTiming);
+    if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_first, hipEventDisableTiming);
     // the max-norm rows are written by pass B's atomics on this device, but a real RCCL all-reduce may let PEERS write the
     // reduced row straight into this buffer (direct / registered-buffer paths): every event keeps the system-scope fence
     // until the fence-less variant has been validated on >= 2 real GPUs.  SOBFU_TILED_LOCAL_EVENTS=1 opts into events
@@ -303,6 +445,88 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
 int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world, int rank, const char unique_id[128],
                            const sobfu_hip_solver_params* params) {
     return sobfu_hip_tiled_create3(out, X, Y, Z, 1, 1, world, rank, unique_id, params);  // z-slabs
+}
+
+// ---- direct transport -------------------------------------------------------------------------------------------------------
+int sobfu_hip_ipc_export(const void* d_ptr, char handle[64]) {
+    SOBFU_CHECK_ARGS(d_ptr && handle);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    SOBFU_HIP_TRY(hipIpcGetMemHandle(&h, const_cast<void*>(d_ptr)));
+    std::memcpy(handle, &h, 64);
+    return 0;
+}
+int sobfu_hip_ipc_open(const char handle[64], void** d_ptr) {
+    SOBFU_CHECK_ARGS(handle && d_ptr);
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, 64);
+    SOBFU_HIP_TRY(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+int sobfu_hip_ipc_close(void* d_ptr) {
+    if (!d_ptr) return 0;
+    SOBFU_HIP_TRY(hipIpcCloseMemHandle(d_ptr));
+    return 0;
+}
+
+int sobfu_hip_tiled_exports_get(const sobfu_hip_tiled* t, sobfu_hip_tiled_exports* out) {
+    SOBFU_CHECK_ARGS(t && out);
+    out->nabla_u[0] = t->nUb[0]; out->nabla_u[1] = t->nUb[1]; out->flags = t->flags; out->rows = t->grows;
+    return 0;
+}
+
+int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ranks, const sobfu_hip_tiled_exports* peers) {
+    SOBFU_CHECK_ARGS(t && n_peers >= 0 && (n_peers == 0 || (peer_ranks && peers)) && !t->q.active && !t->comm);
+    if (t->world > kMaxSync) return SOBFU_E_UNSUPPORTED;
+    const int dims[3] = {t->X, t->Y, t->Z};
+    auto find = [&](int r) -> const sobfu_hip_tiled_exports* {
+        for (int i = 0; i < n_peers; ++i)
+            if (peer_ranks[i] == r) return &peers[i];
+        return nullptr;
+    };
+    // push destinations: every message needs its peer
+    std::vector<float*> d0(t->geom.size()), d1(t->geom.size());
+    std::vector<TileLay> pl;
+    for (size_t i = 0; i < t->geom.size(); ++i) {
+        const sobfu_hip_tiled_exports* e = find(t->geom[i].peer);
+        if (!e || !e->nabla_u[0] || !e->nabla_u[1] || !e->flags) return SOBFU_E_BADARG;
+        d0[i] = (float*) e->nabla_u[0];
+        d1[i] = (float*) e->nabla_u[1];
+        pl.push_back(make_layout(dims, t->P, t->geom[i].peer));
+    }
+    // sync set: EVERY other rank -- the halo neighbours for the nabla_U cells, the rest because the max-norm rows become global by
+    // every rank storing its row maximum at every other rank (world <= 64: a few 4-byte stores per iteration)
+    sobfu_hip::TileSync sy{};
+    sy.my_rank = (uint32_t) t->rank; sy.world = (uint32_t) t->world;
+    sy.timeout_ticks = t->timeout_ticks;
+    sy.my_flags = t->flags; sy.my_grows = t->grows;
+    for (int r = 0; r < t->world; ++r) {
+        if (r == t->rank) continue;
+        const sobfu_hip_tiled_exports* e = find(r);
+        if (!e || !e->flags || !e->rows) return SOBFU_E_BADARG;
+        sy.sync_rank[sy.n_sync]  = r;
+        sy.peer_flags[sy.n_sync] = (uint32_t*) e->flags;
+        sy.peer_grows[sy.n_sync] = (uint32_t*) e->rows;
+        sy.n_sync += 1;
+    }
+    SOBFU_HIP_TRY(hipMemcpy(t->sync_d, &sy, sizeof sy, hipMemcpyHostToDevice));
+    build_a_boxes(t, d0.data(), d1.data(), pl.data());
+    t->direct = true;
+    return 0;
+}
+
+int sobfu_hip_tiled_set_wait(sobfu_hip_tiled* t, int wait) {
+    SOBFU_CHECK_ARGS(t);
+    t->wait_enabled = wait ? 1 : 0;
+    return 0;
+}
+
+int sobfu_hip_tiled_status(sobfu_hip_tiled* t, int* missing_peer) {
+    SOBFU_CHECK_ARGS(t);
+    uint32_t err = 0;
+    SOBFU_HIP_TRY(hipMemcpy(&err, &t->sync_d->err, 4, hipMemcpyDeviceToHost));
+    if (missing_peer) *missing_peer = err ? (int) err - 1 : -1;
+    return (err || t->dead) ? SOBFU_E_TIMEOUT : 0;
 }
 
 int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_fn exchange_fn, sobfu_hip_tiled_allreduce_fn allreduce_fn,
@@ -390,12 +614,10 @@ int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs
         if (send_boxes) std::memcpy(send_boxes + 6 * i, t->sboxes.data() + 6 * i, 6 * sizeof(int));
         if (recv_boxes) std::memcpy(recv_boxes + 6 * i, t->rboxes.data() + 6 * i, 6 * sizeof(int));
     }
-    return n;  // number of messages of an exchange (0 for z-slabs, which exchange planes in place)
+    return n;  // number of messages of an exchange
 }
 
-// One halo exchange of a 12-byte tile field.  z-slabs: `planes` owned planes per interior face travel in place (no copy on
-// either side).  3-D tiles: the faces / edge strips are packed into the send buffer, travel as one message per neighbour, and are
-// scattered into the halo cells -- all on `stream`.
+// Delivers the messages of one exchange from d_send to d_recv (RCCL grouped send/recv, or the user transport).
 static int transfer(sobfu_hip_tiled* t, const float* d_send, float* d_recv, const sobfu_hip_tiled_msg* msgs, int n, hipStream_t stream) {
     if (n == 0) return 0;
     if (!t->comm) return t->xfn ? t->xfn(t->tctx, t->rank, d_send, d_recv, msgs, n, (void*) stream) : 0;  // user transport / dry handle
@@ -408,18 +630,20 @@ static int transfer(sobfu_hip_tiled* t, const float* d_send, float* d_recv, cons
     return 0;
 }
 
-static int exchange(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t stream) {
-    if (t->slab) {
-        const size_t plane_f = (size_t) t->X * t->Y * 3, cnt = plane_f * planes;
-        sobfu_hip_tiled_msg m[2];
-        int n = 0;
-        if (t->rank > 0) m[n++] = {t->rank - 1, plane_f * t->own_lo, plane_f * (t->own_lo - planes), cnt};
-        if (t->rank < t->world - 1) m[n++] = {t->rank + 1, plane_f * (t->own_hi - planes), plane_f * t->own_hi, cnt};
-        return transfer(t, field3, field3, m, n, stream);
-    }
+// z-slab schedules: `planes` owned planes per interior face of a slab field travel in place (no copy on either side)
+static int exchange_planes(sobfu_hip_tiled* t, float* field3, int planes, hipStream_t stream) {
+    const size_t plane_f = (size_t) t->X * t->Y * 3, cnt = plane_f * planes;
+    sobfu_hip_tiled_msg m[2];
+    int n = 0;
+    if (t->rank > 0) m[n++] = {t->rank - 1, plane_f * t->own_lo, plane_f * (t->own_lo - planes), cnt};
+    if (t->rank < t->world - 1) m[n++] = {t->rank + 1, plane_f * (t->own_hi - planes), plane_f * t->own_hi, cnt};
+    return transfer(t, field3, field3, m, n, stream);
+}
+
+// tile path, RCCL / callback transports: the send buffer (filled by pass A's push boxes) -> peers -> scatter into the halo cells
+static int exchange_packed(sobfu_hip_tiled* t, float* field3, hipStream_t stream) {
     const int n = (int) t->msgs.size();
     if (n == 0) return 0;
-    SOBFU_TRY(sobfu_hip::launch_msg_copy(true, field3, t->sendbuf, t->L[0], t->L[1], t->L[2], t->sboxes.data(), n, stream));
     SOBFU_TRY(transfer(t, t->sendbuf, t->recvbuf, t->msgs.data(), n, stream));
     return sobfu_hip::launch_msg_copy(false, field3, t->recvbuf, t->L[0], t->L[1], t->L[2], t->rboxes.data(), n, stream);
 }
@@ -430,10 +654,15 @@ static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_
     return 0;
 }
 
-// Debug / bring-up: exchange `planes` planes of a caller-provided 12-byte slab field exactly as the loop does.
+// Debug / bring-up: one halo exchange of a caller-provided 12-byte tile field exactly as the loop's RCCL / callback transports do
+// it (z-slabs: `planes` planes in place; 3-D tiles: pack, transfer, scatter).
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream) {
     SOBFU_CHECK_ARGS(t && d_field3 && planes > 0 && planes <= kHalo && (t->slab || planes == kHalo));
-    return exchange(t, d_field3, planes, (hipStream_t) stream);
+    if (t->slab) return exchange_planes(t, d_field3, planes, (hipStream_t) stream);
+    const int n = (int) t->msgs.size();
+    if (n == 0) return 0;
+    SOBFU_TRY(sobfu_hip::launch_msg_copy(true, d_field3, t->sendbuf, t->L[0], t->L[1], t->L[2], t->sboxes.data(), n, (hipStream_t) stream));
+    return exchange_packed(t, d_field3, (hipStream_t) stream);
 }
 
 // Bring-up self test usable with ONE rank: a world-1 communicator sends n floats from d_src to itself into d_dst through
@@ -461,20 +690,40 @@ int sobfu_hip_tiled_allreduce_max_u32(sobfu_hip_tiled* t, uint32_t* d_buf, size_
 // Convergence without a stall: psi and F = (phi_n o psi).tsdf are PING-PONGED (iteration k reads buffer (k-1)&1 and writes
 // buffer k&1), and the device-side gate of iteration k looks at the max-norm row of iteration k-2.  When the threshold fires
 // at iteration k, iteration k+1 has already run speculatively -- into the OTHER buffer -- every later launch is a no-op,
-// and the state the reference's `break` (solver.cu:183) leaves is intact in buffer k&1.  The all-reduce that makes row k
-// global therefore has a whole iteration to complete and is issued on the comm stream behind the exchange: nothing in the
-// loop ever waits for a reduction that is still in flight (a same-iteration gate costs an exposed collective or a
-// stream round trip per iteration: 67 vs 55 us per iteration in the N = 8 compute-side timing).
+// and the state the reference's `break` (solver.cu:183) leaves is intact in buffer k&1.  The reduction that makes row k
+// global therefore has a whole iteration to complete: on the direct transport it rides on pass A of iteration k+1 (every rank
+// stores its row maximum at every other rank, covered by that iteration's arrival flags); on the others it is an all-reduce
+// behind the exchange.  Nothing in the loop ever waits for a reduction that is still in flight (a same-iteration gate costs an
+// exposed collective or a stream round trip per iteration: 67 vs 55 us per iteration in the round-2 N = 8 compute-side timing).
+// a bare dry handle (no communicator, no transport plugged in) times the direct schedule -- or, with SOBFU_TILED_DRY_PACKED=1 at
+// create, the launches of the RCCL / callback transports (pass A packing into the send buffer, the scatter kernel, pass B)
+static bool uses_sync(const sobfu_hip_tiled* t) { return t->direct || (!t->comm && !t->xfn && !t->dry_packed); }
+static bool tile_path(const sobfu_hip_tiled* t) { return !t->slab || uses_sync(t); }
+
 static int tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, const float* d_phi_n_full, float* d_phi_n_psi_local,
                        float* d_psi_local, int max_iters, hipStream_t st) {
     sobfu_hip_tiled::Session& q = t->q;
     if (q.active) return SOBFU_E_BADARG;
+    if (t->dead) return SOBFU_E_TIMEOUT;
     const int X = t->X, Y = t->Y, Z = t->Z, Lx = t->L[0], Ly = t->L[1], Lz = t->L[2];
     float* P[2] = {t->c_psi, t->c_psi2};
     float* F[2] = {t->c_f, t->c_f2};
-    q = sobfu_hip_tiled::Session{};
-    q.pn = d_phi_n_full; q.pnp = d_phi_n_psi_local; q.psi = d_psi_local;
-    q.cap = max_iters;
+    if (max_iters > t->slots_iters) {
+        if (t->direct) return SOBFU_E_UNSUPPORTED;  // the global rows are mapped by the peers: their size is fixed (4096 iterations per solve)
+        if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
+        if (t->grows) SOBFU_HIP_TRY(hipFree(t->grows));
+        t->slots = t->grows = nullptr;
+        t->slots_iters = 0;
+        SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (max_iters + 1) * kSlots * 4));
+        SOBFU_HIP_TRY(hipMalloc((void**) &t->grows, (size_t) (max_iters + 2) * kSlots * 4));
+        SOBFU_HIP_TRY(hipMemset(t->grows, 0, (size_t) (max_iters + 2) * kSlots * 4));
+        SOBFU_HIP_TRY(hipMemcpy(&t->sync_d->my_grows, &t->grows, sizeof(uint32_t*), hipMemcpyHostToDevice));
+        t->slots_iters = max_iters;
+    }
+    sobfu_hip_tiled::Session n{};
+    n.pn = d_phi_n_full; n.pnp = d_phi_n_psi_local; n.psi = d_psi_local;
+    n.cap = max_iters;
+    n.seq_base = t->seq_total;
     // enter the compact format (includes the warp of solver.cu:106); both halves start equal so that cells no launch
     // writes (beyond the one-cell shells) hold the caller's values whichever half the loop ends in
     SOBFU_TRY(sobfu_hip::launch_pack_vec(d_psi_local, P[0], t->NL, st));
@@ -483,20 +732,39 @@ static int tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, cons
     SOBFU_TRY(sobfu_hip::launch_apply_tsdf_only(t->c_n, F[0], P[0], Lx, Ly, Lz, st, Z, X, Y));
     SOBFU_HIP_TRY(hipMemcpyAsync(P[1], P[0], t->NL * 12, hipMemcpyDeviceToDevice, st));
     SOBFU_HIP_TRY(hipMemcpyAsync(F[1], F[0], t->NL * 4, hipMemcpyDeviceToDevice, st));
-    if (max_iters > t->slots_iters) {
-        if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
-        t->slots = nullptr;
-        SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (max_iters + 1) * kSlots * 4));
-        t->slots_iters = max_iters;
-    }
     if (max_iters > 0) SOBFU_HIP_TRY(hipMemsetAsync(t->slots, 0, (size_t) (max_iters + 1) * kSlots * 4, st));
+    q        = n;  // the session is open only once everything above has been enqueued
     q.active = true;
     return 0;
 }
 
-static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
+// the first iteration of a communicator's life, under a host-side deadline: a wedged rank says what it is waiting for and
+// aborts its communicators instead of sitting in a collective until somebody's process-group timeout
+static int first_iteration_watchdog(sobfu_hip_tiled* t, hipStream_t st) {
+    t->first_checked = true;
+    SOBFU_HIP_TRY(hipEventRecord(t->ev_first, st));
+    const double limit = deadline_seconds();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(t->ev_first);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return (int) e;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    std::fprintf(stderr, "sobfu_hip: rank %d: the first tiled iteration has not completed after %.0f s -- waiting for the halo exchange "
+                         "(grouped ncclSend/ncclRecv with ranks", t->rank, limit);
+    for (const sobfu_hip_tiled_msg& m : t->msgs) std::fprintf(stderr, " %d", m.peer);
+    std::fprintf(stderr, ")%s; aborting the communicator(s)\n", t->p.max_update_norm >= 0.f ? " or the max-norm all-reduce" : "");
+    abort_comms(t);
+    return SOBFU_E_TIMEOUT;
+}
+
+// phases: 1 = pass A (+ the exchange of the RCCL / callback transports), 2 = pass B (+ the row reduction); 3 = a whole iteration
+static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int phases) {
     sobfu_hip_tiled::Session& q = t->q;
     if (!q.active || n_steps < 0 || q.launched + n_steps > q.cap) return SOBFU_E_BADARG;
+    if (t->dead) return SOBFU_E_TIMEOUT;
     const int X = t->X, Y = t->Y, Z = t->Z, Lx = t->L[0], Ly = t->L[1], Lz = t->L[2];
     const sobfu_hip_solver_params& p = t->p;
     float* P[2] = {t->c_psi, t->c_psi2};
@@ -510,11 +778,9 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
     const int a_lo = t->lo[2] ? std::min(lo + H, hi) : lo, a_hi = t->hi[2] ? std::max(hi - H, a_lo) : hi;
     const int b_lo = t->lo[2] ? std::min(lo + 3, hi) : lo, b_hi = t->hi[2] ? std::max(hi - 3, b_lo) : hi;
     const int b_first = t->lo[2] ? lo - 1 : lo, b_last = t->hi[2] ? hi + 1 : hi;
-    // x / y: pass A produces the owned cells; pass B also the one-cell y shells (rows of the same boxes) and -- serial schedule
-    // only, the one 3-D tiles use -- the one-column x shells as transposed boxes of the same launch
     const int ax0 = t->o0[0], ax1 = t->o1[0], ay0 = t->o0[1], ay1 = t->o1[1];
-    const int by0 = t->lo[1] ? ay0 - 1 : ay0, by1 = t->hi[1] ? ay1 + 1 : ay1;
     const int own[6] = {ax0, ax1, ay0, ay1, lo, hi};
+    const bool tiles = tile_path(t), sync = uses_sync(t);
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
     // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
     // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N >= 4 at 256^3, if a face takes the ~65 us that ~60 GB/s per xGMI direction implies)
@@ -523,30 +789,35 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
     const char* se = std::getenv("SOBFU_TILED_SERIAL");
     const bool want_split = sa ? sa[0] == '1' : (t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes));
     const bool split_a = (t->lo[2] || t->hi[2]) && a_hi > a_lo && want_split;
-    const bool serial = !t->slab || (se ? se[0] == '1' : t->schedule == 3);  // the overlapped schedules exist for z-slabs only
-    // Where the all-reduce of a max-norm row runs (the late gate gives row j until pass B of iteration j+2):
-    //   own communicator + stream (sobfu_hip_tiled_add_reduce_comm): issued right after row j's pass B, never in the way of
-    //   an exchange; otherwise on the comm stream behind the next exchange (overlapped schedules) or in line (serial).
+    const bool serial = se ? se[0] == '1' : t->schedule == 3;  // z-slab path only
+    // Where the all-reduce of a max-norm row runs on the RCCL / callback transports (the late gate gives row j until pass B of
+    // iteration j+2): in line behind pass B (serial / tile path), on the comm stream behind the next exchange (overlapped slab
+    // schedules), or -- opt-in, sobfu_hip_tiled_add_reduce_comm -- on a communicator and stream of its own.
     enum { RED_NONE, RED_INLINE, RED_COMM_STREAM, RED_OWN_COMM };
-    const int red_mode = (!multi || !can_converge) ? RED_NONE : (t->comm2 ? RED_OWN_COMM : (serial ? RED_INLINE : RED_COMM_STREAM));
+    const int red_mode = (!multi || !can_converge || sync) ? RED_NONE : (t->comm2 ? RED_OWN_COMM : ((serial || tiles) ? RED_INLINE : RED_COMM_STREAM));
     bool* red_issued = q.red_issued;  // an asynchronous reduce of the latest row of this parity is behind ev_red[parity]
     const auto host_t0 = std::chrono::steady_clock::now();
     const int last = q.launched + n_steps;
     for (int it = q.launched + 1; it <= last; ++it) {
         const float *psi_in = P[(it - 1) & 1], *f_in = F[(it - 1) & 1];
         float *psi_out = P[it & 1], *f_out = F[it & 1];
-        const uint32_t* prev = (it > 2 && can_converge) ? t->slots + (size_t) (it - 2) * kSlots : nullptr;  // the late gate
+        float* nu = t->nUb[tiles ? (it & 1) : 0];
+        const uint32_t* rows = sync ? t->grows : t->slots;  // the rows the gate reads: global by the time it does
+        const uint32_t* prev = (it > 2 && can_converge) ? rows + (size_t) (it - 2) * kSlots : nullptr;  // the late gate
         uint32_t* row        = t->slots + (size_t) it * kSlots;
         auto A = [&](int za, int zb, int za2 = 0, int zb2 = 0) {  // pass A writes scratch only: never gated
             const sobfu_hip::LaunchBox bx[2] = {{ax0, ax1, ay0, ay1, za, zb, false}, {ax0, ax1, ay0, ay1, za2, zb2, false}};
-            return sobfu_hip::launch_pass_a_boxes(f_in, t->c_g, psi_in, t->nU, p.w_reg, Lx, Ly, Lz, bx, 2, nullptr, 0.f, 0, st, true);
+            return sobfu_hip::launch_pass_a_boxes(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, bx, 2, nullptr, 0.f, 0, st, true);
         };
-        auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0, bool x_shells = false) {
-            const sobfu_hip::LaunchBox bx[4] = {{ax0, ax1, by0, by1, za, zb, false}, {ax0, ax1, by0, by1, za2, zb2, false},
-                                                {ax0 - 1, (x_shells && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
-                                                {ax1, (x_shells && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
-            return sobfu_hip::launch_pass_b_boxes(t->nU, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y,
-                                                  Z, own, bx, 4, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
+        auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0, bool shells = false) {
+            // the owned block with its z shells (extra planes of the march); the one-cell x / y shells are direct boxes
+            const sobfu_hip::LaunchBox bx[6] = {{ax0, ax1, ay0, ay1, za, zb, false}, {ax0, ax1, ay0, ay1, za2, zb2, false},
+                                                {ax0, ax1, ay0 - 1, (shells && t->lo[1]) ? ay0 : ay0 - 1, lo, hi, true},
+                                                {ax0, ax1, ay1, (shells && t->hi[1]) ? ay1 + 1 : ay1, lo, hi, true},
+                                                {ax0 - 1, (shells && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
+                                                {ax1, (shells && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
+            return sobfu_hip::launch_pass_b_boxes(nu, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y,
+                                                  Z, own, bx, 6, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
         };
         auto wait_gate = [&]() -> int {  // row it-2 must be global before the first pass-B launch of this iteration
             if (prev && red_issued[it & 1]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[it & 1], 0));
@@ -573,25 +844,56 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
             }
             return 0;
         };
-        q.launched = it;
+        const bool ev = (tiles || serial) && phases == 3 && t->prof_stride > 0 && it % t->prof_stride == 0 && (size_t) 4 * (t->prof_pending + 1) <= t->prof_ev.size();
+        hipEvent_t* e = ev ? t->prof_ev.data() + 4 * t->prof_pending : nullptr;
+        if (tiles) {
+            // TILE PATH -- pass A's launch carries the exchange (push boxes first).  Direct transport: that is all of it -- the
+            // launch retires when the neighbours' cells have landed too.  RCCL / callback: the packed buffer travels, one
+            // kernel scatters what arrived.  No cross-stream events anywhere.
+            if (phases & 1) {
+                if (ev) SOBFU_HIP_TRY(hipEventRecord(e[0], st));
+                const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[it & 1];
+                const bool pushes = multi || sync;  // a world of one has no messages
+                SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, pushes ? bx.data() : &bx.back(),
+                                                        pushes ? (int) bx.size() : 1, sync ? t->sync_d : nullptr, q.seq_base + (uint32_t) it,
+                                                        t->wait_enabled, (sync && it >= 2) ? t->slots + (size_t) (it - 1) * kSlots : nullptr,
+                                                        (uint32_t) (it - 1), 0, st, true));
+                if (ev) SOBFU_HIP_TRY(hipEventRecord(e[1], st));
+                if (multi && !sync) SOBFU_TRY(exchange_packed(t, nu, st));
+            }
+            if (phases & 2) {
+                SOBFU_TRY(wait_gate());
+                if (ev) SOBFU_HIP_TRY(hipEventRecord(e[2], st));
+                SOBFU_TRY(B(b_first, b_last, 0, 0, true));
+                if (ev) {
+                    SOBFU_HIP_TRY(hipEventRecord(e[3], st));
+                    t->prof_pending += 1;
+                }
+                SOBFU_TRY(after_b());
+                q.launched = it;  // advanced once the iteration is fully enqueued
+                if (t->comm && !t->first_checked) SOBFU_TRY(first_iteration_watchdog(t, st));
+            }
+            continue;
+        }
+        if (phases != 3) return SOBFU_E_UNSUPPORTED;
         if (serial) {
             // no overlap, no cross-stream events: pass A, the exchange and pass B in line on `st`.  Every event record / wait
             // between two kernels costs a few microseconds of drained pipeline (~20 us per iteration for the overlapped
             // schedule's three), which a fast exchange on a thin slab does not repay.
-            const bool ev = t->prof_stride > 0 && it % t->prof_stride == 0 && (size_t) 4 * (t->prof_pending + 1) <= t->prof_ev.size();
-            hipEvent_t* e = ev ? t->prof_ev.data() + 4 * t->prof_pending : nullptr;
             if (ev) SOBFU_HIP_TRY(hipEventRecord(e[0], st));
             SOBFU_TRY(A(lo, hi));
             if (ev) SOBFU_HIP_TRY(hipEventRecord(e[1], st));
-            if (multi) SOBFU_TRY(exchange(t, t->nU, H, st));
+            if (multi) SOBFU_TRY(exchange_planes(t, nu, H, st));
             SOBFU_TRY(wait_gate());
             if (ev) SOBFU_HIP_TRY(hipEventRecord(e[2], st));
-            SOBFU_TRY(B(b_first, b_last, 0, 0, true));
+            SOBFU_TRY(B(b_first, b_last));
             if (ev) {
                 SOBFU_HIP_TRY(hipEventRecord(e[3], st));
                 t->prof_pending += 1;
             }
             SOBFU_TRY(after_b());
+            q.launched = it;
+            if (t->comm && !t->first_checked) SOBFU_TRY(first_iteration_watchdog(t, st));
             continue;
         }
         // both boundary regions of a pass go out as ONE launch (two plane ranges)
@@ -600,7 +902,7 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
         if (multi) {
             SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
             SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
-            SOBFU_TRY(exchange(t, t->nU, H, t->comm_stream));
+            SOBFU_TRY(exchange_planes(t, nu, H, t->comm_stream));
             SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
             if (red_mode == RED_COMM_STREAM && it >= 2 && it < n_iters && q.red_upto < it - 1) {
                 // row it-1 is complete (its pass B precedes this iteration's ev_bnd, which the comm stream has waited for) and
@@ -618,6 +920,8 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
         if (multi) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
         if (b_lo > b_first || b_last > b_hi) SOBFU_TRY(B(b_first, b_lo, b_hi, b_last));
         SOBFU_TRY(after_b());
+        q.launched = it;
+        if (t->comm && !t->first_checked) SOBFU_TRY(first_iteration_watchdog(t, st));
         // the next iteration's A_bnd overwrites nabla_U planes the exchange of THIS iteration sent: it runs on `st` after
         // the wait above, so the sends have completed by then; the next exchange's receives overwrite halo planes B_bnd
         // of THIS iteration read: the comm stream starts it only after the next ev_bnd, recorded on `st` behind B_bnd
@@ -627,25 +931,67 @@ static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st) {
     return 0;
 }
 
+// an error inside the loop: peers may be blocked in a collective this rank never issued -- drain what was enqueued, abort the
+// communicators (so that the peers' calls return instead of hanging) and give the handle up
+static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int phases = 3) {
+    const int rc = tiled_step_impl(t, n_steps, st, phases);
+    if (rc != 0 && rc != SOBFU_E_BADARG && rc != SOBFU_E_UNSUPPORTED) {
+        (void) hipStreamSynchronize(st);
+        abort_comms(t);
+        t->q.active = false;
+    }
+    return rc;
+}
+
+// direct transport, end of a solve: the last max-norm row travels now; the handshake also tells every rank that its neighbours
+// have retired their last pass B, i.e. that the next solve's first pushes cannot land under a kernel still reading the halo cells
+static int tiled_flush(sobfu_hip_tiled* t, hipStream_t st) {
+    sobfu_hip_tiled::Session& q = t->q;
+    if (q.flushed) return 0;
+    const int n = q.launched;
+    const uint32_t seq = q.seq_base + (uint32_t) n + 1u;
+    SOBFU_TRY(sobfu_hip::launch_tile_flush(t->sync_d, seq, t->wait_enabled, n > 0 ? t->slots + (size_t) n * kSlots : nullptr, (uint32_t) n, st));
+    t->seq_total = seq;
+    q.flushed    = true;
+    return 0;
+}
+
 static int tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, float* per_iter_max_norm, hipStream_t st) {
     sobfu_hip_tiled::Session& q = t->q;
     if (!q.active) return SOBFU_E_BADARG;
+    if (t->dead) return SOBFU_E_TIMEOUT;
     const sobfu_hip_solver_params& p = t->p;
     float* P[2] = {t->c_psi, t->c_psi2};
     sobfu_hip_solver_report r{};
     r.last_max_update_norm = r.last_max_update_index = r.last_e_data = r.last_e_reg = NAN;
     const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
     const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
+    const bool sync = uses_sync(t);
     const int n_iters = q.launched;
-    if (multi && n_iters > 0) {  // rows the loop has not reduced yet: all of them without a threshold, the tail otherwise
+    const uint32_t* rows = t->slots;
+    if (sync) {
+        SOBFU_TRY(tiled_flush(t, st));
+        rows = t->grows;
+    } else if (multi && n_iters > 0) {  // rows the loop has not reduced yet: all of them without a threshold, the tail otherwise
         for (int k = 0; k < 2; ++k)
             if (q.red_issued[k]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[k], 0));
         const int first = q.red_upto + 1;
         if (first <= n_iters) SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (n_iters - first + 1) * kSlots, st));
     }
     std::vector<uint32_t> hs((size_t) std::max(n_iters, 1) * kSlots, 0u);
-    if (n_iters > 0) SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), t->slots + kSlots, (size_t) n_iters * kSlots * 4, hipMemcpyDeviceToHost, st));
+    if (n_iters > 0) SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), rows + kSlots, (size_t) n_iters * kSlots * 4, hipMemcpyDeviceToHost, st));
     SOBFU_HIP_TRY(hipStreamSynchronize(st));
+    if (sync) {
+        uint32_t err = 0;
+        SOBFU_HIP_TRY(hipMemcpy(&err, &t->sync_d->err, 4, hipMemcpyDeviceToHost));
+        if (err) {
+            std::fprintf(stderr, "sobfu_hip: rank %d: the arrival flag of rank %u did not reach this GPU within the deadline (direct transport)\n",
+                         t->rank, err - 1u);
+            t->dead  = true;
+            q.active = false;
+            return SOBFU_E_TIMEOUT;
+        }
+    }
     int done = n_iters;
     for (int k = 0; k < n_iters; ++k) {
         uint32_t m = 0;
@@ -683,6 +1029,12 @@ int sobfu_hip_tiled_step(sobfu_hip_tiled* t, int n_iters, void* stream) {
     return tiled_step(t, n_iters, (hipStream_t) stream);
 }
 
+int sobfu_hip_tiled_step_phase(sobfu_hip_tiled* t, int phase, void* stream) {
+    SOBFU_CHECK_ARGS(t && phase >= 0 && phase <= 2);
+    if (phase == 2) return (t->q.active && uses_sync(t)) ? tiled_flush(t, (hipStream_t) stream) : SOBFU_E_BADARG;
+    return tiled_step(t, 1, (hipStream_t) stream, phase == 0 ? 1 : 2);
+}
+
 int sobfu_hip_tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, float* per_iter_max_norm, void* stream) {
     SOBFU_CHECK_ARGS(t);
     return tiled_end(t, report, per_iter_max_norm, (hipStream_t) stream);
@@ -694,14 +1046,7 @@ int sobfu_hip_tiled_iterate(sobfu_hip_tiled* t, const float* d_phi_global_local,
     SOBFU_CHECK_ARGS(t && d_phi_global_local && d_phi_n_full && d_phi_n_psi_local && d_psi_local && n_iters >= 0);
     hipStream_t st = (hipStream_t) stream;
     SOBFU_TRY(tiled_begin(t, d_phi_global_local, d_phi_n_full, d_phi_n_psi_local, d_psi_local, n_iters, st));
-    const int rc = tiled_step(t, n_iters, st);
-    if (rc != 0) {
-        // peers may be blocked in a collective this rank never issued: drain what was enqueued and give the session up (the
-        // caller must treat the communicator as dead -- sobfu_hip_tiled_destroy)
-        (void) hipStreamSynchronize(st);
-        t->q.active = false;
-        return rc;
-    }
+    SOBFU_TRY(tiled_step(t, n_iters, st));
     return tiled_end(t, report, per_iter_max_norm, st);
 }
 

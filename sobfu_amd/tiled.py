@@ -117,15 +117,20 @@ class TileLayout:
         return (self.o0[0], self.o1[0], self.o0[1], self.o1[1], self.o0[2], self.o1[2])
 
     def pass_b_boxes(self):
-        """[(box, transposed)] pass B produces: the owned cells with their one-cell y / z shells, and the one-column x shells
-        (lanes along y).  Cells on tile edges (two shells at once) come out of stale halo data and are never read."""
+        """[(box, thin)] pass B produces: the owned cells with their one-cell z shells (extra planes of the march) and the one-cell
+        y / x shells as THIN boxes (evaluated lane per cell).  Cells on tile edges (two shells at once) are never read."""
         o0, o1, lo, hi = self.o0, self.o1, self.lo3, self.hi3
         ext = lambda a: (o0[a] - (1 if lo[a] else 0), o1[a] + (1 if hi[a] else 0))  # noqa: E731
-        boxes = [((o0[0], o1[0]) + ext(1) + ext(2), False)]
+        own = lambda a: (o0[a], o1[a])  # noqa: E731
+        boxes = [(own(0) + own(1) + ext(2), False)]
+        if lo[1]:
+            boxes.append((own(0) + (o0[1] - 1, o0[1]) + own(2), True))
+        if hi[1]:
+            boxes.append((own(0) + (o1[1], o1[1] + 1) + own(2), True))
         if lo[0]:
-            boxes.append(((o0[0] - 1, o0[0], o0[1], o1[1], o0[2], o1[2]), True))
+            boxes.append(((o0[0] - 1, o0[0]) + own(1) + own(2), True))
         if hi[0]:
-            boxes.append(((o1[0], o1[0] + 1, o0[1], o1[1], o0[2], o1[2]), True))
+            boxes.append(((o1[0], o1[0] + 1) + own(1) + own(2), True))
         return boxes
 
     def messages(self, width=None):
@@ -287,15 +292,15 @@ class HipBackend:
         self._call("sobfu_hip_tile3_apply_tsdf_only", self._p(st.c_n), X, Y, Z, self._p(st.c_f), self._p(st.c_psi), Lx, Ly, Lz)  # solver.cu:106
         return st
 
-    def pass_a(self, st, box, w_reg, prev_slots, thr, transposed=False):
+    def pass_a(self, st, box, w_reg, prev_slots, thr, thin=False):
         """nabla_U on the local cells of `box` = (x0, x1, y0, y1, z0, z1)"""
         if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0:
             return
         prev = self._p(prev_slots) if prev_slots is not None else None
         self._call("sobfu_hip_tile3_potential_gradient", self._p(st.c_f), self._p(st.c_g), self._p(st.c_psi), self._p(st.nabla_U),
-                   C.c_float(w_reg), *st.layout.L, (C.c_int * 6)(*box), 1 if transposed else 0, prev, C.c_float(thr), 1 if self.compact else 0)
+                   C.c_float(w_reg), *st.layout.L, (C.c_int * 6)(*box), 1 if thin else 0, prev, C.c_float(thr), 1 if self.compact else 0)
 
-    def pass_b(self, st, box, slots, taps, alpha, prev_slots, thr, transposed=False):
+    def pass_b(self, st, box, slots, taps, alpha, prev_slots, thr, thin=False):
         """psi update + warp on the local cells of `box`"""
         if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0:
             return
@@ -303,7 +308,7 @@ class HipBackend:
         prev = self._p(prev_slots) if prev_slots is not None else None
         self._call("sobfu_hip_tile3_smooth_update_apply", self._p(st.nabla_U), self._p(st.c_psi), self._p(st.c_n), self._p(st.c_f), None,
                    self._p(slots), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), *L.L, *L.dims, (C.c_int * 6)(*L.own_box()),
-                   (C.c_int * 6)(*box), 1 if transposed else 0, prev, C.c_float(thr), 1 if self.compact else 0)
+                   (C.c_int * 6)(*box), 1 if thin else 0, prev, C.c_float(thr), 1 if self.compact else 0)
 
     def end(self, st):
         if not self.compact:
@@ -391,7 +396,7 @@ class TiledSolver:
                 finish_halo_ops(start_halo_ops(xch))
                 unpack()
                 for box, tr in b_boxes:
-                    be.pass_b(st, box, row, self.taps, self.alpha, prev, self.thr, transposed=tr)
+                    be.pass_b(st, box, row, self.taps, self.alpha, prev, self.thr, thin=tr)
             if self.world > 1 and can_converge:
                 dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
         if self.world > 1 and not can_converge:
@@ -509,15 +514,23 @@ class TiledMsg(C.Structure):
     _fields_ = [("peer", C.c_int), ("send_off", C.c_size_t), ("recv_off", C.c_size_t), ("count", C.c_size_t)]
 
 
-class NativeTiledSolver:
-    """The same tile loop run entirely in C++ (sobfu_amd/csrc/tiled_capi.hip): RCCL send/recv issued from the library, no Python
-    per iteration (z-slabs: on a dedicated communication stream, overlapped with the interior compute).  torch.distributed is
-    used once, to hand the RCCL unique id to every rank."""
+class TiledExports(C.Structure):
+    """sobfu_hip_tiled_exports"""
+    _fields_ = [("nabla_u", C.c_void_p * 2), ("flags", C.c_void_p), ("rows", C.c_void_p)]
 
-    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, group=None, dry=None, grid=None):
+
+class NativeTiledSolver:
+    """The same tile loop run entirely in C++ (sobfu_amd/csrc/tiled_capi.hip), no Python per iteration.  Transports:
+    "direct" -- halo cells stored straight into the neighbours' arrays over xGMI from pass A's launch (peer-mapped with hipIpc;
+    torch.distributed is used once, to hand the 64-byte handles around), two launches per iteration and no collective in the
+    loop; "rccl" -- RCCL send/recv issued from the library (z-slabs: on a dedicated communication stream, overlapped with the
+    interior compute; torch.distributed hands the unique id to every rank)."""
+
+    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, group=None, dry=None, grid=None, transport=None):
         """grid: (Px, Py, Pz) tiles (default: z-slabs, 1 x 1 x world).  dry=(world, rank): a communicator-less handle with that
-        rank's layout -- every launch and stream dependency of the rank's schedule without peers (halos are stale unless a
-        transport is plugged in with set_transport; alone, only its TIMING means anything: tools/slab_time_native.py)."""
+        rank's layout -- every launch of the rank's schedule without peers (halos are stale unless a transport is plugged in with
+        set_transport / connect_local; alone, only its TIMING means anything: tools/tile_time_native.py).  transport: "rccl"
+        (default with a process group) or "direct"."""
         import os
 
         from . import _lib
@@ -528,6 +541,13 @@ class NativeTiledSolver:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.transport = transport or ("none" if dry is not None else "rccl")
+        self._opened = []
+        if self.transport == "direct" and dry is None:
+            dry = (self.world, self.rank)  # a communicator-less handle; connect_ipc() below maps the peers
+            self._connect_group = True
+        else:
+            self._connect_group = False
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         _lib.check(L.sobfu_hip_tiled_load_rccl(path.encode()), "tiled_load_rccl")
         uid = (C.c_char * 128)()
@@ -535,7 +555,7 @@ class NativeTiledSolver:
             self.world, self.rank = dry
         elif self.rank == 0:
             _lib.check(L.sobfu_hip_tiled_unique_id(uid), "tiled_unique_id")
-        if self.world > 1 and dry is None:
+        if self.world > 1 and dry is None:  # noqa: SIM102
             box = [bytes(uid)]
             dist.broadcast_object_list(box, src=0, group=group)
             uid = (C.c_char * 128).from_buffer_copy(box[0])
@@ -547,7 +567,10 @@ class NativeTiledSolver:
         self._h = C.c_void_p()
         X, Y, Z = (int(d) for d in dims)
         _lib.check(L.sobfu_hip_tiled_create3(C.byref(self._h), X, Y, Z, *grid, self.rank, uid, C.byref(self.params)), "tiled_create3")
-        want2 = os.environ.get("SOBFU_TILED_REDUCE_COMM", "1")  # "force": also on a world of one (bring-up / tests)
+        # opt-in ("1"; "force": also on a world of one, bring-up / tests): two communicators with operations in flight at once
+        # are a known RCCL hang hazard and this mode has never run on >= 2 real GPUs -- the default keeps the max-norm
+        # all-reduce on the main communicator, in line behind the exchange
+        want2 = os.environ.get("SOBFU_TILED_REDUCE_COMM", "0")
         if dry is None and ((self.world > 1 and want2 == "1") or want2 == "force"):
             # a communicator of its own for the max-norm all-reduce (collective; every rank or none)
             uid2 = (C.c_char * 128)()
@@ -569,10 +592,76 @@ class NativeTiledSolver:
         # the library's message table must be the one TileLayout.messages() describes (both sides of the C ABI build it)
         mm, sb, rb = (TiledMsg * 18)(), (C.c_int * (6 * 18))(), (C.c_int * (6 * 18))()
         n = L.sobfu_hip_tiled_messages(self._h, mm, sb, rb, 18)
-        mine = [] if lay.slab else lay.messages()
+        mine = lay.messages()
         assert n == len(mine), (n, len(mine))
         for i, (peer, sbox, rbox) in enumerate(mine):
             assert mm[i].peer == peer and tuple(sb[6 * i:6 * i + 6]) == sbox and tuple(rb[6 * i:6 * i + 6]) == rbox, (i, peer, sbox, rbox)
+        if self._connect_group:
+            self.connect_ipc()
+
+    # -- direct transport ----------------------------------------------------------------------------------------------
+    def exports(self):
+        e = TiledExports()
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_exports_get(self._h, C.byref(e)), "tiled_exports_get")
+        return e
+
+    def connect(self, ranks, exports):
+        """hand the library the device pointers (valid in THIS process) of the other ranks' exported arrays"""
+        n = len(ranks)
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_connect(self._h, n, (C.c_int * max(n, 1))(*ranks), (TiledExports * max(n, 1))(*exports)),
+                        "tiled_connect")
+        self.transport = "direct"
+
+    @staticmethod
+    def connect_local(solvers):
+        """ranks that live in ONE process (tests): plain pointers, no IPC"""
+        ex = [s.exports() for s in solvers]
+        for s in solvers:
+            others = [q for q in range(len(solvers)) if q != s.rank]
+            s.connect(others, [ex[q] for q in others])
+
+    def connect_ipc(self):
+        """one process per rank: every rank exports its four arrays as 64-byte hipIpc handles, all ranks gather them over
+        torch.distributed (any backend) and map the others' arrays; a barrier, so that nobody begins a solve before every rank
+        is connected (and has cleared its halo cells)"""
+        lib, check = self._lib.lib(), self._lib.check
+        e = self.exports()
+        mine = []
+        for ptr in (e.nabla_u[0], e.nabla_u[1], e.flags, e.rows):
+            h = (C.c_char * 64)()
+            check(lib.sobfu_hip_ipc_export(C.c_void_p(ptr), h), "ipc_export")
+            mine.append(bytes(h))
+        allh = [None] * self.world
+        dist.all_gather_object(allh, mine, group=self.group)
+        ranks, exps = [], []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            ptrs = []
+            for hb in allh[q]:
+                out = C.c_void_p()
+                check(lib.sobfu_hip_ipc_open((C.c_char * 64).from_buffer_copy(hb), C.byref(out)), "ipc_open")
+                ptrs.append(out.value)
+                self._opened.append(out.value)
+            x = TiledExports()
+            x.nabla_u[0], x.nabla_u[1], x.flags, x.rows = ptrs
+            ranks.append(q)
+            exps.append(x)
+        self.connect(ranks, exps)
+        dist.barrier(group=self.group)
+
+    def status(self):
+        """(ok, missing_peer): whether every peer has answered within the deadline so far"""
+        m = C.c_int(-1)
+        rc = self._lib.lib().sobfu_hip_tiled_status(self._h, C.byref(m))
+        return rc == 0, m.value
+
+    def set_wait(self, wait):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_set_wait(self._h, C.c_int(1 if wait else 0)), "tiled_set_wait")
+
+    def step_phase(self, phase):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_step_phase(self._h, C.c_int(int(phase)), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "tiled_step_phase")
 
     EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(TiledMsg), C.c_int, C.c_void_p)
     ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -589,6 +678,9 @@ class NativeTiledSolver:
         if getattr(self, "_h", None):
             self._lib.lib().sobfu_hip_tiled_destroy(self._h)
             self._h = None
+            for ptr in getattr(self, "_opened", []):
+                self._lib.lib().sobfu_hip_ipc_close(C.c_void_p(ptr))
+            self._opened = []
 
     __del__ = close
 
@@ -741,10 +833,12 @@ def _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks, 
         torch.cuda.synchronize()
         return ranks.max([(time.perf_counter() - t0) / n * 1e6])[0]
 
-    field = torch.zeros(L.local_shape(3), dtype=torch.float32, device="cuda")
-    for planes in ((1, 2, HALO) if L.slab else (HALO,)):  # latency vs bandwidth of a face message (z-slabs: 1/4, 1/2 and all of the halo)
-        out[f"exchange_{planes}_cells_us"] = timed(
-            lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(planes), st), "exchange"), reps)
+    direct = solver.transport == "direct"
+    if not direct:  # (the direct transport has no separate exchange step: the stores are part of pass A's launch)
+        field = torch.zeros(L.local_shape(3), dtype=torch.float32, device="cuda")
+        for planes in ((1, 2, HALO) if L.slab else (HALO,)):  # latency vs bandwidth of a face message (z-slabs: 1/4, 1/2 and all of the halo)
+            out[f"exchange_{planes}_cells_us"] = timed(
+                lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(planes), st), "exchange"), reps)
     msgs = L.messages()
     out["exchange_messages"] = len(msgs)
     out["exchange_bytes_out"] = sum((m[1][1] - m[1][0]) * (m[1][3] - m[1][2]) * (m[1][5] - m[1][4]) for m in msgs) * 12
@@ -757,7 +851,7 @@ def _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks, 
     def loop(s):
         return lambda: s.iterate(pg, pn_full, pnp, psi, iters)
 
-    if L.slab:
+    if L.slab and not direct:
         prev = os.environ.get("SOBFU_TILED_SPLIT_A")
         for name, val in (("iteration_us_pass_a_unsplit", "0"), ("iteration_us_pass_a_split", "1")):
             os.environ["SOBFU_TILED_SPLIT_A"] = val
@@ -792,7 +886,62 @@ def candidate_grids(world, dims):
     return out
 
 
-def autotune_grid(P, ranks, kw, iters=40):
+def make_native_solver(dims, grid, ranks, kw, transport):
+    """NativeTiledSolver on the given transport ("direct" / "rccl"); ranks that SHARE a GPU (bring-up) cannot use RCCL -- their
+    "rccl" is the same buffers over gloo (GlooTransport).  Returns (solver, keep-alive)."""
+    if transport == "direct":
+        return NativeTiledSolver(dims, grid=grid, transport="direct", **kw), None
+    if ranks.share and ranks.world > 1:
+        sv = NativeTiledSolver(dims, dry=(ranks.world, ranks.rank), grid=grid, **kw)
+        tr = GlooTransport()
+        sv.set_transport(tr.exchange, tr.allreduce)
+        return sv, tr
+    return NativeTiledSolver(dims, grid=grid, **kw), None
+
+
+def direct_transport_precheck(P, ranks, kw, grid, iters=6):
+    """The direct transport on THIS machine, before anything is timed: a few iterations of the bench workload on tiles against the
+    single-GPU solver, bit for bit on every rank (peer mapping, flags and deadline all exercised).  Returns None when every rank
+    agrees it works, else a reason string (collective: every rank gets the same verdict)."""
+    from . import ops
+
+    dims = P["dims"]
+    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
+    why, sv = None, None
+    try:
+        sv = NativeTiledSolver(dims, grid=grid, transport="direct", **kw)
+    except Exception as e:  # noqa: BLE001
+        why = f"setup failed: {e!r}"
+    if ranks.min([0 if why else 1])[0] == 0:  # some rank could not map its peers: nobody uses the transport
+        if sv is not None:
+            sv.close()
+        return why or "setup failed on another rank"
+    try:
+        pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
+        ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
+        ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
+        L = sv.layout
+        pg = L.take(pg_full).clone().contiguous()
+        pnp, psi = sv.new_local(2), sv.identity_psi()
+        done, norms = sv.iterate(pg, pn_full, pnp, psi, iters)
+        one = ops.Solver(dims, max_iter=iters, **kw)
+        psi_f, pnp_f = ops.new_field(dims), ops.new_volume(dims)
+        ops.init_identity(psi_f)
+        _, norms_one = one.iterate(pg_full, pn_full, pnp_f, psi_f, iters)
+        one.close()
+        same = (np.array_equal(np.asarray(norms_one, np.float32).view(np.uint32), np.asarray(norms, np.float32).view(np.uint32))
+                and torch.equal(L.owned_global(psi_f)[..., :3].contiguous().view(torch.int32), L.owned(psi)[..., :3].contiguous().view(torch.int32))
+                and torch.equal(L.owned_global(pnp_f).contiguous().view(torch.int32), L.owned(pnp).contiguous().view(torch.int32)))
+        if not same:
+            why = "tiles differ from the single-GPU solve"
+    except Exception as e:  # noqa: BLE001 -- e.g. SOBFU_E_TIMEOUT: a peer's flag did not arrive
+        why = f"{e!r}"
+    ok = ranks.min([0 if why else 1])[0]
+    sv.close()
+    return None if ok else (why or "failed on another rank")
+
+
+def autotune_grid(P, ranks, kw, iters=40, transport="rccl"):
     """us per iteration of the native loop for every candidate tile grid on the machine at hand (MAX over ranks: all agree)"""
     from . import ops
 
@@ -803,12 +952,7 @@ def autotune_grid(P, ranks, kw, iters=40):
     ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
     times = {}
     for grid in candidate_grids(ranks.world, dims):
-        if ranks.share and ranks.world > 1:
-            sv = NativeTiledSolver(dims, dry=(ranks.world, ranks.rank), grid=grid, **kw)
-            tr = GlooTransport()
-            sv.set_transport(tr.exchange, tr.allreduce)
-        else:
-            sv = NativeTiledSolver(dims, grid=grid, **kw)
+        sv, _ = make_native_solver(dims, grid, ranks, kw, transport)
         pg = sv.layout.take(pg_full).clone().contiguous()
         pnp, psi = sv.new_local(2), sv.identity_psi()
         sv.iterate(pg, pn_full, pnp, psi, 4)
@@ -836,29 +980,33 @@ def bench_tiled(args, P, ranks, timed_regions):
     kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
     K, W, R, PR = args.steps, args.warmup, args.repeats, args.profile_repeats
     total = W + (R + PR) * K
+    native = os.environ.get("SOBFU_TILED_NATIVE", "1") == "1"
+    if world == 1 and not dist.is_initialized():  # SOBFU_FORCE_TILED=1 on one GPU: a world of one
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", ranks.device))
+    # transport of the native loop: "direct" (default: peer-mapped stores over xGMI, no RCCL in the loop) is taken only after
+    # it has reproduced the single-GPU solve bit for bit on THIS machine on every rank (direct_transport_precheck, a few
+    # iterations before anything is timed); otherwise every rank falls back to "rccl" and the line says why
+    want = os.environ.get("SOBFU_TILED_TRANSPORT", "direct")
+    transport_name, fallback = ("rccl" if want != "direct" else "direct"), None
+    if native and transport_name == "direct":
+        fallback = direct_transport_precheck(P, ranks, kw, parse_grid("" if spec == "auto" else spec, world))
+        if fallback is not None:
+            print(f"[rank {rank}] direct transport not used: {fallback}", file=sys.stderr, flush=True)
+            transport_name = "rccl"
     grid_times = None
     if spec == "auto":  # time every tile grid of `world` tiles on THIS machine (real exchange included) and keep the fastest
-        grid_times = autotune_grid(P, ranks, kw)
+        grid_times = autotune_grid(P, ranks, kw, transport=transport_name)
         grid = min(grid_times, key=grid_times.get)
     else:
         grid = parse_grid(spec, world)
-    # default: the native C++ loop (RCCL issued from the library); if ANY rank fails to set it up, every rank falls back to
-    # the torch.distributed loop (same decomposition, same results).  Ranks that share a GPU (bring-up) run the native loop
-    # over the gloo transport.
-    native = os.environ.get("SOBFU_TILED_NATIVE", "1") == "1"
+    # if ANY rank fails to set the native loop up, every rank falls back to the torch.distributed loop (same decomposition, same
+    # results).  Ranks that share a GPU (bring-up) run "rccl" over the gloo transport.
     solver, transport = None, None
     if native:
         try:
-            if ranks.share and world > 1:
-                solver = NativeTiledSolver(dims, dry=(world, rank), grid=grid, **kw)
-                transport = GlooTransport()
-                solver.set_transport(transport.exchange, transport.allreduce)
-            else:
-                if world == 1 and not dist.is_initialized():  # SOBFU_FORCE_TILED=1 on one GPU: a world of one
-                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                    os.environ.setdefault("MASTER_PORT", "29533")
-                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", ranks.device))
-                solver = NativeTiledSolver(dims, grid=grid, **kw)
+            solver, transport = make_native_solver(dims, grid, ranks, kw, transport_name)
         except Exception as e:  # noqa: BLE001 -- report and agree on the fallback collectively
             print(f"[rank {rank}] native tiled loop unavailable: {e!r}", file=sys.stderr, flush=True)
         ok = ranks.min([1 if solver is not None else 0])[0]
@@ -878,7 +1026,7 @@ def bench_tiled(args, P, ranks, timed_regions):
     pnp = solver.new_local(2)
     psi = solver.identity_psi()
     tuned = None
-    if native and L.slab and transport is None and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
+    if native and L.slab and transport is None and transport_name == "rccl" and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
         tuned = solver.autotune(pg, pn_full)  # outside the timed region: this machine's best z-slab schedule
     if native:
         solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
@@ -887,7 +1035,8 @@ def bench_tiled(args, P, ranks, timed_regions):
         prof = None
         if PR > 0:  # the split of an iteration (serial schedule: pass A / exchange / pass B), outside the timed regions
             sched = getattr(solver, "schedule", 0)
-            if L.slab:
+            slab_sched = L.slab and transport_name == "rccl"
+            if slab_sched:
                 solver.set_schedule(3)  # the split is measured on the serial schedule (same results whatever the schedule)
             solver.set_profiling(1, PR * K)
             solver.get_profile(reset=True)
@@ -896,7 +1045,7 @@ def bench_tiled(args, P, ranks, timed_regions):
             torch.cuda.synchronize()
             pa, px, pb, n = solver.get_profile()
             solver.set_profiling(0)
-            if L.slab:
+            if slab_sched:
                 solver.set_schedule(sched)
             if n > 0:
                 prof = ranks.max([pa / n, px / n, pb / n]) + [n]
@@ -956,16 +1105,31 @@ def bench_tiled(args, P, ranks, timed_regions):
         diag = box.get("diag") or {"error": "timed out" if hung else box.get("error", "unknown")}
         if "error" in diag:
             print(f"[rank {rank}] tiled diagnostics: {diag['error']}", file=sys.stderr, flush=True)
+    # whether ANY rank hung is agreed over the rendezvous store, not over the (possibly wedged) communicator: every rank then
+    # takes the same exit path (no rank waits in a barrier the hung rank never reaches)
+    hung_any = hung
+    if world > 1 and native and os.environ.get("SOBFU_TILED_DIAG", "1") == "1":
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            store.set(f"sobfu_diag_hung_{rank}", "1" if hung else "0")
+            hung_any = any(store.get(f"sobfu_diag_hung_{q}") == b"1" for q in range(world))
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] could not agree on the diagnostics verdict: {e!r}", file=sys.stderr, flush=True)
+            hung_any = True
     own = tuple(L.g1[a] - L.g0[a] for a in range(3))
     what = (f"{world} z-slabs of {own[2]} planes" if L.slab else f"{grid[0]}x{grid[1]}x{grid[2]} tiles of {own[0]}x{own[1]}x{own[2]} cells")
-    return dict(diag_hung=hung, region_seconds=secs, N=X * Y * Z, ms_a=(prof[0] if prof else None), ms_b=(prof[2] if prof else None),
+    via = {"direct": "peer-mapped stores over xGMI issued by pass A's own launch (no pack / unpack, no RCCL in the loop; arrival flags "
+                     "and max-norm rows travel the same way)",
+           "rccl": "gloo (ranks share a GPU: bring-up transport)" if transport else "RCCL send/recv (packed by pass A's launch, one scatter kernel)"}
+    return dict(diag_hung=hung, diag_hung_any=hung_any, transport=(transport_name if native else "torch.distributed"),
+                transport_fallback=fallback, region_seconds=secs, N=X * Y * Z, ms_a=(prof[0] if prof else None), ms_b=(prof[2] if prof else None),
                 ms_exchange=(prof[1] if prof else None), n_prof=(prof[3] if prof else None),
                 launch_cells=max((l.g1[0] - l.g0[0]) * (l.g1[1] - l.g0[1]) * (l.g1[2] - l.g0[2]) for l in (TileLayout(dims, grid, q) for q in range(world))), last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
                 tiled_diag=diag, tiles={"grid": list(grid), "owned_cells_rank0": list(own), "halo": HALO,
                                         "messages_per_exchange_rank0": len(L.messages())},
                 parallelism=f"{what} (+{HALO}-cell halos), one nabla_U halo exchange per iteration over "
-                            + ("gloo (ranks share a GPU: bring-up transport)" if transport else "RCCL send/recv") + ", "
+                            + (via[transport_name] if native else "RCCL send/recv") + ", "
                             + ("native C++ loop" if native else "torch.distributed loop")
-                            + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ("" if L.slab else ", serial schedule")),
+                            + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ""),
                 tiled_autotune_us=({solver.SCHEDULES[k]: round(v, 2) for k, v in tuned.items()} if tuned else None)
                 if not grid_times else {"x".join(map(str, g)): round(v, 2) for g, v in grid_times.items()})

@@ -51,7 +51,7 @@ class OracleBackend:
     def _sl(box):
         return (slice(box[4], box[5]), slice(box[2], box[3]), slice(box[0], box[1]))
 
-    def pass_a(self, st, box, w_reg, prev, thr, transposed=False):
+    def pass_a(self, st, box, w_reg, prev, thr, thin=False):
         """whole-array oracle kernels, only the cells of `box` are committed (a launch of the HIP kernel produces exactly those)"""
         if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0 or self._gate(prev, thr):
             return
@@ -62,7 +62,7 @@ class OracleBackend:
         O.potential_gradient(st.pnp, st.pg, g, Lap, out, w_reg)
         st.nabla_U.numpy()[self._sl(box)] = out[self._sl(box)]
 
-    def pass_b(self, st, box, slots, taps, alpha, prev, thr, transposed=False):
+    def pass_b(self, st, box, slots, taps, alpha, prev, thr, thin=False):
         if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0 or self._gate(prev, thr):
             return
         L = st.layout

@@ -23,7 +23,7 @@ def test_exports_every_declared_symbol(lib):
     assert len(names) >= 40
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.sobfu_hip_abi_version() == 2
+    assert lib.sobfu_hip_abi_version() == 3
 
 
 def test_error_strings(lib):

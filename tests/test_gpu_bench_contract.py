@@ -65,17 +65,23 @@ def test_tile_path_line_on_one_gpu():
     assert d["tiled_diag"]["iteration_us_compute_only"] > 0 and d["tiles"]["grid"] == [1, 1, 1]
 
 
+@pytest.mark.parametrize("transport", ["direct", "rccl"])
 @pytest.mark.parametrize("n,grid", [(8, [2, 2, 2]), (4, [1, 2, 2]), (2, [1, 1, 2])])
-def test_gpus_n_strong_scaling_self_launch(n, grid):
+def test_gpus_n_strong_scaling_self_launch(n, grid, transport):
     """plain `python bench.py --gpus 8`: self-launch, the default tile grid (2 x 2 x 2 at N = 8), the native loop on every rank,
-    one REAL process per rank -- on this 1-GPU box the ranks share cuda:0 and the halo messages travel over gloo instead of
-    RCCL; every rank checks its tile against the single-GPU solve bit for bit"""
-    d = run_bench("--gpus", str(n), "--steps", "6", "--warmup", "2", "--dim", "64", "--repeats", "2", env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})
+    one REAL process per rank -- on this 1-GPU box the ranks share cuda:0.  direct: the ranks map each other's arrays with hipIpc
+    and the halo cells, arrival flags and max-norm rows travel as plain stores between the processes (in-kernel waits live);
+    rccl: the packed messages travel over gloo instead of RCCL.  Every rank checks its tile against the single-GPU solve bit for
+    bit; the line names the transport."""
+    d = run_bench("--gpus", str(n), "--steps", "6", "--warmup", "2", "--dim", "64", "--repeats", "2",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0", "SOBFU_TILED_TRANSPORT": transport})
     assert d["n_gpus"] == n and d["scaling"] == "strong" and d["tiles"]["grid"] == grid
+    assert d["transport"] == transport, d.get("transport_fallback")
     assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and "native C++ loop" in d["config"]["parallelism"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6 and "cpu_baseline" not in d
     t = d["tiled_iteration_ms"]
-    assert t["pass_a"] > 0 and t["pass_b"] > 0 and t["exchange_incl_pack_unpack_and_peer_wait"] > 0
+    a_key = "pass_a_incl_message_stores" + ("_and_peer_wait" if transport == "direct" else "")
+    assert t[a_key] > 0 and t["pass_b"] > 0 and (t["exchange_transfer_and_scatter"] > 0 or transport == "direct")
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 64 ** 3 // n * 64 and d["roofline"]["launches_timed"] == 2 * 6
 
 

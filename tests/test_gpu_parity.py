@@ -491,7 +491,7 @@ def test_tile_kernels_match_full_volume(ops, oracle, grid, compact):
         ob = L.own_box()
         z0, z1 = ob[4], ob[5]
         be.pass_a(st, ob[:4] + (z0, z0 + 2), w_reg, None, 0.0)
-        be.pass_a(st, ob[:4] + (z1 - 3, z1), w_reg, None, 0.0, transposed=True)
+        be.pass_a(st, ob[:4] + (z1 - 3, z1), w_reg, None, 0.0, thin=True)
         be.pass_a(st, ob[:4] + (z0 + 2, z1 - 3), w_reg, None, 0.0)
         nU_own = L.owned(st.nabla_U)[..., :3]
         assert torch.equal(nU_own.contiguous().view(torch.int32), L.owned_global(nU_f)[..., :3].contiguous().view(torch.int32))
@@ -499,8 +499,8 @@ def test_tile_kernels_match_full_volume(ops, oracle, grid, compact):
         slots = torch.zeros(256, dtype=torch.int32, device="cuda")
         for box, tr in L.pass_b_boxes():
             mid = (box[4] + box[5]) // 2
-            be.pass_b(st, box[:4] + (mid, box[5]), slots, S, alpha, None, 0.0, transposed=tr)
-            be.pass_b(st, box[:4] + (box[4], mid), slots, S, alpha, None, 0.0, transposed=tr)
+            be.pass_b(st, box[:4] + (mid, box[5]), slots, S, alpha, None, 0.0, thin=tr)
+            be.pass_b(st, box[:4] + (box[4], mid), slots, S, alpha, None, 0.0, thin=tr)
         be.end(st)
         torch.cuda.synchronize()
         # owned cells and the one-cell shell along each axis (cells on tile edges / corners are not part of the contract)

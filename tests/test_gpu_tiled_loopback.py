@@ -1,9 +1,10 @@
 """N ranks of the NATIVE tiled loop (sobfu_hip_tiled_iterate) on ONE GPU: communicator-less handles, one host thread per
 rank, and an in-process loopback transport (device-to-device copies between the ranks' buffers + a host max) plugged in
 through sobfu_hip_tiled_set_transport.  Everything but RCCL itself -- tile layout (z-slabs, x / y splits, 2 x 2 x 2), message
-boxes and their pack / unpack kernels, boundary / interior plane ranges, the multi-box launches with the transposed x shells,
-halo widths, ungated pass A, stream and event order -- runs exactly as on N GPUs, and the gathered result must equal the
-single-GPU solve bit for bit."""
+boxes, pass A's push boxes and the scatter kernel, boundary / interior plane ranges, the multi-box launches with the thin x / y
+shells, halo widths, ungated pass A, stream and event order -- runs exactly as on N GPUs, and the gathered result must equal the
+single-GPU solve bit for bit.  The DIRECT transport (halo cells stored straight into the neighbours' arrays, arrival flags and
+max-norm rows the same way) runs here too: the ranks' arrays live in one process, so "peer-mapped" is a plain pointer."""
 import ctypes as C
 import threading
 
@@ -117,6 +118,138 @@ def run_world(dims, grid, psi0, pg, pn, n_iters, thr, schedule=None):
     for s in solvers:
         s.close()
     return out, full
+
+
+def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1):
+    """N ranks on the DIRECT transport in one process.  stepped: one host thread drives all ranks phase by phase (pass A incl.
+    the pushes | pass B | ... | end-of-solve handshake) with the in-kernel waits off -- any number of ranks; else one thread
+    per rank runs the real loop, in-kernel waits live (few ranks: every rank's stream needs a hardware queue of its own)."""
+    import torch
+
+    from sobfu_amd import tiled
+
+    grid = as_grid(grid)
+    world = grid[0] * grid[1] * grid[2]
+    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr, dry=(world, r), grid=grid) for r in range(world)]
+    tiled.NativeTiledSolver.connect_local(solvers)
+    torch.cuda.synchronize()
+    pn_d = torch.from_numpy(pn).cuda()
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    state = []
+    for r, s in enumerate(solvers):
+        L = s.layout
+        with torch.cuda.stream(streams[r]):
+            state.append([torch.from_numpy(np.ascontiguousarray(L.take(pg))).cuda(), torch.from_numpy(np.ascontiguousarray(L.take(psi0))).cuda(), s.new_local(2)])
+    torch.cuda.synchronize()
+    out = [None] * world
+    for _ in range(solves):  # a second solve warm-starts from the first one's psi (sequence numbers and flags carry over)
+        if stepped:
+            for s in solvers:
+                s.set_wait(False)
+            for r, s in enumerate(solvers):
+                with torch.cuda.stream(streams[r]):
+                    s.begin(state[r][0], pn_d, state[r][2], state[r][1], n_iters)
+            torch.cuda.synchronize()
+            for phase in [p for _ in range(n_iters) for p in (0, 1)] + [2]:
+                for r, s in enumerate(solvers):
+                    with torch.cuda.stream(streams[r]):
+                        s.step_phase(phase)
+                torch.cuda.synchronize()
+            for r, s in enumerate(solvers):
+                with torch.cuda.stream(streams[r]):
+                    out[r] = s.end()
+        else:
+            errs = []
+
+            def rank_main(r):
+                try:
+                    with torch.cuda.stream(streams[r]):
+                        out[r] = solvers[r].iterate(state[r][0], pn_d, state[r][2], state[r][1], n_iters)
+                except Exception as e:  # noqa: BLE001
+                    errs.append((r, repr(e)))
+
+            th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(timeout=180)
+            assert not errs, errs
+        torch.cuda.synchronize()
+        assert all(s.status()[0] for s in solvers)
+    res = [(out[r][0], out[r][1], solvers[r].layout.owned(state[r][1]).cpu().numpy(), solvers[r].layout.owned(state[r][2]).cpu().numpy()) for r in range(world)]
+    full = (assemble(solvers, [o[2] for o in res]), assemble(solvers, [o[3] for o in res]))
+    for s in solvers:
+        s.close()
+    return res, full
+
+
+@pytest.mark.parametrize("dims,grid,stepped", [((40, 24, 36), (2, 2, 2), True), ((64, 64, 64), (2, 2, 2), True), ((33, 17, 16), (1, 2, 2), True),
+                                                ((40, 24, 36), (1, 1, 3), True), ((70, 33, 23), (2, 1, 1), True), ((141, 19, 17), (2, 1, 2), True),
+                                                ((36, 36, 36), (3, 3, 3), True), ((8, 9, 10), (2, 2, 2), True),
+                                                # in-kernel waits live: one thread per rank, the real loop
+                                                ((40, 24, 36), (1, 1, 2), False), ((70, 33, 23), (2, 1, 1), False), ((40, 24, 36), (1, 2, 1), False)])
+def test_native_loop_direct_transport(dims, grid, stepped):
+    """The direct transport against the single-GPU solve, bit for bit: psi, phi_n o psi, the GLOBAL max-norm history (made global
+    by stores into the peers' rows, no collective), dead / live / firing thresholds, and a warm-started second solve."""
+    import torch
+
+    import oracle
+    from sobfu_amd import ops
+
+    rng = np.random.default_rng(5)
+    X, Y, Z = dims
+    pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    psi0 = oracle.new_field(dims)
+    oracle.init_identity(psi0)
+    psi0[..., :3] += rng.uniform(-0.7, 0.7, psi0[..., :3].shape).astype(np.float32)
+    n_iters = 6
+
+    def single(thr, solves):
+        sv = ops.Solver(dims, max_iter=n_iters, alpha=0.05, w_reg=0.4, max_update_norm=thr)
+        psi, pnp = torch.from_numpy(psi0.copy()).cuda(), ops.new_volume(dims)
+        for _ in range(solves):
+            rep, hist = sv.iterate(torch.from_numpy(pg).cuda(), torch.from_numpy(pn).cuda(), pnp, psi, n_iters)
+        sv.close()
+        return rep.iterations, np.asarray(hist[:rep.iterations], np.float32), psi.cpu().numpy(), pnp.cpu().numpy()
+
+    _, hist_dead, _, _ = single(-1.0, 1)
+    for thr, solves in ((-1.0, 1), (1e-10, 2), (float(hist_dead[2]), 1)):
+        done_e, hist_e, psi_e, pnp_e = single(thr, solves)
+        out, (psi_t, pnp_t) = run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves)
+        for done, hist, _, _ in out:
+            assert done == done_e
+            assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), hist_e.view(np.uint32))
+        assert np.array_equal(psi_t[..., :3].view(np.uint32), psi_e[..., :3].view(np.uint32))
+        assert np.array_equal(pnp_t.view(np.uint32), pnp_e.view(np.uint32))
+
+
+def test_direct_transport_deadline():
+    """A peer that never shows up: the wait in pass A's tail gives up at the deadline, records WHOM it missed, the handle reports
+    SOBFU_E_TIMEOUT -- and the GPU is never hung."""
+    import os
+
+    import torch
+
+    from sobfu_amd import tiled
+
+    os.environ["SOBFU_TILED_DEADLINE_S"] = "0.5"
+    try:
+        dims, grid = (40, 24, 36), (1, 1, 2)
+        solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(2, r), grid=grid) for r in range(2)]
+    finally:
+        os.environ.pop("SOBFU_TILED_DEADLINE_S")
+    tiled.NativeTiledSolver.connect_local(solvers)
+    s = solvers[0]  # rank 1 never runs
+    pg, pn = s.new_local(2), torch.zeros((36, 24, 40, 2), device="cuda")
+    pnp, psi = s.new_local(2), s.identity_psi()
+    with pytest.raises(RuntimeError, match="deadline"):
+        s.iterate(pg, pn, pnp, psi, 3)
+    ok, missing = s.status()
+    assert not ok and missing == 1
+    torch.cuda.synchronize()
+    for q in solvers:
+        q.close()
 
 
 @pytest.mark.parametrize("dims,world,split", [((40, 24, 36), 3, None), ((40, 24, 36), 3, "1"), ((33, 17, 16), 4, None), ((20, 12, 120), 2, None),
