@@ -28,7 +28,7 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
 // the tail of tile_potential_gradient_kernel).
 constexpr int kMaxSync = 64;
 struct TileSync {
-    uint32_t ticket_push, ticket_all;  // 0 at rest
+    uint32_t ticket_push, reserved;    // 0 at rest
     uint32_t err;                      // 0, or 1 + the rank whose flag did not arrive before the deadline
     uint32_t n_sync;                   // ranks this rank signals and waits for
     uint32_t my_rank, world;

@@ -588,11 +588,11 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 //       pack kernel, no unpack kernel and, with the direct transport, no communication launch at all.  They are numbered
 //       first, so they leave while the owned block is still being computed.
 //   the owned block (marching), stored locally.
-// Synchronisation of the direct transport, in the kernel's tail (TileSync): every workgroup that pushed fences at system
-// scope and takes a ticket; the LAST of them writes this rank's arrival flag (= the iteration's sequence number) at every
-// rank of the sync set (release, system scope).  The last workgroup of the WHOLE launch then waits until the flags of all
-// those ranks have reached the sequence number (with a deadline), so that when the launch retires every halo cell of this
-// iteration has landed and pass B -- a separate launch, whose start invalidates the caches -- reads it.  nabla_U is
+// Synchronisation of the direct transport, in the kernel's tail (TileSync): every workgroup that pushed waits for its stores'
+// acknowledgements and takes a ticket; the LAST of them writes this rank's arrival flag (= the iteration's sequence number) at
+// every rank of the sync set, then waits until the flags of all those ranks have reached the sequence number (with a
+// deadline): a launch retires when all its workgroups have, so when this one does every halo cell of the iteration has landed
+// and pass B -- a separate launch, whose start invalidates the caches -- reads it.  nabla_U is
 // double-buffered by iteration parity, which orders a neighbour's stores of iteration k+1 behind this rank's reads of
 // iteration k without a second handshake (see tiled_capi.hip).
 constexpr int kMaxTileBoxes = 20;  // 18 messages + the owned block + one spare
@@ -619,6 +619,23 @@ struct TilePassAArgs {
     uint32_t row_index;      // ... which is row `row_index` of the global rows
 };
 
+// ---- stores that leave the GPU ----------------------------------------------------------------------------------------------
+// What travels to a peer (message cells, row maxima, flags) is stored WRITE-THROUGH at system scope (sc0 sc1): it never sits
+// dirty in this GPU's write-back L2, so "everything I sent has arrived" is `s_waitcnt vmcnt(0)` -- the stores' acknowledgements --
+// and not the L2 write-back a system-scope release fence would do (pass A is filling that L2 with nabla_U at the time: one such
+// fence per push workgroup cost 4x the whole iteration).  The flag goes out after the wait, so it cannot overtake the data.
+SOBFU_DEV void st3_system(float* p, const float4& v) {
+    const v3f o = {v.x, v.y, v.z};
+    asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(p), "v"(o) : "memory");
+}
+SOBFU_DEV void st1_system(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+SOBFU_DEV uint32_t ld1_system(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+SOBFU_DEV void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // wave 0 of one workgroup: the maximum of this rank's slot row -> entry `my_rank` of that row at every rank of the sync set (and
 // here); the next signal covers these stores
 SOBFU_DEV void tile_row_push(const TileSync* sy, const uint32_t* row, uint32_t row_index) {
@@ -628,23 +645,24 @@ SOBFU_DEV void tile_row_push(const TileSync* sy, const uint32_t* row, uint32_t r
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t) __shfl_xor((int) m, o, 64));
     const size_t e = (size_t) row_index * 256u + sy->my_rank;
     if (l == 0) sy->my_grows[e] = m;
-    for (int q = l; q < (int) sy->n_sync; q += 64) __hip_atomic_store(sy->peer_grows[q] + e, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int q = l; q < (int) sy->n_sync; q += 64) st1_system(sy->peer_grows[q] + e, m);
 }
-// one lane: raise this rank's arrival flag at every rank of the sync set (everything stored before is released system-wide)
+// one lane: raise this rank's arrival flag at every rank of the sync set (after stores_acknowledged() on everything it covers)
 SOBFU_DEV void tile_signal(const TileSync* sy, uint32_t seq) {
-    for (uint32_t q = 0; q < sy->n_sync; ++q) __hip_atomic_store(sy->peer_flags[q] + sy->my_rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (uint32_t q = 0; q < sy->n_sync; ++q) st1_system(sy->peer_flags[q] + sy->my_rank, seq);
 }
 // one lane: wait until every rank of the sync set has raised its flag to `seq` -- with a deadline: a missing peer is recorded
-// (err = 1 + its rank) and every later wait returns at once, so a wedged neighbour never hangs this GPU
+// (err = 1 + its rank) and every later wait returns at once, so a wedged neighbour never hangs this GPU.  The cells the flags
+// announce are read by the NEXT launch (whose start invalidates the caches), never by this one.
 SOBFU_DEV void tile_wait(TileSync* sy, uint32_t seq) {
     if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const uint64_t t0 = wall_clock64();
     for (uint32_t q = 0; q < sy->n_sync; ++q) {
         const uint32_t* f = sy->my_flags + sy->sync_rank[q];
-        while ((int32_t) (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            __builtin_amdgcn_s_sleep(8);
+        while ((int32_t) (ld1_system(f) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > sy->timeout_ticks) {
-                __hip_atomic_store(&sy->err, 1u + (uint32_t) sy->sync_rank[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&sy->err, 1u + (uint32_t) sy->sync_rank[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
         }
@@ -652,7 +670,7 @@ SOBFU_DEV void tile_wait(TileSync* sy, uint32_t seq) {
 }
 __global__ void __launch_bounds__(64) tile_flush_kernel(TileSync* sy, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index) {
     if (row != nullptr) tile_row_push(sy, row, row_index);
-    __threadfence_system();
+    stores_acknowledged();
     if (threadIdx.x != 0) return;
     tile_signal(sy, seq);
     if (wait) tile_wait(sy, seq);
@@ -686,7 +704,7 @@ __global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePas
             const float4 o = pass_a_direct_cell<COMPACT>(a.c, x, y, z);
             if (pd.base != nullptr) {
                 const size_t i = (size_t) (x + pd.ox) + (size_t) pd.px * ((size_t) (y + pd.oy) + (size_t) pd.py * (size_t) (z + pd.oz));
-                stv<true>(pd.base, i, o);  // messages are always 12-byte cells
+                st3_system(pd.base + 3 * i, o);  // messages are always 12-byte cells
             } else {
                 stv<COMPACT>(a.c.nU, vidx(a.c.d, x, y, z), o);
             }
@@ -697,21 +715,18 @@ __global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePas
         for (int k = 0; k < 8; ++k) gate.v[k] = 0xffffffffu;  // pass A of a tile writes scratch only: never gated
         pass_a_march<RPT, WY, COMPACT>(a.c, geom_in_box(b, t, first, a.c.d, RPT * WY), gate);
     }
-    if (a.sync == nullptr) return;
+    if (a.sync == nullptr || !push_wg) return;
+    // the push workgroups count themselves out; the LAST one raises this rank's flag at its peers and then waits for theirs: a
+    // launch retires when all its workgroups have, so pass B cannot start before every neighbour's cells have landed -- while the
+    // owned block's workgroups never touch the synchronisation at all
     TileSync* sy = a.sync;
-    if (push_wg) __threadfence_system();  // every lane: its stores to the peers are visible system-wide ...
-    __syncthreads();                      // ... before lane 0 takes the workgroup's ticket
+    stores_acknowledged();  // every lane: what it stored at the peers has arrived ...
+    __syncthreads();        // ... before lane 0 takes the workgroup's ticket
     if (tid != 0) return;
-    if (push_wg) {
-        const uint32_t k = __hip_atomic_fetch_add(&sy->ticket_push, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == (uint32_t) L.n_push_wgs - 1u) {  // the last push workgroup: everything this rank sends has left
-            __hip_atomic_store(&sy->ticket_push, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tile_signal(sy, a.seq);
-        }
-    }
-    const uint32_t k2 = __hip_atomic_fetch_add(&sy->ticket_all, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (k2 == nb - 1u) {  // the last workgroup of the launch
-        __hip_atomic_store(&sy->ticket_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k = __hip_atomic_fetch_add(&sy->ticket_push, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == (uint32_t) L.n_push_wgs - 1u) {
+        __hip_atomic_store(&sy->ticket_push, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tile_signal(sy, a.seq);
         if (a.wait) tile_wait(sy, a.seq);
     }
 }

@@ -781,6 +781,9 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
     const int ax0 = t->o0[0], ax1 = t->o1[0], ay0 = t->o0[1], ay1 = t->o1[1];
     const int own[6] = {ax0, ax1, ay0, ay1, lo, hi};
     const bool tiles = tile_path(t), sync = uses_sync(t);
+    // timing experiments only (results are wrong): bit 0 no push boxes, bit 1 no thin shells, bit 2 no pass A, bit 3 no pass B
+    const char* dbg_e = std::getenv("SOBFU_TILED_DEBUG_SKIP");
+    const int dbg = dbg_e ? std::atoi(dbg_e) : 0;
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
     // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
     // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N >= 4 at 256^3, if a face takes the ~65 us that ~60 GB/s per xGMI direction implies)
@@ -853,7 +856,8 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
             if (phases & 1) {
                 if (ev) SOBFU_HIP_TRY(hipEventRecord(e[0], st));
                 const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[it & 1];
-                const bool pushes = multi || sync;  // a world of one has no messages
+                const bool pushes = (multi || sync) && !(dbg & 1);  // a world of one has no messages
+                if (!(dbg & 4))
                 SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, pushes ? bx.data() : &bx.back(),
                                                         pushes ? (int) bx.size() : 1, sync ? t->sync_d : nullptr, q.seq_base + (uint32_t) it,
                                                         t->wait_enabled, (sync && it >= 2) ? t->slots + (size_t) (it - 1) * kSlots : nullptr,
@@ -864,7 +868,7 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
             if (phases & 2) {
                 SOBFU_TRY(wait_gate());
                 if (ev) SOBFU_HIP_TRY(hipEventRecord(e[2], st));
-                SOBFU_TRY(B(b_first, b_last, 0, 0, true));
+                if (!(dbg & 8)) SOBFU_TRY(B(b_first, b_last, 0, 0, !(dbg & 2)));
                 if (ev) {
                     SOBFU_HIP_TRY(hipEventRecord(e[3], st));
                     t->prof_pending += 1;

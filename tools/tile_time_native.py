@@ -27,8 +27,8 @@ for g in grids.split(","):
     world = grid[0] * grid[1] * grid[2]
     lays = [tiled.TileLayout(dims, grid, q) for q in range(world)]
     rank = max(range(world), key=lambda q: (lays[q].L[0] * lays[q].L[1] * lays[q].L[2], q))  # a tile with the most halos
-    for thr in (-1.0, 1e-10):
-        for mode in ("direct", "packed"):
+    for thr in [float(v) for v in os.environ.get("TILE_THR", "-1,1e-10").split(",")]:
+        for mode in os.environ.get("TILE_MODES", "direct,packed").split(","):
             os.environ["SOBFU_TILED_DRY_PACKED"] = "1" if mode == "packed" else "0"
             for sched in ((3,) if (mode == "direct" or not lays[rank].slab) else (0, 3)):
                 sv = tiled.NativeTiledSolver(dims, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=thr, dry=(world, rank), grid=grid)
