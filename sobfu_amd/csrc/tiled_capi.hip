@@ -250,7 +250,8 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
             v.push_back(b);
         }
         sobfu_hip::TileLaunchBox own{};
-        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], false};
+        const char* ad = std::getenv("SOBFU_TILE_A_DIRECT");  // experiment: the owned block lane per cell too
+        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], ad && ad[0] == '1'};
         v.push_back(own);
     }
 }
@@ -782,6 +783,8 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
     const int own[6] = {ax0, ax1, ay0, ay1, lo, hi};
     const bool tiles = tile_path(t), sync = uses_sync(t);
     // timing experiments only (results are wrong): bit 0 no push boxes, bit 1 no thin shells, bit 2 no pass A, bit 3 no pass B
+    const char* bd_e = std::getenv("SOBFU_TILE_B_DIRECT");  // experiment: pass B's owned block lane per cell too
+    const bool b_direct = bd_e && bd_e[0] == '1';
     const char* dbg_e = std::getenv("SOBFU_TILED_DEBUG_SKIP");
     const int dbg = dbg_e ? std::atoi(dbg_e) : 0;
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
@@ -814,7 +817,7 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
         };
         auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0, bool shells = false) {
             // the owned block with its z shells (extra planes of the march); the one-cell x / y shells are direct boxes
-            const sobfu_hip::LaunchBox bx[6] = {{ax0, ax1, ay0, ay1, za, zb, false}, {ax0, ax1, ay0, ay1, za2, zb2, false},
+            const sobfu_hip::LaunchBox bx[6] = {{ax0, ax1, ay0, ay1, za, zb, b_direct}, {ax0, ax1, ay0, ay1, za2, zb2, b_direct},
                                                 {ax0, ax1, ay0 - 1, (shells && t->lo[1]) ? ay0 : ay0 - 1, lo, hi, true},
                                                 {ax0, ax1, ay1, (shells && t->hi[1]) ? ay1 + 1 : ay1, lo, hi, true},
                                                 {ax0 - 1, (shells && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},

@@ -749,14 +749,38 @@ def test_native_tiled_loop_comm_choreography_on_one_rank(ops, oracle, monkeypatc
 # picked when a z-chunk has >= 24 planes -- forced here with the tuning override, on grids the oracle finishes in seconds,
 # including chunk lengths that leave a short last chunk and a chunk that is the whole volume
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pipe", ["0", "1"])
 @pytest.mark.parametrize("dims,zc", [((70, 33, 80), 24), ((70, 33, 80), 31), ((40, 24, 96), 96), ((65, 9, 50), 27)])
-def test_long_march_variant_on_small_grids(ops, oracle, dims, zc, monkeypatch):
+def test_long_march_variant_on_small_grids(ops, oracle, dims, zc, pipe, monkeypatch):
+    """the instantiations big grids run (halo lead, streaming hints; plain and software-pipelined march), forced onto small ones"""
     monkeypatch.setenv("SOBFU_ZC_B", str(zc))
+    monkeypatch.setenv("SOBFU_CACHE_CELLS", "0")  # "does not fit the Infinity Cache"
+    monkeypatch.setenv("SOBFU_PIPE_B", pipe)
     pg, pn = rand_volume(dims, 91), rand_volume(dims, 92)
     psi = warped_identity(oracle, dims, 93, 0.9)
     r = oracle.estimate_psi(pg, pn, psi, max_iter=4, alpha=0.05, w_reg=0.4, inverse_iters=0, compute_jacobian=False)
     sv = ops.Solver(dims, max_iter=4, alpha=0.05, w_reg=0.4)
     psi_d, pnp_d = dev(warped_identity(oracle, dims, 93, 0.9)), ops.new_volume(dims)
+    _, hist = sv.iterate(dev(pg), dev(pn), pnp_d, psi_d, 4)
+    assert nmis(host(psi_d), psi) == 0
+    assert nmis(host(pnp_d), r["phi_n_psi"]) == 0
+    assert same(hist, r["trace"][:, 2])
+    sv.close()
+
+
+@pytest.mark.parametrize("pipe", ["0", "1"])
+@pytest.mark.parametrize("cache_cells", ["0", "1000000000"])
+@pytest.mark.parametrize("dims", [(70, 33, 19), (40, 24, 20), (65, 9, 2), (130, 37, 41)])
+def test_march_variants_agree_with_oracle(ops, oracle, dims, cache_cells, pipe, monkeypatch):
+    """every (streaming hints, pipelined march) instantiation of the compact solver format against the oracle: psi, phi_n o psi and
+    the max-norm history bit for bit (the pipelined march issues the phi_n gather one plane early and consumes it one plane late)"""
+    monkeypatch.setenv("SOBFU_CACHE_CELLS", cache_cells)
+    monkeypatch.setenv("SOBFU_PIPE_B", pipe)
+    pg, pn = rand_volume(dims, 191), rand_volume(dims, 192)
+    psi = warped_identity(oracle, dims, 193, 1.1)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=4, alpha=0.05, w_reg=0.4, inverse_iters=0, compute_jacobian=False)
+    sv = ops.Solver(dims, max_iter=4, alpha=0.05, w_reg=0.4)
+    psi_d, pnp_d = dev(warped_identity(oracle, dims, 193, 1.1)), ops.new_volume(dims)
     _, hist = sv.iterate(dev(pg), dev(pn), pnp_d, psi_d, 4)
     assert nmis(host(psi_d), psi) == 0
     assert nmis(host(pnp_d), r["phi_n_psi"]) == 0
