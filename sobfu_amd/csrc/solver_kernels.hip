@@ -214,6 +214,30 @@ SOBFU_DEV float interp_tsdf_only32(const float* __restrict__ v, const Dims& d, f
     return lerp1(lerp1(lerp1(hhh, hhg, c.t), lerp1(hgh, hgg, c.t), b.t), lerp1(lerp1(ghh, ghg, c.t), lerp1(ggh, ggg, c.t), b.t), a.t);
 }
 
+// interp_tsdf_only32 in two halves, for the software-pipelined pass B: the eight corner loads are ISSUED when a plane's psi is
+// known and CONSUMED one plane later (the gather's round trip then overlaps the next plane's barrier and taps instead of ending
+// every plane's dependent chain).  Same loads, same lerp chain, same bits.
+struct Gather8 {
+    float c[8];  // hhh, hhg, hgh, hgg, ghh, ghg, ggh, ggg
+    float ta, tb, tc;
+};
+SOBFU_DEV Gather8 gather_issue32(const float* __restrict__ v, const Dims& d, float px, float py, float pz) {
+    const Tri a = tri_setup(px, d.x), b = tri_setup(py, d.y), c = tri_setup(pz, d.z);
+    const uint32_t sy = 4u * (uint32_t) d.x, sz = sy * (uint32_t) d.y;
+    const uint32_t o  = 4u * (uint32_t) a.g + sy * (uint32_t) b.g + sz * (uint32_t) c.g;
+    const uint32_t ox = a.h != a.g ? 4u : 0u, oy = b.h != b.g ? sy : 0u, oz = c.h != c.g ? sz : 0u;
+    const char* base = (const char*) v;
+    auto at = [&](uint32_t off) { return *(const float*) (base + (size_t) off); };
+    Gather8 g;
+    g.c[0] = at(o + ox + oy + oz); g.c[1] = at(o + ox + oy); g.c[2] = at(o + ox + oz); g.c[3] = at(o + ox);
+    g.c[4] = at(o + oy + oz); g.c[5] = at(o + oy); g.c[6] = at(o + oz); g.c[7] = at(o);
+    g.ta = a.t; g.tb = b.t; g.tc = c.t;
+    return g;
+}
+SOBFU_DEV float gather_finish(const Gather8& g) {
+    return lerp1(lerp1(lerp1(g.c[0], g.c[1], g.tc), lerp1(g.c[2], g.c[3], g.tc), g.tb), lerp1(lerp1(g.c[4], g.c[5], g.tc), lerp1(g.c[6], g.c[7], g.tc), g.tb), g.ta);
+}
+
 // --- workgroup -> tile map ---------------------------------------------------------------------------------------
 // A launch produces up to kMaxBoxes BOXES of cells of the (local) array: the whole volume on a single GPU; on a multi-GPU
 // tile, the owned cells (plus the one-cell shells pass B refreshes) or the boundary / interior regions of an overlapped
@@ -238,6 +262,7 @@ struct Box {
 };
 struct BoxList {
     int n;
+    int n_march;  // workgroups [0, n_march) belong to marching boxes (listed first), the rest to direct boxes
     Box b[kMaxBoxes];
     int first[kMaxBoxes + 1];  // first workgroup of box i; first[n] = workgroups in the launch
 };
@@ -779,6 +804,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef SOBFU_MINW_B
 #define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
 #endif
+#ifndef SOBFU_MINW_PIPE
+#define SOBFU_MINW_PIPE 4  // the pipelined march: <= 128 VGPR -> 2 workgroups of 8 waves per CU
+#endif
 // HL: planes the halo requests run ahead of the plane they are staged for (0: one plane ahead, straight from registers -- short
 // marches, where the extra prologue round trip costs more than the re-fetched halo lines).
 // max ||u||^2 over the voxels a workgroup owns -> one atomicMax on one of 256 slots
@@ -842,9 +870,146 @@ SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
     return owned ? norm_sq4(uu) : 0.f;
 }
 
+// The SOFTWARE-PIPELINED march of pass B (compact solver format, one row per lane).  In the plain march a plane's dependent
+// chain ends in a memory round trip nothing hides when few workgroups share a CU (multi-GPU tiles, small grids: fewer workgroups
+// than the chip has slots for): the eight phi_n corners are gathered at the coordinates the psi update has just produced, and the
+// step waits for them.  Here the gather of plane z-1 is ISSUED AT THE TOP of step z, together with the step's other requests
+// (psi(z), nabla_U plane z+4, the halo of plane z+1), and everything is awaited once, behind the barrier and the 63 taps:
+//     requests | barrier | taps of plane z (LDS + the 7 register planes) | -- await --
+//     fold the corners into phi_n o psi(z-1), psi(z) -= alpha * t, store both, shift the z pipeline, stage plane z+1 (centre +
+//     halo) into the OTHER LDS buffer.
+// No request is in flight across the loop's back edge (the compiler would wait for all of them there anyway, to copy the
+// loop-carried registers), one barrier per plane as before (a wave writes buffer b^1 only behind the barrier that followed the
+// last reads of b^1).  Same arithmetic, same bits.
+template <int WY, int NTL>
+SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const GateRegs& gate, float4 (*tile)[WY + 6][TX + 8], uint32_t* s_max) {
+    constexpr int R = 3, TY = WY;
+    constexpr int NXH = (2 * R * TY + TX - 1) / TX, NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
+    constexpr uint32_t VB = 12u, TB = 4u;
+    const Dims d = a.d;
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
+    const int u = u0 + lx, uc = min(u, tg.DU - 1), v = v0 + wy;
+    const size_t plane = (size_t) d.x * d.y, sv = (size_t) d.x;
+    const uint32_t cell = (uint32_t) ((size_t) uc + sv * (size_t) min(v, tg.DV - 1));
+    const uint32_t off = cell * VB, offT = cell * TB;
+    const bool mine = u < tg.u_hi && v < tg.v_hi;
+    const bool owned = u >= a.own[0] && u < a.own[1] && v >= a.own[2] && v < a.own[3];
+    int h_lr[TPW], h_lc[TPW];
+    uint32_t h_off[TPW];
+    bool h_on[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int task = wy + k * WY;
+        h_on[k] = task < NTASK;
+        int lr = 0, lc = 0;
+        if (task < R) { lr = task; lc = lx + R; }
+        else if (task < 2 * R) { lr = TY + task; lc = lx + R; }
+        else {
+            const int e = (task - 2 * R) * TX + lx;
+            h_on[k] = h_on[k] && e < 2 * R * TY;
+            const int row = e / (2 * R), c = e % (2 * R);
+            lr = R + row;
+            lc = c < R ? c : TX + c;
+        }
+        h_lr[k] = lr;
+        h_lc[k] = lc;
+        const int gu = min(max(u0 - R + lc, 0), tg.DU - 1), gv = min(max(v0 - R + lr, 0), tg.DV - 1);
+        h_off[k] = (uint32_t) ((size_t) gu + (size_t) gv * sv) * VB;
+    }
+    auto nU_plane = [&](int z) { return (const char*) a.nU + (size_t) min(max(z, 0), d.z - 1) * plane * VB; };
+    // prologue: planes zb-3 .. zb+3 and the halo of plane zb, staged at once
+    float4 q[7], hq[TPW];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q[k] = ldvb<true>(nU_plane(zb - 3 + k), off);
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+        if (h_on[k]) hq[k] = ldvb<true>(nU_plane(zb), h_off[k]);
+    if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
+    tile[0][wy + R][lx + R] = q[3];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+        if (h_on[k]) tile[0][h_lr[k]][h_lc[k]] = hq[k];
+    float4 p_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    float msq = 0.f;
+    for (int z = zb; z < ze; ++z) {
+        const int buf = (z - zb) & 1;
+        const size_t zcur = (size_t) z * plane;
+        // this step's requests
+        const float4 pv = ldvb<true>((const char*) a.psi + zcur * VB, off, NTL >= 2);
+        float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (z + 1 < ze) {
+            qn = ldvb<true>(nU_plane(z + 4), off);
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (h_on[k]) hq[k] = ldvb<true>(nU_plane(z + 1), h_off[k]);
+        }
+        Gather8 g;
+        if (mine && z > zb) g = gather_issue32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
+        __syncthreads();
+        // the taps of plane z: x and y from the LDS tile, z from the register planes (sum = 0; ascending j; products not contracted)
+        v2f l01 = {0.f, 0.f}, l23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, z01 = {0.f, 0.f}, z23 = {0.f, 0.f};
+#pragma unroll
+        for (int j = -R; j <= R; ++j) {
+            const v2f s2 = {a.S.s[R - j], a.S.s[R - j]};
+            const float4 vl = (j == 0) ? q[3] : tile[buf][wy + R][lx + R + j];
+            l01 += v2f{vl.x, vl.y} * s2;
+            l23 += v2f{vl.z, vl.w} * s2;
+            const float4 vr = (j == 0) ? q[3] : tile[buf][wy + R + j][lx + R];
+            r01 += v2f{vr.x, vr.y} * s2;
+            r23 += v2f{vr.z, vr.w} * s2;
+            const float4 vz = q[3 + j];
+            z01 += v2f{vz.x, vz.y} * s2;
+            z23 += v2f{vz.z, vz.w} * s2;
+        }
+        const v2f t01 = (l01 + r01) + z01;
+        const float tx = t01.x, ty = t01.y, tz = (l23.x + r23.x) + z23.x;
+        // update_psi_kernel (solver.cu:64-67)
+        const float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
+        float4 p = pv;
+        p.x -= uu.x;
+        p.y -= uu.y;
+        p.z -= uu.z;
+        pin3<2>(p);
+        if (mine) {
+            if (owned && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
+            if (z > zb) {  // apply_kernel (vector_fields.cu:95-98) of the plane before
+                float* fo = (float*) ((char*) a.pnp + (zcur - plane) * TB + (size_t) offT);
+                const float f = gather_finish(g);
+                if (NTL >= 1) __builtin_nontemporal_store(f, fo);
+                else *fo = f;
+            }
+            stvb<true>((char*) a.psi_out + zcur * VB, off, p, NTL >= 1);
+        }
+        p_prev = p;
+        // shift the z pipeline (plain register moves: see the plain march) and stage plane z+1 into the other buffer
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            q[k] = q[k + 1];
+            asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z));
+        }
+        q[6] = qn;
+        if (z + 1 < ze) {
+            tile[buf ^ 1][wy + R][lx + R] = q[3];
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (h_on[k]) tile[buf ^ 1][h_lr[k]][h_lc[k]] = hq[k];
+        }
+    }
+    if (ze > zb && mine) {  // the last plane's warp
+        float* fo = (float*) ((char*) a.pnp + (size_t) (ze - 1) * plane * TB + (size_t) offT);
+        const float f = interp_tsdf_only32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
+        if (NTL >= 1) __builtin_nontemporal_store(f, fo);
+        else *fo = f;
+    }
+    maxnorm_tail<WY>(msq, a.slots, s_max);
+}
+
 // DIRECT_OK: the launch may hold direct boxes (multi-GPU tiles)
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0>
-__global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
+// NTL: streaming hints (see pass_a_march).  PIPE: the software-pipelined march (pass_b_march_pipe).
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0, int NTL = SOBFU_NT, bool PIPE = false>
+__global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
+    static_assert(!PIPE || (RPT == 1 && COMPACT && IDX32 && !WRITE_UPDATES && HL == 0), "the pipelined march exists for the compact solver format");
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
     static_assert(HL == 0 || HL >= 2, "the halo-lead FIFO needs a lead of >= 2 planes (a lead of 1 is the register path, HL = 0)");
     constexpr int NXH = (2 * R * TY + TX - 1) / TX;  // row-tasks for the 2R lane-halo columns
@@ -857,7 +1022,10 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
-    const unsigned wg = SOBFU_SWIZZLE_B ? xcd_swizzle(blockIdx.x, (unsigned) a.boxes.first[a.boxes.n]) : blockIdx.x;
+    // marching workgroups are XCD-swizzled among themselves; direct ones (numbered behind them) keep the dispatch order, which
+    // spreads them over all XCDs -- a thin box concentrated on one XCD's 32 CUs is bound by their address units
+    const unsigned wg = (SOBFU_SWIZZLE_B && (!DIRECT_OK || (int) blockIdx.x < a.boxes.n_march))
+                            ? xcd_swizzle(blockIdx.x, (unsigned) (DIRECT_OK ? a.boxes.n_march : a.boxes.first[a.boxes.n])) : blockIdx.x;
     int first_wg;
     const Box box = find_box(a.boxes, wg, first_wg);
     if (DIRECT_OK && box.kind != 0) {  // a thin box: one lane per cell
@@ -869,6 +1037,10 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         return;
     }
     const TileGeom tg = geom_in_box(box, wg, first_wg, d, TY);
+    if constexpr (PIPE) {
+        pass_b_march_pipe<WY, NTL>(a, tg, gate, tile, s_max);
+        return;
+    }
     const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
     const int u = u0 + lx, uc = min(u, tg.DU - 1);
     const size_t plane = (size_t) d.x * d.y, sv = (size_t) d.x;
@@ -984,7 +1156,7 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
         const size_t zcur = (size_t) z * plane;
         float4 pv[RPT], nq[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) pv[r] = ldvb<COMPACT>((const char*) a.psi + zcur * VB, off[r], SOBFU_NT >= 2);
+        for (int r = 0; r < RPT; ++r) pv[r] = ldvb<COMPACT>((const char*) a.psi + zcur * VB, off[r], NTL >= 2);
         if (z + 1 < ze) {
             const char* nU4 = (const char*) a.nU + (size_t) min(z + 4, d.z - 1) * plane * VB;
 #pragma unroll
@@ -1069,14 +1241,14 @@ __global__ void __launch_bounds__(TX* WY, SOBFU_MINW_B) fused_smooth_update_appl
             if (mine[r]) {
                 if (owned[r] && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
                 // inside the box no clamp was active: off[r] is the cell itself
-                stvb<COMPACT>((char*) a.psi_out + zcur * VB, off[r], p, SOBFU_NT >= 1);
+                stvb<COMPACT>((char*) a.psi_out + zcur * VB, off[r], p, NTL >= 1);
                 if (WRITE_UPDATES) *(float4*) ((char*) a.updates + zcur * 16 + (size_t) (offT[r] / TB * 16u)) = uu;
                 // apply_kernel (vector_fields.cu:95-98)
                 if (COMPACT) {
                     const float f = IDX32 ? interp_tsdf_only32((const float*) a.phi_n, a.pd, p.x, p.y, p.z)
                                           : interp_tsdf_only((const float*) a.phi_n, a.pd, p.x, p.y, p.z);
                     float* fo = (float*) ((char*) a.pnp + zcur * TB + (size_t) offT[r]);
-                    if (SOBFU_NT >= 1) __builtin_nontemporal_store(f, fo);
+                    if (NTL >= 1) __builtin_nontemporal_store(f, fo);
                     else *fo = f;
                 }
                 else *(float2*) ((char*) a.pnp + zcur * TB + (size_t) offT[r]) = interp_tsdf((const float2*) a.phi_n, a.pd, p.x, p.y, p.z);
@@ -1248,19 +1420,23 @@ static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill,
     return ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty) * ((nz + b.zc - 1) / b.zc);
 }
 // Fills the launch geometry of a box list: z-chunk per marching box (cost model above, the chip's capacity shared between the
-// marching boxes; direct boxes are one short round trip and take no share) and the workgroup prefix.  Returns the workgroups.
+// marching boxes; direct boxes are one short round trip and take no share) and the workgroup prefix -- marching boxes first.
+// Returns the workgroups.
 static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env) {
     L.n = 0;
     int live = 0;
     for (int i = 0; i < n; ++i) live += (box_cells(boxes[i]) > 0 && !boxes[i].direct) ? 1 : 0;
     int total = 0;
-    for (int i = 0; i < n && L.n < kMaxBoxes; ++i) {
-        if (box_cells(boxes[i]) == 0) continue;
-        // the chip's workgroup slots are shared equally between the marching boxes (the two plane ranges of an overlapped slab
-        // schedule): a thin range is latency-critical, so it gets as many short marches as the big one gets long ones
-        L.first[L.n] = total;
-        total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env);
-        ++L.n;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < n && L.n < kMaxBoxes; ++i) {
+            if (box_cells(boxes[i]) == 0 || boxes[i].direct != (pass == 1)) continue;
+            // the chip's workgroup slots are shared equally between the marching boxes (the two plane ranges of an overlapped slab
+            // schedule): a thin range is latency-critical, so it gets as many short marches as the big one gets long ones
+            L.first[L.n] = total;
+            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env);
+            ++L.n;
+        }
+        if (pass == 0) L.n_march = total;
     }
     for (int k = L.n; k <= kMaxBoxes; ++k) L.first[k] = total;
     return total;
@@ -1332,18 +1508,35 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
                 {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 3 * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B");  // <= 80 VGPR (launch bounds), 48 KB LDS: 3 workgroups of 8 waves per CU
+    const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
+    // the solver's own format (compact, 32-bit gather offsets, no `updates`): streaming hints only for grids beyond the Infinity
+    // Cache; the pipelined march where the launch is latency-bound (cache-resident sizes; SOBFU_PIPE_B=0/1 overrides)
+    const bool resident = cache_resident(X, Y, Z);
+    const char* pipe_e = getenv("SOBFU_PIPE_B");
+    const bool pipe = compact && idx32 && !updates && (pipe_e ? atoi(pipe_e) != 0 : resident);
+    // workgroups a CU holds: <= 80 VGPR (launch bounds) and 32 - 48 KB LDS: 3 of 8 waves; the pipelined march (<= 128 VGPR): 2
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B");
     if (groups == 0) return 0;
     bool direct = false;
-    for (int i = 0; i < a.boxes.n; ++i) direct = direct || a.boxes.b[i].kind != 0;
+    int zc_max = 0;
+    for (int i = 0; i < a.boxes.n; ++i) {
+        direct = direct || a.boxes.b[i].kind != 0;
+        if (a.boxes.b[i].kind == 0) zc_max = std::max(zc_max, a.boxes.b[i].zc);
+    }
     const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
 #define SOBFU_LAUNCH_B(UPD, CMP, DIR) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, DIR>), grid, block, 0, stream, a)
-    const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
+#define SOBFU_LAUNCH_BX(DIR, HLV, NTV, PIP) \
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, 0, stream, a)
     if (direct) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);
-        else if (compact && idx32) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, true, true, 0>), grid, block, 0, stream, a);
+        else if (compact && idx32) {
+            if (resident && pipe) SOBFU_LAUNCH_BX(true, 0, 0, true);
+            else if (resident) SOBFU_LAUNCH_BX(true, 0, 0, false);
+            else if (pipe) SOBFU_LAUNCH_BX(true, 0, SOBFU_NT, true);
+            else SOBFU_LAUNCH_BX(true, 0, SOBFU_NT, false);
+        }
         else if (compact) SOBFU_LAUNCH_B(false, true, true);
         else SOBFU_LAUNCH_B(false, false, true);
     } else {
@@ -1352,15 +1545,17 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
         else if (compact && idx32) {
             // long marches (big grids): halo requests run SOBFU_HLEAD planes ahead; short ones (small grids, multi-GPU tiles) skip
             // the extra prologue round trip
-            int zc_max = 0;
-            for (int i = 0; i < a.boxes.n; ++i) zc_max = std::max(zc_max, a.boxes.b[i].zc);
-            if (SOBFU_HLEAD > 0 && zc_max >= SOBFU_HLEAD_MIN_ZC)
-                hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, SOBFU_HLEAD>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, 0>), grid, block, 0, stream, a);
+            const bool lead = SOBFU_HLEAD > 0 && zc_max >= SOBFU_HLEAD_MIN_ZC && !resident && !pipe;
+            if (lead) SOBFU_LAUNCH_BX(false, SOBFU_HLEAD, SOBFU_NT, false);
+            else if (resident && pipe) SOBFU_LAUNCH_BX(false, 0, 0, true);
+            else if (resident) SOBFU_LAUNCH_BX(false, 0, 0, false);
+            else if (pipe) SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, true);
+            else SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, false);
         }
         else if (compact) SOBFU_LAUNCH_B(false, true, false);
         else SOBFU_LAUNCH_B(false, false, false);
     }
+#undef SOBFU_LAUNCH_BX
 #undef SOBFU_LAUNCH_B
     return (int) hipGetLastError();
 }
