@@ -259,6 +259,7 @@ struct Box {
     int x0, x1, y0, y1, z0, z1;  // cells [x0, x1) x [y0, y1) x [z0, z1)
     int zc;                      // marching: planes per march (z-chunk); direct: wx, the lanes of a wave that run along x
     int kind;                    // 0 marching, 1 direct
+    int wpg;                     // direct: waves of a workgroup that take cells (the others leave at once) -- see direct_wpg()
 };
 struct BoxList {
     int n;
@@ -294,7 +295,9 @@ SOBFU_DEV TileGeom geom_in_box(const Box& b, unsigned t, int first, const Dims& 
 SOBFU_DEV bool direct_cell(const Box& b, unsigned t, int first, int& x, int& y, int& z) {
     const int wx = b.zc, wyl = 64 / wx;
     const unsigned ntx = (unsigned) ((b.x1 - b.x0 + wx - 1) / wx), nty = (unsigned) ((b.y1 - b.y0 + wyl - 1) / wyl);
-    const unsigned w = (t - (unsigned) first) * (unsigned) blockDim.y + (unsigned) __builtin_amdgcn_readfirstlane((int) threadIdx.y);  // wave of the box
+    const unsigned wv = (unsigned) __builtin_amdgcn_readfirstlane((int) threadIdx.y);
+    if (wv >= (unsigned) b.wpg) return false;
+    const unsigned w = (t - (unsigned) first) * (unsigned) b.wpg + wv;  // wave of the box
     const int lane = threadIdx.x;
     x = b.x0 + (int) (w % ntx) * wx + (lane & (wx - 1));
     y = b.y0 + (int) ((w / ntx) % nty) * wyl + lane / wx;
@@ -1399,10 +1402,15 @@ static int direct_wx(int ex) {
     while (wx < ex && wx < 64) wx *= 2;
     return wx;
 }
+// A wave of a box that is thin in x touches up to 64 / wx cache lines with EVERY load (its lanes sit in different rows), and the
+// address unit of a CU takes them one line per cycle: eight such waves in one workgroup -- on one CU -- queue up behind each
+// other (the one-column x shell of a 2 x 2 x 2 tile: 13.9 us as 32 full workgroups).  Such boxes get few working waves per
+// workgroup, i.e. many small workgroups that the dispatcher spreads over all CUs.
+static int direct_wpg(int wx) { return std::max(1, std::min(SOBFU_WY, wx / 4)); }
 static int direct_groups(const LaunchBox& s, int wx) {
-    const int wyl = 64 / wx;
+    const int wyl = 64 / wx, wpg = direct_wpg(wx);
     const long waves = (long) ((s.x1 - s.x0 + wx - 1) / wx) * ((s.y1 - s.y0 + wyl - 1) / wyl) * (s.z1 - s.z0);
-    return (int) ((waves + SOBFU_WY - 1) / SOBFU_WY);
+    return (int) ((waves + wpg - 1) / wpg);
 }
 static double box_cells(const LaunchBox& s) {
     return (s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0) ? (double) (s.x1 - s.x0) * (s.y1 - s.y0) * (s.z1 - s.z0) : 0.0;
@@ -1411,8 +1419,10 @@ static double box_cells(const LaunchBox& s) {
 static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env) {
     b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
     b.kind = s.direct ? 1 : 0;
+    b.wpg = SOBFU_WY;
     if (s.direct) {
-        b.zc = direct_wx(s.x1 - s.x0);
+        b.zc  = direct_wx(s.x1 - s.x0);
+        b.wpg = direct_wpg(b.zc);
         return direct_groups(s, b.zc);
     }
     const int eu = s.x1 - s.x0, ev = s.y1 - s.y0, nz = s.z1 - s.z0;

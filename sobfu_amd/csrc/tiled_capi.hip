@@ -782,7 +782,8 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
     const int ax0 = t->o0[0], ax1 = t->o1[0], ay0 = t->o0[1], ay1 = t->o1[1];
     const int own[6] = {ax0, ax1, ay0, ay1, lo, hi};
     const bool tiles = tile_path(t), sync = uses_sync(t);
-    // timing experiments only (results are wrong): bit 0 no push boxes, bit 1 no thin shells, bit 2 no pass A, bit 3 no pass B
+    // timing experiments only (results are wrong): bit 0 no push boxes, bit 1 no thin shells, bit 2 no pass A, bit 3 no pass B,
+    // bit 4 no owned block in pass B, bit 5 no y shells, bit 6 no x shells
     const char* bd_e = std::getenv("SOBFU_TILE_B_DIRECT");  // experiment: pass B's owned block lane per cell too
     const bool b_direct = bd_e && bd_e[0] == '1';
     const char* dbg_e = std::getenv("SOBFU_TILED_DEBUG_SKIP");
@@ -817,11 +818,12 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
         };
         auto B = [&](int za, int zb, int za2 = 0, int zb2 = 0, bool shells = false) {
             // the owned block with its z shells (extra planes of the march); the one-cell x / y shells are direct boxes
-            const sobfu_hip::LaunchBox bx[6] = {{ax0, ax1, ay0, ay1, za, zb, b_direct}, {ax0, ax1, ay0, ay1, za2, zb2, b_direct},
-                                                {ax0, ax1, ay0 - 1, (shells && t->lo[1]) ? ay0 : ay0 - 1, lo, hi, true},
-                                                {ax0, ax1, ay1, (shells && t->hi[1]) ? ay1 + 1 : ay1, lo, hi, true},
-                                                {ax0 - 1, (shells && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
-                                                {ax1, (shells && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
+            const bool ysh = shells && !(dbg & 32), xsh = shells && !(dbg & 64);
+            const sobfu_hip::LaunchBox bx[6] = {{ax0, ax1, ay0, ay1, za, (dbg & 16) ? za : zb, b_direct}, {ax0, ax1, ay0, ay1, za2, zb2, b_direct},
+                                                {ax0, ax1, ay0 - 1, (ysh && t->lo[1]) ? ay0 : ay0 - 1, lo, hi, true},
+                                                {ax0, ax1, ay1, (ysh && t->hi[1]) ? ay1 + 1 : ay1, lo, hi, true},
+                                                {ax0 - 1, (xsh && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
+                                                {ax1, (xsh && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
             return sobfu_hip::launch_pass_b_boxes(nu, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y,
                                                   Z, own, bx, 6, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
         };

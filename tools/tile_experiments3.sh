@@ -22,3 +22,8 @@ b SOBFU_PIPE_B=1
 done
 b SOBFU_PIPE_B=1 SOBFU_ZC_B=64
 b SOBFU_PIPE_B=1 SOBFU_ZC_B=32
+V=$PWD/build/variants/libsobfu_hip_1x8xSOBFU_MINW_PIPE=6.so
+run TILE_GRIDS=2x2x2 SOBFU_PIPE_B=1 SOBFU_HIP_LIB=$V
+b SOBFU_PIPE_B=1 SOBFU_HIP_LIB=$V
+b SOBFU_PIPE_B=1 SOBFU_HIP_LIB=$V
+b SOBFU_PIPE_B=0 SOBFU_HIP_LIB=$V
