@@ -1406,9 +1406,11 @@ static int direct_wx(int ex) {
 // address unit of a CU takes them one line per cycle: eight such waves in one workgroup -- on one CU -- queue up behind each
 // other (the one-column x shell of a 2 x 2 x 2 tile: 13.9 us as 32 full workgroups).  Such boxes get few working waves per
 // workgroup, i.e. many small workgroups that the dispatcher spreads over all CUs.
-static int direct_wpg(int wx) { return std::max(1, std::min(SOBFU_WY, wx / 4)); }
-static int direct_groups(const LaunchBox& s, int wx) {
-    const int wyl = 64 / wx, wpg = direct_wpg(wx);
+// Only where the launch leaves the chip room (pass B of a tile: fewer workgroups than slots) -- in pass A, whose march fills every
+// slot, a thousand one-wave workgroups in front of it cost more than they save (`spread` = false: full workgroups).
+static int direct_wpg(int wx, bool spread) { return spread ? std::max(1, std::min(SOBFU_WY, wx / 4)) : SOBFU_WY; }
+static int direct_groups(const LaunchBox& s, int wx, bool spread) {
+    const int wyl = 64 / wx, wpg = direct_wpg(wx, spread);
     const long waves = (long) ((s.x1 - s.x0 + wx - 1) / wx) * ((s.y1 - s.y0 + wyl - 1) / wyl) * (s.z1 - s.z0);
     return (int) ((waves + wpg - 1) / wpg);
 }
@@ -1416,14 +1418,14 @@ static double box_cells(const LaunchBox& s) {
     return (s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0) ? (double) (s.x1 - s.x0) * (s.y1 - s.y0) * (s.z1 - s.z0) : 0.0;
 }
 // geometry of one live box; returns its workgroups
-static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env) {
+static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env, bool spread) {
     b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
     b.kind = s.direct ? 1 : 0;
     b.wpg = SOBFU_WY;
     if (s.direct) {
         b.zc  = direct_wx(s.x1 - s.x0);
-        b.wpg = direct_wpg(b.zc);
-        return direct_groups(s, b.zc);
+        b.wpg = direct_wpg(b.zc, spread);
+        return direct_groups(s, b.zc, spread);
     }
     const int eu = s.x1 - s.x0, ev = s.y1 - s.y0, nz = s.z1 - s.z0;
     b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, share, refill, env);
@@ -1443,7 +1445,7 @@ static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int c
             // the chip's workgroup slots are shared equally between the marching boxes (the two plane ranges of an overlapped slab
             // schedule): a thin range is latency-critical, so it gets as many short marches as the big one gets long ones
             L.first[L.n] = total;
-            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env);
+            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env, true);
             ++L.n;
         }
         if (pass == 0) L.n_march = total;
@@ -1489,7 +1491,7 @@ int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, floa
             if (L.n >= kMaxTileBoxes || (s.dst != nullptr && !s.box.direct)) return SOBFU_E_BADARG;
             TileBox& t = L.b[L.n];
             L.first[L.n] = total;
-            total += finish_box(t.b, s.box, TY, std::max(256 * 4 * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc, "SOBFU_ZC_A");
+            total += finish_box(t.b, s.box, TY, std::max(256 * 4 * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc, "SOBFU_ZC_A", false);
             t.push = PushDst{s.dst, s.ox, s.oy, s.oz, s.px, s.py};
             ++L.n;
         }
