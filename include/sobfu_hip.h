@@ -363,16 +363,18 @@ int sobfu_hip_tiled_set_transport(sobfu_hip_tiled* t, sobfu_hip_tiled_exchange_f
                                   void* ctx);
 /* DIRECT transport (communicator-less handles): the halo cells travel as plain stores from pass A's launch into the neighbours'
  * own nabla_U arrays, peer-mapped over xGMI -- no pack / unpack kernels, no communication launch, no collective in the loop; arrival
- * flags and the max-norm rows travel the same way (see sobfu_amd/csrc/tiled_capi.hip).  Every rank exports four device
+ * flags and the max-norm rows travel the same way (see sobfu_amd/csrc/tiled_capi.hip).  Every rank exports two device
  * allocations (sobfu_hip_tiled_exports_get; across processes: sobfu_hip_ipc_export -> 64-byte handles -> sobfu_hip_ipc_open on the
  * other side), hands the pointers of ALL other ranks -- valid in ITS process -- to sobfu_hip_tiled_connect, and every rank must have
  * connected (a barrier of the caller's) before any begins a solve.  A peer whose flag does not arrive within
  * SOBFU_TILED_DEADLINE_S (default 30 s) is recorded instead of waited for: _end / _status return SOBFU_E_TIMEOUT. */
 #define SOBFU_E_TIMEOUT (-5) /* a peer did not answer within the deadline; the handle is dead (destroy it) */
 typedef struct {
-    void* nabla_u[2]; /* the two halves of the double-buffered nabla_U tile (12-byte cells, local extents) */
-    void* flags;      /* arrival flags, one uint32 per rank */
-    void* rows;       /* global max-norm rows, 256 uint32 per iteration */
+    void* arena;           /* ONE allocation (what crosses the process boundary): the two halves of the double-buffered nabla_U tile
+                              (12-byte cells, local extents) and the global max-norm rows (256 uint32 per iteration) ... */
+    size_t nabla_u_off[2]; /* ... at these byte offsets */
+    size_t rows_off;
+    void* flags;           /* a second allocation: arrival flags, one uint32 per rank (uncached) */
 } sobfu_hip_tiled_exports;
 int sobfu_hip_tiled_exports_get(const sobfu_hip_tiled* t, sobfu_hip_tiled_exports* out);
 int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ranks, const sobfu_hip_tiled_exports* peers);

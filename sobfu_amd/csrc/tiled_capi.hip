@@ -193,7 +193,12 @@ struct sobfu_hip_tiled {
     bool direct = false, dead = false, first_checked = false, dry_packed = false;
     int wait_enabled = 1;
     sobfu_hip::TileSync* sync_d = nullptr;
-    uint32_t *flags = nullptr, *grows = nullptr;  // arrival flags [kMaxSync] (uncached), global max-norm rows [(slots_iters + 1) x 256]
+    // what the peers map (direct transport): ONE arena [nabla_U half 0 | half 1 | global max-norm rows ((slots_iters + 2) x 256)] -- a
+    // big allocation of its own, which hipIpcGetMemHandle always accepts (small ones may be carved out of a shared block and are
+    // refused now and then) -- and the arrival flags [kMaxSync], uncached, padded to a block of their own for the same reason
+    char* arena = nullptr;
+    size_t arena_bytes = 0, nu_off[2] = {0, 0}, rows_off = 0;
+    uint32_t *flags = nullptr, *grows = nullptr, *grows_own = nullptr;  // grows_own: a larger private copy once a solve outgrew the arena's
     uint32_t seq_total = 0;                        // sequence numbers used so far (every rank counts the same)
     uint64_t timeout_ticks = 0;                    // deadline of the in-kernel waits (100 MHz ticks; SOBFU_TILED_DEADLINE_S at create)
     std::vector<sobfu_hip::TileLaunchBox> a_boxes[2];  // pass A's boxes per nabla_U half: one push box per message + the owned block
@@ -309,10 +314,11 @@ int sobfu_hip_tiled_unique_id(char out[128]) {
 
 int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (!t) return 0;
-    for (float* q : {t->nUb[0], t->nUb[1], t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
+    for (float* q : {t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
         if (q) (void) hipFree(q);
+    if (t->arena) (void) hipFree(t->arena);
     if (t->slots) (void) hipFree(t->slots);
-    if (t->grows) (void) hipFree(t->grows);
+    if (t->grows_own) (void) hipFree(t->grows_own);
     if (t->flags) (void) hipFree(t->flags);
     if (t->sync_d) (void) hipFree(t->sync_d);
     for (hipEvent_t e : t->prof_ev) (void) hipEventDestroy(e);
@@ -376,32 +382,42 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
             if (rc == 0) rc = (int) hipMalloc((void**) &t->recvbuf, off * sizeof(float));
         }
     }
-    if (rc == 0) rc = (int) hipMalloc((void**) &t->nUb[0], t->NL * 12);
-    if (rc == 0) rc = (int) hipMalloc((void**) &t->nUb[1], t->NL * 12);
+    if (rc == 0) {
+        auto up = [](size_t v) { return (v + 4095) & ~(size_t) 4095; };
+        t->nu_off[0] = 0;
+        t->nu_off[1] = up(t->NL * 12);
+        t->rows_off  = t->nu_off[1] + up(t->NL * 12);
+        t->arena_bytes = std::max(t->rows_off + up((size_t) (4096 + 2) * kSlots * 4), (size_t) 4 << 20);
+        rc = (int) hipMalloc((void**) &t->arena, t->arena_bytes);
+        if (rc == 0) {
+            t->nUb[0] = (float*) (t->arena + t->nu_off[0]);
+            t->nUb[1] = (float*) (t->arena + t->nu_off[1]);
+            t->grows  = (uint32_t*) (t->arena + t->rows_off);
+            // halo cells no message fills (tile corners) stay finite; rows start at "converged nowhere" = 0 (blocking: the loop's
+            // streams do not order against the null stream)
+            rc = (int) hipMemset(t->arena, 0, t->arena_bytes);
+        }
+    }
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_psi2, t->NL * 12);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
-    // halo cells no message fills (tile corners) stay finite (blocking: the loop's streams do not order against the null stream)
-    if (rc == 0) rc = (int) hipMemset(t->nUb[0], 0, t->NL * 12);
-    if (rc == 0) rc = (int) hipMemset(t->nUb[1], 0, t->NL * 12);
     if (rc == 0) {  // max-norm slot rows for 4096 iterations up front: a solve never reallocates inside a timed region
         rc = (int) hipMalloc((void**) &t->slots, (size_t) (4096 + 1) * kSlots * 4);
-        if (rc == 0) rc = (int) hipMalloc((void**) &t->grows, (size_t) (4096 + 2) * kSlots * 4);
-        if (rc == 0) rc = (int) hipMemset(t->grows, 0, (size_t) (4096 + 2) * kSlots * 4);
         if (rc == 0) t->slots_iters = 4096;
     }
     if (rc == 0) {
         // arrival flags: written by the peers over xGMI, polled here -- uncached memory, so that neither side's L2 sits between
         // a store and the poll (plain device memory if the runtime refuses)
-        if (hipExtMallocWithFlags((void**) &t->flags, kMaxSync * sizeof(uint32_t), hipDeviceMallocUncached) != hipSuccess) {
+        constexpr size_t kFlagBlock = (size_t) 2 << 20;
+        if (hipExtMallocWithFlags((void**) &t->flags, kFlagBlock, hipDeviceMallocUncached) != hipSuccess) {
             (void) hipGetLastError();
             t->flags = nullptr;
-            rc = (int) hipMalloc((void**) &t->flags, kMaxSync * sizeof(uint32_t));
+            rc = (int) hipMalloc((void**) &t->flags, kFlagBlock);
         }
-        if (rc == 0) rc = (int) hipMemset(t->flags, 0, kMaxSync * sizeof(uint32_t));
+        if (rc == 0) rc = (int) hipMemset(t->flags, 0, kFlagBlock);
     }
     if (rc == 0) rc = (int) hipMalloc((void**) &t->sync_d, sizeof(sobfu_hip::TileSync));
     if (rc == 0) {
@@ -435,6 +451,10 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
             rc = SOBFU_E_RCCL;
         }
     }
+    // hipMemset / hipMemcpy on device memory may return before they have run.  The arrays cleared above are about to be mapped and
+    // written by OTHER processes, which no stream of this one orders against: a clear that ran late would wipe a peer's first
+    // arrival flag (seen: one hang in ~10 start-ups with four ranks sharing a GPU) -- drain the device before anybody can see them.
+    if (rc == 0) rc = (int) hipDeviceSynchronize();
     if (rc != 0) {
         sobfu_hip_tiled_destroy(t);
         return rc;
@@ -472,7 +492,8 @@ int sobfu_hip_ipc_close(void* d_ptr) {
 
 int sobfu_hip_tiled_exports_get(const sobfu_hip_tiled* t, sobfu_hip_tiled_exports* out) {
     SOBFU_CHECK_ARGS(t && out);
-    out->nabla_u[0] = t->nUb[0]; out->nabla_u[1] = t->nUb[1]; out->flags = t->flags; out->rows = t->grows;
+    out->arena = t->arena; out->nabla_u_off[0] = t->nu_off[0]; out->nabla_u_off[1] = t->nu_off[1]; out->rows_off = t->rows_off;
+    out->flags = t->flags;
     return 0;
 }
 
@@ -490,9 +511,9 @@ int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ran
     std::vector<TileLay> pl;
     for (size_t i = 0; i < t->geom.size(); ++i) {
         const sobfu_hip_tiled_exports* e = find(t->geom[i].peer);
-        if (!e || !e->nabla_u[0] || !e->nabla_u[1] || !e->flags) return SOBFU_E_BADARG;
-        d0[i] = (float*) e->nabla_u[0];
-        d1[i] = (float*) e->nabla_u[1];
+        if (!e || !e->arena || !e->flags) return SOBFU_E_BADARG;
+        d0[i] = (float*) ((char*) e->arena + e->nabla_u_off[0]);
+        d1[i] = (float*) ((char*) e->arena + e->nabla_u_off[1]);
         pl.push_back(make_layout(dims, t->P, t->geom[i].peer));
     }
     // sync set: EVERY other rank -- the halo neighbours for the nabla_U cells, the rest because the max-norm rows become global by
@@ -504,13 +525,14 @@ int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ran
     for (int r = 0; r < t->world; ++r) {
         if (r == t->rank) continue;
         const sobfu_hip_tiled_exports* e = find(r);
-        if (!e || !e->flags || !e->rows) return SOBFU_E_BADARG;
+        if (!e || !e->flags || !e->arena) return SOBFU_E_BADARG;
         sy.sync_rank[sy.n_sync]  = r;
         sy.peer_flags[sy.n_sync] = (uint32_t*) e->flags;
-        sy.peer_grows[sy.n_sync] = (uint32_t*) e->rows;
+        sy.peer_grows[sy.n_sync] = (uint32_t*) ((char*) e->arena + e->rows_off);
         sy.n_sync += 1;
     }
     SOBFU_HIP_TRY(hipMemcpy(t->sync_d, &sy, sizeof sy, hipMemcpyHostToDevice));
+    SOBFU_HIP_TRY(hipDeviceSynchronize());
     build_a_boxes(t, d0.data(), d1.data(), pl.data());
     t->direct = true;
     return 0;
@@ -712,12 +734,13 @@ static int tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, cons
     if (max_iters > t->slots_iters) {
         if (t->direct) return SOBFU_E_UNSUPPORTED;  // the global rows are mapped by the peers: their size is fixed (4096 iterations per solve)
         if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
-        if (t->grows) SOBFU_HIP_TRY(hipFree(t->grows));
-        t->slots = t->grows = nullptr;
+        if (t->grows_own) SOBFU_HIP_TRY(hipFree(t->grows_own));
+        t->slots = t->grows_own = nullptr;
         t->slots_iters = 0;
         SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (max_iters + 1) * kSlots * 4));
-        SOBFU_HIP_TRY(hipMalloc((void**) &t->grows, (size_t) (max_iters + 2) * kSlots * 4));
-        SOBFU_HIP_TRY(hipMemset(t->grows, 0, (size_t) (max_iters + 2) * kSlots * 4));
+        SOBFU_HIP_TRY(hipMalloc((void**) &t->grows_own, (size_t) (max_iters + 2) * kSlots * 4));
+        SOBFU_HIP_TRY(hipMemset(t->grows_own, 0, (size_t) (max_iters + 2) * kSlots * 4));
+        t->grows = t->grows_own;
         SOBFU_HIP_TRY(hipMemcpy(&t->sync_d->my_grows, &t->grows, sizeof(uint32_t*), hipMemcpyHostToDevice));
         t->slots_iters = max_iters;
     }

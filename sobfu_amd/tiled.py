@@ -516,7 +516,7 @@ class TiledMsg(C.Structure):
 
 class TiledExports(C.Structure):
     """sobfu_hip_tiled_exports"""
-    _fields_ = [("nabla_u", C.c_void_p * 2), ("flags", C.c_void_p), ("rows", C.c_void_p)]
+    _fields_ = [("arena", C.c_void_p), ("nabla_u_off", C.c_size_t * 2), ("rows_off", C.c_size_t), ("flags", C.c_void_p)]
 
 
 class NativeTiledSolver:
@@ -621,34 +621,50 @@ class NativeTiledSolver:
             s.connect(others, [ex[q] for q in others])
 
     def connect_ipc(self):
-        """one process per rank: every rank exports its four arrays as 64-byte hipIpc handles, all ranks gather them over
+        """one process per rank: every rank exports its two allocations as 64-byte hipIpc handles, all ranks gather them over
         torch.distributed (any backend) and map the others' arrays; a barrier, so that nobody begins a solve before every rank
-        is connected (and has cleared its halo cells)"""
+        is connected (and has cleared its halo cells).  Every step is agreed on collectively: a rank that fails reports it in the
+        NEXT gather, so the ranks never sit in different collectives -- all of them raise."""
         lib, check = self._lib.lib(), self._lib.check
-        e = self.exports()
-        mine = []
-        for ptr in (e.nabla_u[0], e.nabla_u[1], e.flags, e.rows):
-            h = (C.c_char * 64)()
-            check(lib.sobfu_hip_ipc_export(C.c_void_p(ptr), h), "ipc_export")
-            mine.append(bytes(h))
+        mine, err = [], None
+        try:
+            e = self.exports()
+            for what, ptr in (("arena", e.arena), ("flags", e.flags)):
+                h = (C.c_char * 64)()
+                check(lib.sobfu_hip_ipc_export(C.c_void_p(ptr), h), f"ipc_export({what})")
+                mine.append(bytes(h))
+            mine.append((e.nabla_u_off[0], e.nabla_u_off[1], e.rows_off))
+        except Exception as ex:  # noqa: BLE001
+            err = f"rank {self.rank}: export: {ex!r}"
         allh = [None] * self.world
-        dist.all_gather_object(allh, mine, group=self.group)
-        ranks, exps = [], []
-        for q in range(self.world):
-            if q == self.rank:
-                continue
-            ptrs = []
-            for hb in allh[q]:
-                out = C.c_void_p()
-                check(lib.sobfu_hip_ipc_open((C.c_char * 64).from_buffer_copy(hb), C.byref(out)), "ipc_open")
-                ptrs.append(out.value)
-                self._opened.append(out.value)
-            x = TiledExports()
-            x.nabla_u[0], x.nabla_u[1], x.flags, x.rows = ptrs
-            ranks.append(q)
-            exps.append(x)
-        self.connect(ranks, exps)
-        dist.barrier(group=self.group)
+        dist.all_gather_object(allh, (mine, err), group=self.group)
+        errs = [a[1] for a in allh if a[1]]
+        if not errs:
+            try:
+                ranks, exps = [], []
+                for q in range(self.world):
+                    if q == self.rank:
+                        continue
+                    ptrs = []
+                    for hb in allh[q][0][:2]:
+                        out = C.c_void_p()
+                        check(lib.sobfu_hip_ipc_open((C.c_char * 64).from_buffer_copy(hb), C.byref(out)), f"ipc_open (rank {q})")
+                        ptrs.append(out.value)
+                        self._opened.append(out.value)
+                    x = TiledExports()
+                    x.arena, x.flags = ptrs
+                    x.nabla_u_off[0], x.nabla_u_off[1], x.rows_off = allh[q][0][2]
+                    ranks.append(q)
+                    exps.append(x)
+                self.connect(ranks, exps)
+            except Exception as ex:  # noqa: BLE001
+                err = f"rank {self.rank}: map: {ex!r}"
+            st = [None] * self.world
+            dist.all_gather_object(st, err, group=self.group)  # doubles as the barrier
+            errs = [a for a in st if a]
+        if errs:
+            print(f"[rank {self.rank}] direct transport: {errs}", file=sys.stderr, flush=True)
+            raise RuntimeError("direct transport: peer mapping failed: " + "; ".join(errs))
 
     def status(self):
         """(ok, missing_peer): whether every peer has answered within the deadline so far"""

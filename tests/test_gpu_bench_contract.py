@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run_bench(*args, env=None):
     e = dict(os.environ, **(env or {}))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-12000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0]  # exactly one JSON line, and it is the last line
     return json.loads(lines[0])
