@@ -79,6 +79,10 @@ struct Rccl {
 constexpr int kHalo = 4, kSlots = 256;
 constexpr int kSplitAMaxPlanes = 64;  // owned planes up to which pass A is split into boundary + interior launches
 constexpr int kMaxSync = sobfu_hip::kMaxSync;
+// The runtime carves allocations of up to GPU_MAX_SUBALLOC_SIZE (4 MiB by default) out of shared blocks, and hipIpcGetMemHandle
+// refuses a pointer that is not the base of its block ("invalid argument", one start-up in ~10 on small test grids): whatever
+// is exported to other processes is allocated at least this large, i.e. as a block of its own.
+constexpr size_t kOwnBlock = (size_t) 8 << 20;
 
 #define RCCL_TRY(expr)                                                                          \
     do {                                                                                        \
@@ -193,9 +197,8 @@ struct sobfu_hip_tiled {
     bool direct = false, dead = false, first_checked = false, dry_packed = false;
     int wait_enabled = 1;
     sobfu_hip::TileSync* sync_d = nullptr;
-    // what the peers map (direct transport): ONE arena [nabla_U half 0 | half 1 | global max-norm rows ((slots_iters + 2) x 256)] -- a
-    // big allocation of its own, which hipIpcGetMemHandle always accepts (small ones may be carved out of a shared block and are
-    // refused now and then) -- and the arrival flags [kMaxSync], uncached, padded to a block of their own for the same reason
+    // what the peers map (direct transport): ONE arena [nabla_U half 0 | half 1 | global max-norm rows ((slots_iters + 2) x 256)] and
+    // the arrival flags [kMaxSync], uncached -- both padded to kOwnBlock so that hipIpcGetMemHandle accepts them
     char* arena = nullptr;
     size_t arena_bytes = 0, nu_off[2] = {0, 0}, rows_off = 0;
     uint32_t *flags = nullptr, *grows = nullptr, *grows_own = nullptr;  // grows_own: a larger private copy once a solve outgrew the arena's
@@ -387,7 +390,7 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
         t->nu_off[0] = 0;
         t->nu_off[1] = up(t->NL * 12);
         t->rows_off  = t->nu_off[1] + up(t->NL * 12);
-        t->arena_bytes = std::max(t->rows_off + up((size_t) (4096 + 2) * kSlots * 4), (size_t) 4 << 20);
+        t->arena_bytes = std::max(t->rows_off + up((size_t) (4096 + 2) * kSlots * 4), kOwnBlock);
         rc = (int) hipMalloc((void**) &t->arena, t->arena_bytes);
         if (rc == 0) {
             t->nUb[0] = (float*) (t->arena + t->nu_off[0]);
@@ -411,7 +414,7 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     if (rc == 0) {
         // arrival flags: written by the peers over xGMI, polled here -- uncached memory, so that neither side's L2 sits between
         // a store and the poll (plain device memory if the runtime refuses)
-        constexpr size_t kFlagBlock = (size_t) 2 << 20;
+        constexpr size_t kFlagBlock = kOwnBlock;
         if (hipExtMallocWithFlags((void**) &t->flags, kFlagBlock, hipDeviceMallocUncached) != hipSuccess) {
             (void) hipGetLastError();
             t->flags = nullptr;
