@@ -84,6 +84,44 @@ constexpr int kMaxSync = sobfu_hip::kMaxSync;
 // is exported to other processes is allocated at least this large, i.e. as a block of its own.
 constexpr size_t kOwnBlock = (size_t) 8 << 20;
 
+// Blocks that other processes map are never handed back to the runtime while the process lives: they are parked and reused by
+// the next handle.  A block that has been exported keeps its 64-byte handle -- and the mappings the peers hold -- for good;
+// exporting memory again after a free / re-allocation at the same address is what hipIpcGetMemHandle refused now and then
+// when a process built several handles in a row (tile-grid autotuning).  One block per size class and kind in practice.
+struct PooledBlock {
+    void* ptr;
+    size_t bytes;
+    bool uncached, in_use;
+};
+std::vector<PooledBlock> g_pool;
+int pool_take(void** out, size_t bytes, bool uncached) {
+    for (PooledBlock& b : g_pool)
+        if (!b.in_use && b.uncached == uncached && b.bytes >= bytes) {
+            b.in_use = true;
+            *out     = b.ptr;
+            return 0;
+        }
+    void* p = nullptr;
+    bool unc = uncached;
+    if (uncached && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void) hipGetLastError();
+        p   = nullptr;
+        unc = false;  // plain device memory if the runtime refuses (the flags are polled with system-scope loads either way)
+    }
+    if (!p) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return (int) e;
+    }
+    (void) unc;
+    g_pool.push_back(PooledBlock{p, bytes, uncached, true});
+    *out = p;
+    return 0;
+}
+void pool_give_back(void* p) {
+    for (PooledBlock& b : g_pool)
+        if (b.ptr == p) b.in_use = false;
+}
+
 #define RCCL_TRY(expr)                                                                          \
     do {                                                                                        \
         ncclResult_t _r = (expr);                                                               \
@@ -319,10 +357,10 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (!t) return 0;
     for (float* q : {t->c_psi, t->c_psi2, t->c_f, t->c_f2, t->c_g, t->c_n})
         if (q) (void) hipFree(q);
-    if (t->arena) (void) hipFree(t->arena);
+    if (t->arena) pool_give_back(t->arena);
     if (t->slots) (void) hipFree(t->slots);
     if (t->grows_own) (void) hipFree(t->grows_own);
-    if (t->flags) (void) hipFree(t->flags);
+    if (t->flags) pool_give_back(t->flags);
     if (t->sync_d) (void) hipFree(t->sync_d);
     for (hipEvent_t e : t->prof_ev) (void) hipEventDestroy(e);
     if (t->sendbuf) (void) hipFree(t->sendbuf);
@@ -391,7 +429,7 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
         t->nu_off[1] = up(t->NL * 12);
         t->rows_off  = t->nu_off[1] + up(t->NL * 12);
         t->arena_bytes = std::max(t->rows_off + up((size_t) (4096 + 2) * kSlots * 4), kOwnBlock);
-        rc = (int) hipMalloc((void**) &t->arena, t->arena_bytes);
+        rc = pool_take((void**) &t->arena, t->arena_bytes, false);
         if (rc == 0) {
             t->nUb[0] = (float*) (t->arena + t->nu_off[0]);
             t->nUb[1] = (float*) (t->arena + t->nu_off[1]);
@@ -414,13 +452,8 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     if (rc == 0) {
         // arrival flags: written by the peers over xGMI, polled here -- uncached memory, so that neither side's L2 sits between
         // a store and the poll (plain device memory if the runtime refuses)
-        constexpr size_t kFlagBlock = kOwnBlock;
-        if (hipExtMallocWithFlags((void**) &t->flags, kFlagBlock, hipDeviceMallocUncached) != hipSuccess) {
-            (void) hipGetLastError();
-            t->flags = nullptr;
-            rc = (int) hipMalloc((void**) &t->flags, kFlagBlock);
-        }
-        if (rc == 0) rc = (int) hipMemset(t->flags, 0, kFlagBlock);
+        rc = pool_take((void**) &t->flags, kOwnBlock, true);
+        if (rc == 0) rc = (int) hipMemset(t->flags, 0, kMaxSync * sizeof(uint32_t));
     }
     if (rc == 0) rc = (int) hipMalloc((void**) &t->sync_d, sizeof(sobfu_hip::TileSync));
     if (rc == 0) {

@@ -519,6 +519,11 @@ class TiledExports(C.Structure):
     _fields_ = [("arena", C.c_void_p), ("nabla_u_off", C.c_size_t * 2), ("rows_off", C.c_size_t), ("flags", C.c_void_p)]
 
 
+# hipIpc bookkeeping of this process (direct transport): a device block is exported ONCE (the library parks and reuses the blocks
+# it has exported) and a peer's handle is opened ONCE -- the mappings live as long as the process
+_IPC_EXPORTED, _IPC_OPENED = {}, {}
+
+
 class NativeTiledSolver:
     """The same tile loop run entirely in C++ (sobfu_amd/csrc/tiled_capi.hip), no Python per iteration.  Transports:
     "direct" -- halo cells stored straight into the neighbours' arrays over xGMI from pass A's launch (peer-mapped with hipIpc;
@@ -630,9 +635,11 @@ class NativeTiledSolver:
         try:
             e = self.exports()
             for what, ptr in (("arena", e.arena), ("flags", e.flags)):
-                h = (C.c_char * 64)()
-                check(lib.sobfu_hip_ipc_export(C.c_void_p(ptr), h), f"ipc_export({what})")
-                mine.append(bytes(h))
+                if ptr not in _IPC_EXPORTED:
+                    h = (C.c_char * 64)()
+                    check(lib.sobfu_hip_ipc_export(C.c_void_p(ptr), h), f"ipc_export({what})")
+                    _IPC_EXPORTED[ptr] = bytes(h)
+                mine.append(_IPC_EXPORTED[ptr])
             mine.append((e.nabla_u_off[0], e.nabla_u_off[1], e.rows_off))
         except Exception as ex:  # noqa: BLE001
             err = f"rank {self.rank}: export: {ex!r}"
@@ -647,10 +654,11 @@ class NativeTiledSolver:
                         continue
                     ptrs = []
                     for hb in allh[q][0][:2]:
-                        out = C.c_void_p()
-                        check(lib.sobfu_hip_ipc_open((C.c_char * 64).from_buffer_copy(hb), C.byref(out)), f"ipc_open (rank {q})")
-                        ptrs.append(out.value)
-                        self._opened.append(out.value)
+                        if (q, hb) not in _IPC_OPENED:
+                            out = C.c_void_p()
+                            check(lib.sobfu_hip_ipc_open((C.c_char * 64).from_buffer_copy(hb), C.byref(out)), f"ipc_open (rank {q})")
+                            _IPC_OPENED[(q, hb)] = out.value
+                        ptrs.append(_IPC_OPENED[(q, hb)])
                     x = TiledExports()
                     x.arena, x.flags = ptrs
                     x.nabla_u_off[0], x.nabla_u_off[1], x.rows_off = allh[q][0][2]
