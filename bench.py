@@ -242,6 +242,50 @@ def bench_single(args, P, ranks, torch):
     return res
 
 
+FRAME_CONFIGS = {"config3": ("params/config3_boxing_256.ini", 256), "config5": ("params/config5_umbrella_512.ini", 512),
+                 "config2": ("params/config2_snoopy_128.ini", 128), "config1": ("params/config1_sphere_64.ini", 64)}
+
+
+def bench_frames(args, ranks, torch):
+    """Frames/s through the WHOLE per-frame pipeline the reference runs per sequence (src/sobfu/sob_fusion.cpp:71-145): depth
+    pre-steps (bilateral, truncation, ray lengths) -> integrate(depth) into phi_n -> estimate_psi (MAX_ITER iterations + 48-sweep
+    inverse + canonical->live warp) -> fuse.  One synthetic depth sequence per rank (a sphere translating 1.3 voxels per frame),
+    frame 0 (initialisation of phi_global) not timed; every later frame is timed on its own, host-synchronised."""
+    from sobfu_amd import fusion, params, synthetic
+
+    ini, dim0 = FRAME_CONFIGS[args.frame_config]
+    dim = args.dim if args.frame_dim <= 0 else args.frame_dim
+    P = params.read_ini(os.path.join(ROOT, ini), dims=(dim if dim != dim0 else None))
+    size, tz = float(P["size"][0]), float(P["t"][2])
+    vx = float(P["vs"][0])
+    radius = 0.2 * size
+    depth = [torch.from_numpy(synthetic.render_sphere_depth((1.3 * vx * n, 0.0, tz + 0.5 * size), radius, P["intr"])).cuda()
+             for n in range(args.frames)]
+    fu = fusion.SobFusion(P, max_iter=args.frame_iters)
+    fu(depth[0])
+    torch.cuda.synchronize()
+    ranks.barrier()
+    ms, iters = [], []
+    for n in range(1, args.frames):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rep = fu(depth[n])
+        torch.cuda.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0))
+        iters.append(int(rep[0].iterations) if rep is not None else 0)
+    moved = float((fu.psi[..., 0] - torch.arange(P["dims"][0], device="cuda", dtype=torch.float32)).abs().max().item())
+    fu.close()
+    worst = ranks.max(ms)  # per frame index, the slowest rank
+    med = sorted(worst)[len(worst) // 2]
+    return {"config": f"{ini} values, {P['dims'][0]}^3, {args.frame_iters} solver iterations per frame (MAX_ITER; max_update_norm "
+                      f"{P['max_update_norm']:g} never fires), synthetic 640x480 depth sequence (sphere translating 1.3 voxels / frame)",
+            "pipeline": "bilateral + truncation + ray lengths -> integrate(depth) -> estimate_psi (iterations + 48-sweep inverse + "
+                        "canonical->live warp) -> fuse   [reference src/sobfu/sob_fusion.cpp:71-145]",
+            "frames_timed": len(worst), "ms_per_frame": med, "ms_per_frame_all": [round(v, 3) for v in worst],
+            "frames_per_s_per_gpu": 1e3 / med, "frames_per_s_aggregate": ranks.world * 1e3 / med, "sequences": ranks.world,
+            "iterations_per_frame": iters, "psi_moved_max_abs": moved}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,7 +301,16 @@ def main():
     ap.add_argument("--tiles", type=str, default="", help="N > 1, strong scaling: tile grid PxxPyxPz (default sobfu_amd.tiled.default_grid: "
                                                          "2x2x2 at N=8, 1x2x2 at N=4, 1x1x2 at N=2), or 'auto': time every grid of N "
                                                          "tiles on this machine before the timed region and keep the fastest")
+    ap.add_argument("--frames", type=int, default=-1, help="frames of the per-frame pipeline to run for the `per_frame` block (frame 0 = "
+                                                           "initialisation, untimed); default: 5 at N = 1 and with --replicas, 0 otherwise")
+    ap.add_argument("--frame-config", choices=sorted(FRAME_CONFIGS), default="config3",
+                    help="parameter set of the per-frame pipeline: config3 = params_boxing.ini values (the bench grid), config5 = "
+                         "params_umbrella.ini values at 512^3 (BASELINE config 5; use with --replicas for batched sequences)")
+    ap.add_argument("--frame-dim", type=int, default=0, help="grid edge of the per-frame pipeline (default: --dim)")
+    ap.add_argument("--frame-iters", type=int, default=50, help="solver iterations per frame (MAX_ITER; BASELINE config 3 states 50)")
     args = ap.parse_args()
+    if args.frames < 0:
+        args.frames = 5 if (args.gpus == 1 or args.replicas) else 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
 
@@ -282,6 +335,8 @@ def main():
         res = tiled.bench_tiled(args, P, ranks, timed_regions)
     else:
         res = bench_single(args, P, ranks, torch)
+        if args.frames >= 2 and not force_tiled:
+            res["per_frame"] = bench_frames(args, ranks, torch)
 
     out = None
     if rank == 0:
@@ -353,7 +408,7 @@ def main():
                                 "iterations_per_s_incl_fixed": 50 / s50,
                                 "note": "one whole sobfu_hip_solver_iterate call of 50 iterations (BASELINE config 3's frame): enter the "
                                         "compact format + 50 iterations + max-norm rows to the host + leave, host-synchronised"}
-        for k in ("tiles", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback"):
+        for k in ("tiles", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame"):
             if res.get(k):
                 out[k] = res[k]
         if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise

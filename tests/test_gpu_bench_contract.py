@@ -22,7 +22,7 @@ def run_bench(*args, env=None):
 def test_single_gpu_line():
     d = run_bench("--gpus", "1", "--steps", "24", "--warmup", "8", "--dim", "128", "--repeats", "5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline", "repeats", "region_its", "per_solve"):
+              "data", "config", "roofline", "cpu_baseline", "repeats", "region_its", "per_solve", "per_frame"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 8 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "iterations/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
@@ -34,6 +34,8 @@ def test_single_gpu_line():
     assert r["traffic"] is None and 0 < r["frac_physical"] < 1 and 0 < r["pass_a"]["frac_physical"] < 1
     assert r["physical_bytes_per_launch"] == 128 ** 3 * 44
     assert d["per_solve"]["iterations"] == 50 and d["per_solve"]["ms"] > 0
+    f = d["per_frame"]  # the whole per-frame pipeline on the bench grid (5 frames by default, the first one untimed)
+    assert f["frames_timed"] == 4 and f["iterations_per_frame"] == [50] * 4 and f["frames_per_s_per_gpu"] > 0 and "128^3" in f["config"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s" and c["sample"]
     assert c["one_core"]["cores"] == 1 and c["one_core"]["value"] > 0
@@ -54,9 +56,14 @@ def test_gpus_n_self_launches_replicas():
 def test_config5_replicas_512():
     """BASELINE config 5's shape: 512^3 grids, one independent sequence per rank (two ranks sharing this box's GPU)"""
     d = run_bench("--gpus", "2", "--replicas", "--dim", "512", "--steps", "4", "--warmup", "2", "--repeats", "2", "--profile-repeats", "1",
-                  "--no-cpu-baseline", env={"SOBFU_BENCH_SHARE_GPU": "1"})
+                  "--no-cpu-baseline", "--frames", "3", "--frame-config", "config5", "--frame-iters", "6", env={"SOBFU_BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["grid"] == [512, 512, 512] and d["value"] > 0
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 512 ** 3 * 64
+    # ... and the frames/s of the whole per-frame pipeline (pre-steps -> integrate -> estimate_psi -> fuse) on those sequences
+    f = d["per_frame"]
+    assert "config5_umbrella_512.ini" in f["config"] and "512^3" in f["config"] and f["sequences"] == 2 and f["frames_timed"] == 2
+    assert f["iterations_per_frame"] == [6, 6] and f["ms_per_frame"] > 0 and f["psi_moved_max_abs"] > 0
+    assert abs(f["frames_per_s_aggregate"] - 2 * f["frames_per_s_per_gpu"]) < 1e-9 and abs(f["frames_per_s_per_gpu"] - 1e3 / f["ms_per_frame"]) < 1e-9
 
 
 def test_tile_path_line_on_one_gpu():
