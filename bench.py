@@ -177,6 +177,70 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+class GpuState:
+    """Shader clock and package power of THIS rank's GPU, read from the amdgpu hwmon files (freq1_input, power1_input) by a
+    sampling thread while the timed regions run -- evidence for (or against) attributing box-to-box / run-to-run differences to
+    the device's clock / power state.  Silent when sysfs does not expose the device."""
+
+    def __init__(self, torch, device):
+        import glob
+        import threading
+
+        self.dir, self.samples, self.marks, self._stop, self.why = None, [], [], threading.Event(), None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(d).endswith(bdf):
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                        self.dir, self.bdf = hw[0], bdf
+            if self.dir is None:
+                self.why = f"no hwmon directory for PCI device {bdf} under /sys/class/drm"
+        except Exception as e:  # noqa: BLE001
+            self.why = repr(e)
+        if self.dir:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return float("nan")
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((time.perf_counter(), self._read("freq1_input") / 1e6, self._read("power1_input") / 1e6))
+            time.sleep(0.002)
+
+    def mark(self, t0, t1):
+        self.marks.append((t0, t1))
+
+    def report(self):
+        if not self.dir:
+            return {"available": False, "why": self.why}
+        self._stop.set()
+        self.thread.join(timeout=1.0)
+        inside = [(c, p) for t, c, p in self.samples if any(a <= t <= b for a, b in self.marks) and c == c]
+        per = []
+        for a, b in self.marks:
+            v = [c for t, c, _ in self.samples if a <= t <= b and c == c]
+            per.append(round(float(np.median(v)), 0) if v else None)
+        if not inside:
+            return {"available": True, "samples_in_timed_regions": 0, "source": f"hwmon of {self.bdf}"}
+        c, p = np.array([x[0] for x in inside]), np.array([x[1] for x in inside])
+        return {"available": True, "source": f"amdgpu hwmon (freq1_input, power1_input) of PCI device {self.bdf}, sampled every ~2 ms",
+                "samples_in_timed_regions": len(inside),
+                "sclk_mhz": {"median": float(np.median(c)), "min": float(c.min()), "max": float(c.max())},
+                "power_w": {"median": float(np.nanmedian(p)), "min": float(np.nanmin(p)), "max": float(np.nanmax(p))},
+                "sclk_mhz_per_region": per}
+
+
+GPU_STATE = None
+
+
 def timed_regions(ranks, torch, fn, repeats):
     """`repeats` regions of one fn() each (fn enqueues exactly K iterations), barrier + synchronize on both sides of every
     region; returns the per-region seconds after a MAX over ranks.  A rank's clock runs from its exit of the opening barrier to
@@ -192,6 +256,8 @@ def timed_regions(ranks, torch, fn, repeats):
         t1 = time.perf_counter()
         ranks.barrier()
         secs.append(t1 - t0)
+        if GPU_STATE is not None:
+            GPU_STATE.mark(t0, t1)
     return ranks.max(secs)
 
 
@@ -326,6 +392,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     ranks = Ranks(torch, dist)
+    global GPU_STATE
+    if rank == 0:
+        GPU_STATE = GpuState(torch, ranks.device)
 
     P = boxing_params(args.dim)
     force_tiled = os.environ.get("SOBFU_FORCE_TILED") == "1"  # exercise the tile path on one GPU (debugging)
@@ -352,12 +421,17 @@ def main():
         def gbps(nbytes, ms):
             return (nbytes / (ms * 1e-3) / 1e9) if ms else None
 
-        pmc = pmc_file = None
+        pmc = pmc_file = pmc_stale = None
         for name in ("pmc_latest.json",):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
+                import hashlib
+
                 with open(path) as f:
-                    pmc, pmc_file = json.load(f).get("pass_b_hbm_bytes_per_launch"), "profiles/" + name
+                    pj = json.load(f)
+                pmc, pmc_file = pj.get("pass_b_hbm_bytes_per_launch"), "profiles/" + name
+                with open(os.path.join(ROOT, "sobfu_amd", "csrc", "solver_kernels.hip"), "rb") as f:
+                    pmc_stale = pj.get("kernel_source_sha256") != hashlib.sha256(f.read()).hexdigest()  # measured on other kernels?
         NL = res.get("launch_cells") or N  # cells one launch produces on one GPU (the largest tile's owned cells when tiled)
         ach_b = gbps(NL * B_PASS_B, ms_b)
         phys_b = gbps(NL * C_PASS_B, ms_b)
@@ -394,6 +468,7 @@ def main():
                 # the kernel must physically move are below the survey's algorithmic figure
                 "physical_bytes_per_launch": NL * C_PASS_B, "physical_GBps": phys_b, "frac_physical": phys_b / HBM_PEAK_GBPS,
                 "traffic_from_profiles": {"file": pmc_file, "bytes_per_launch": pmc, "GBps": gbps(pmc, ms_b) if pmc else None,
+                                          "stale": pmc_stale,  # true: the kernel source has changed since the counters were collected
                                           "note": "rocprofv3 PMC pass committed under profiles/, NOT measured in this run"},
                 "pass_a": {"avg_launch_ms": ms_a, "algorithmic_bytes_per_launch": NL * B_PASS_A, "physical_bytes_per_launch": NL * C_PASS_A,
                            "physical_GBps": gbps(NL * C_PASS_A, ms_a), "frac_physical": gbps(NL * C_PASS_A, ms_a) / HBM_PEAK_GBPS},
@@ -411,6 +486,8 @@ def main():
         for k in ("tiles", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame"):
             if res.get(k):
                 out[k] = res[k]
+        if GPU_STATE is not None:
+            out["gpu_state"] = GPU_STATE.report()
         if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise
             out["tiled_parity_vs_single_gpu"] = "bit-exact" if res["tiled_parity"] else "MISMATCH"
         if world == 1 and not args.no_cpu_baseline:

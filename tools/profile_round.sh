@@ -21,7 +21,9 @@ for db in sorted(glob.glob("$O/pmc*/r_results.db")):
     for name, cn, avg, n in c.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events where name like '%fused_%' group by name, counter_name"):
         k = "pass_a" if "potential" in name else "pass_b"
         rows.setdefault(k, {})[cn] = avg
-out = {"note": "rocprofv3 --pmc, one counter set per run, averages per launch at 256^3; FETCH_SIZE/WRITE_SIZE in KiB. "
+import hashlib
+out = {"kernel_source_sha256": hashlib.sha256(open("$R/sobfu_amd/csrc/solver_kernels.hip", "rb").read()).hexdigest(),
+       "note": "rocprofv3 --pmc, one counter set per run, averages per launch at 256^3; FETCH_SIZE/WRITE_SIZE in KiB. "
                "Correction factors MEASURED on this part with streaming copies of known size in the kernels' own access widths "
                "(12-byte dwordx3, 4-byte dword, 16-byte; plain and nontemporal -- tools/calibrate_counters.sh, "
                "profiles/r02_counter_calibration.json): FETCH_SIZE reports exactly 1/2 of the bytes read, WRITE_SIZE the bytes "
@@ -34,4 +36,6 @@ json.dump(out, open("$O/pmc.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}))
 PY
 rm -rf $O/kt $O/pmc[0-9]   # keep the summaries, drop the raw databases
+# one rank's iteration of the 2x2x2 tile loop, per kernel (compute side)
+timeout 600 $R/tools/profile_tiles.sh $tag 2x2x2 > $O/tiles.log 2>&1
 head -c 600 $O/bench.json; echo; cat $O/rocprof_kernel_stats.md | head -6
