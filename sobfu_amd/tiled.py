@@ -991,7 +991,22 @@ def autotune_grid(P, ranks, kw, iters=40, transport="rccl"):
 
 
 def bench_tiled(args, P, ranks, timed_regions):
-    """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N tiles (strong scaling; 2 x 2 x 2 at N = 8)."""
+    """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N tiles (strong scaling; 2 x 2 x 2 at N = 8).  The direct
+    transport is the default; should it -- after passing its precheck -- still break during the run (a peer missing its deadline,
+    or tiles that differ from the single-GPU solve in the final bitwise self-check), every rank repeats the whole leg on RCCL
+    and the line says so: a wrong or wedged transport never becomes the reported number."""
+    import os
+
+    res = _bench_tiled_once(args, P, ranks, timed_regions, os.environ.get("SOBFU_TILED_TRANSPORT", "direct"))
+    if res.get("retry"):
+        why = res["retry"]
+        print(f"[rank {ranks.rank}] direct transport abandoned ({why}): repeating the run on RCCL", file=sys.stderr, flush=True)
+        res = _bench_tiled_once(args, P, ranks, timed_regions, "rccl")
+        res["transport_fallback"] = why
+    return res
+
+
+def _bench_tiled_once(args, P, ranks, timed_regions, want):
     import os
 
     from . import ops
@@ -1012,7 +1027,6 @@ def bench_tiled(args, P, ranks, timed_regions):
     # transport of the native loop: "direct" (default: peer-mapped stores over xGMI, no RCCL in the loop) is taken only after
     # it has reproduced the single-GPU solve bit for bit on THIS machine on every rank (direct_transport_precheck, a few
     # iterations before anything is timed); otherwise every rank falls back to "rccl" and the line says why
-    want = os.environ.get("SOBFU_TILED_TRANSPORT", "direct")
     transport_name, fallback = ("rccl" if want != "direct" else "direct"), None
     if native and transport_name == "direct":
         fallback = direct_transport_precheck(P, ranks, kw, parse_grid("" if spec == "auto" else spec, world))
@@ -1052,12 +1066,12 @@ def bench_tiled(args, P, ranks, timed_regions):
     tuned = None
     if native and L.slab and transport is None and transport_name == "rccl" and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
         tuned = solver.autotune(pg, pn_full)  # outside the timed region: this machine's best z-slab schedule
-    if native:
+    def timed_native():
         solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
         solver.step(W)
         secs = timed_regions(ranks, torch, lambda: solver.step(K), R)
         prof = None
-        if PR > 0:  # the split of an iteration (serial schedule: pass A / exchange / pass B), outside the timed regions
+        if PR > 0:  # the split of an iteration (pass A incl. the message stores / transfer + scatter / pass B), outside the timed regions
             sched = getattr(solver, "schedule", 0)
             slab_sched = L.slab and transport_name == "rccl"
             if slab_sched:
@@ -1075,6 +1089,19 @@ def bench_tiled(args, P, ranks, timed_regions):
                 prof = ranks.max([pa / n, px / n, pb / n]) + [n]
         done, norms = solver.end()
         assert done == total and np.isfinite(norms).all() and float(norms.max()) > 0, (done, total)
+        return secs, prof, norms
+
+    if native:
+        broke = None
+        try:
+            secs, prof, norms = timed_native()
+        except Exception as e:  # noqa: BLE001
+            if transport_name != "direct":
+                raise
+            broke = repr(e)  # e.g. SOBFU_E_TIMEOUT: a peer's flag did not arrive within the deadline
+        if transport_name == "direct" and ranks.max([1 if broke else 0])[0] > 0:  # every rank leaves the transport together
+            solver.close()
+            return {"retry": broke or "another rank's direct transport broke"}
     else:  # the torch loop has no open-solve form: a region is a whole iterate() of K iterations
         prof, total = None, W + R * K
         if W > 0:
@@ -1105,6 +1132,9 @@ def bench_tiled(args, P, ranks, timed_regions):
         if not parity:
             print(f"[rank {rank}] tiled self-check: tile differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
         del pg_full, psi_full, pnp_full
+        if not parity and native and transport_name == "direct":
+            solver.close()
+            return {"retry": "tiles differed from the single-GPU solve in the final bitwise self-check"}
     # diagnostics for the next tuning round, outside the timed region (every rank takes part in the collective ones):
     # what one halo exchange, one slot all-reduce and the compute side alone cost on THIS machine
     diag, hung = None, False
