@@ -470,11 +470,18 @@ SOBFU_DEV float4 pass_a_direct_cell(const PassACore& a, int x, int y, int z) {
 }
 
 // the MARCHING path of pass A for the tile tg (a z-chunk of a 64 x TY tile)
+// where the cells of a PUSH box go (pass A of a multi-GPU tile: see tile_potential_gradient_kernel)
+struct PushDst {
+    float* base;             // null: the box is stored locally
+    int ox, oy, oz, px, py;  // cell (x, y, z) -> base + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz)))
+};
+SOBFU_DEV void st3_system(float* p, const float4& v);
+
 // NTL: streaming (nontemporal) hints, as SOBFU_NT -- for grids whose state exceeds the 256 MiB Infinity Cache; 0 for cache-resident
 // ones (multi-GPU tiles, small grids), where the hints keep the data the NEXT launch reads out of the cache (2 x 2 x 2 tile of
 // 256^3: 54.4 -> 48.8 us per iteration without them)
-template <int RPT, int WY, bool COMPACT, int NTL>
-SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRegs& gate) {
+template <int RPT, int WY, bool COMPACT, int NTL, bool PUSHABLE = false>
+SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRegs& gate, const PushDst* pd = nullptr) {
     constexpr int TY = RPT * WY, LW = TX + 2, LH = TY + 2;
     constexpr int NXH = (2 * TY + TX - 1) / TX;  // row-tasks for the two lane-halo columns
     constexpr int NTASK = 2 + NXH, TPW = (NTASK + WY - 1) / WY;
@@ -593,7 +600,10 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
             pin3<1>(o);
             if (u < tg.u_hi && v < tg.v_hi) {
                 const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
-                if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
+                if (PUSHABLE && pd->base != nullptr) {  // a marching PUSH box: the cell goes to its destination only
+                    const size_t j = (size_t) (u + pd->ox) + (size_t) pd->px * ((size_t) (v + pd->oy) + (size_t) pd->py * (size_t) (z + pd->oz));
+                    st3_system(pd->base + 3 * j, o);
+                } else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
                 else stv<COMPACT>(a.nU, i, o);
             }
         }
@@ -620,8 +630,9 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 
 // ---- pass A of a multi-GPU TILE: the halo exchange is part of the launch ---------------------------------------------------
 // Boxes of a tile launch, in workgroup order:
-//   PUSH boxes (direct): the cells of one halo message (a 4-cell face or a 4 x 4 edge strip of the owned block) are evaluated
-//       a second time, lane per cell, and stored STRAIGHT INTO THE DESTINATION -- the halo cells of the neighbour's nabla_U
+//   PUSH boxes: the cells of one halo message (a 4-cell face or a 4 x 4 edge strip of the owned block) are evaluated a second
+//       time -- lane per cell where the box is thin in x, by a short march where its rows are wide -- and stored STRAIGHT INTO
+//       THE DESTINATION -- the halo cells of the neighbour's nabla_U
 //       array, peer-mapped over xGMI (direct transport), or this rank's packed send buffer (RCCL / callback transports): no
 //       pack kernel, no unpack kernel and, with the direct transport, no communication launch at all.  They are numbered
 //       first, so they leave while the owned block is still being computed.
@@ -634,10 +645,6 @@ __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAA
 // double-buffered by iteration parity, which orders a neighbour's stores of iteration k+1 behind this rank's reads of
 // iteration k without a second handshake (see tiled_capi.hip).
 constexpr int kMaxTileBoxes = 20;  // 18 messages + the owned block + one spare
-struct PushDst {
-    float* base;             // null: the box is stored locally
-    int ox, oy, oz, px, py;  // cell (x, y, z) -> base + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz)))
-};
 struct TileBox {
     Box b;
     PushDst push;
@@ -751,7 +758,7 @@ __global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePas
         GateRegs gate;
 #pragma unroll
         for (int k = 0; k < 8; ++k) gate.v[k] = 0xffffffffu;  // pass A of a tile writes scratch only: never gated
-        pass_a_march<RPT, WY, COMPACT, NTL>(a.c, geom_in_box(b, t, first, a.c.d, RPT * WY), gate);
+        pass_a_march<RPT, WY, COMPACT, NTL, true>(a.c, geom_in_box(b, t, first, a.c.d, RPT * WY), gate, &pd);
     }
     if (a.sync == nullptr || !push_wg) return;
     // the push workgroups count themselves out; the LAST one raises this rank's flag at its peers and then waits for theirs: a
@@ -1483,15 +1490,19 @@ int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, floa
     TileBoxList& L = a.boxes;
     L.n = 0;
     int live = 0, total = 0;
-    for (int i = 0; i < n; ++i) live += (box_cells(boxes[i].box) > 0 && !boxes[i].box.direct) ? 1 : 0;
+    for (int i = 0; i < n; ++i) live += (box_cells(boxes[i].box) > 0 && !boxes[i].box.direct && boxes[i].dst == nullptr) ? 1 : 0;
     for (int pass = 0; pass < 2; ++pass) {  // push boxes first
         for (int i = 0; i < n; ++i) {
             const TileLaunchBox& s = boxes[i];
             if ((s.dst != nullptr) != (pass == 0) || box_cells(s.box) == 0) continue;
-            if (L.n >= kMaxTileBoxes || (s.dst != nullptr && !s.box.direct)) return SOBFU_E_BADARG;
+            if (L.n >= kMaxTileBoxes) return SOBFU_E_BADARG;
             TileBox& t = L.b[L.n];
             L.first[L.n] = total;
-            total += finish_box(t.b, s.box, TY, std::max(256 * 4 * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc, "SOBFU_ZC_A", false);
+            // z-chunks: a marching push box (a face with wide rows) marches up to 8 planes; the owned block is sized for TWO
+            // workgroups per CU -- the push boxes take slots too, and at tile size 8-plane marches beat the 4-plane ones that
+            // filling all four slots per CU would give (2 x 2 x 2 tile of 256^3: pass A 19.8 -> 19.1 us, 1 x 2 x 4: 18.9 -> 17.2)
+            const int zc_box = zc > 0 ? zc : ((s.dst != nullptr && !s.box.direct) ? std::min(8, s.box.z1 - s.box.z0) : 0);
+            total += finish_box(t.b, s.box, TY, std::max(256 * 2 * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc_box, "SOBFU_ZC_A", false);
             t.push = PushDst{s.dst, s.ox, s.oy, s.oz, s.px, s.py};
             ++L.n;
         }
@@ -1539,7 +1550,9 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
 #define SOBFU_LAUNCH_B(UPD, CMP, DIR) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, DIR>), grid, block, 0, stream, a)
 #define SOBFU_LAUNCH_BX(DIR, HLV, NTV, PIP) \
-    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, 0, stream, a)
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, lds_pad, stream, a)
+    const char* pad_e = getenv("SOBFU_LDS_PAD_B");  // experiment: unused dynamic LDS, to cap the workgroups a CU takes
+    const unsigned lds_pad = pad_e ? (unsigned) atoi(pad_e) : 0u;
     if (direct) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);
