@@ -1498,11 +1498,12 @@ int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, floa
             if (L.n >= kMaxTileBoxes) return SOBFU_E_BADARG;
             TileBox& t = L.b[L.n];
             L.first[L.n] = total;
-            // z-chunks: a marching push box (a face with wide rows) marches up to 8 planes; the owned block is sized for TWO
-            // workgroups per CU -- the push boxes take slots too, and at tile size 8-plane marches beat the 4-plane ones that
+            // z-chunks: a marching push box (a face with wide rows) marches up to 8 planes; the owned block of a cache-resident
+            // tile is sized for TWO workgroups per CU -- the push boxes take slots too, and at that size 8-plane marches beat the 4-plane ones that
             // filling all four slots per CU would give (2 x 2 x 2 tile of 256^3: pass A 19.8 -> 19.1 us, 1 x 2 x 4: 18.9 -> 17.2)
             const int zc_box = zc > 0 ? zc : ((s.dst != nullptr && !s.box.direct) ? std::min(8, s.box.z1 - s.box.z0) : 0);
-            total += finish_box(t.b, s.box, TY, std::max(256 * 2 * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc_box, "SOBFU_ZC_A", false);
+            total += finish_box(t.b, s.box, TY, std::max(256 * (cache_resident(X, Y, Z) ? 2 : 4) * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc_box,
+                                "SOBFU_ZC_A", false);
             t.push = PushDst{s.dst, s.ox, s.oy, s.oz, s.px, s.py};
             ++L.n;
         }
