@@ -1,8 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): tools/profile_round.sh r01   -- bench line + rocprofv3 kernel stats + PMC passes -> gpurun_out/<tag>/
 R="$(cd "$(dirname "$0")/.." && pwd)"; tag=${1:-r01}; O=$R/gpurun_out/$tag; mkdir -p $O
-cd $R
-python bench.py 2>$O/bench.err > $O/bench.json
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
 python $R/tools/rocprof_summary.py $O/kt/r_results.db > $O/rocprof_kernel_stats.md
@@ -36,6 +34,11 @@ json.dump(out, open("$O/pmc.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}))
 PY
 rm -rf $O/kt $O/pmc[0-9]   # keep the summaries, drop the raw databases
+# the bench line LAST, on the same box, with this run's counters in place (so that its traffic_from_profiles is this run's)
+cp $O/pmc.json $R/profiles/pmc_latest.json
+cd $R
+python bench.py 2>$O/bench.err > $O/bench.json
+cd /tmp
 # one rank's iteration of the 2x2x2 tile loop, per kernel (compute side)
 timeout 600 $R/tools/profile_tiles.sh $tag 2x2x2 > $O/tiles.log 2>&1
 head -c 600 $O/bench.json; echo; cat $O/rocprof_kernel_stats.md | head -6
