@@ -177,6 +177,43 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+def measure_traffic(args):
+    """HBM-side bytes per launch of pass A / pass B, LIVE: two short rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- counters only,
+    with --kernel-trace for the kernel names, never combined with other trace domains) over this same script, corrected with the
+    factors measured on this part (profiles/r02_counter_calibration.json: FETCH_SIZE reports 1/2 of the bytes read, WRITE_SIZE the
+    bytes written; KiB units) -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  These are L2 <-> fabric bytes (Infinity-Cache hits
+    included): an upper bound of the HBM bytes.  Any failure (no rocprofv3, a time-out) -> None: the line is printed regardless."""
+    import shutil
+    import sqlite3
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
+                       "--steps", "20", "--warmup", "5", "--repeats", "1", "--profile-repeats", "0", "--frames", "0", "--dim", str(args.dim),
+                       "--no-cpu-baseline", "--no-traffic"]
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=150, check=True)
+                db = os.path.join(tmp, "r_results.db")
+                c = sqlite3.connect(db)
+                for name, cn, avg, n in c.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events "
+                                                  "where name like '%fused_%' group by name, counter_name"):
+                    vals[("a" if "potential" in name else "b", cn)] = (float(avg), int(n))
+                c.close()
+        out = {}
+        for k in ("a", "b"):
+            f, w = vals[(k, "FETCH_SIZE")], vals[(k, "WRITE_SIZE")]
+            out[k] = {"bytes": (2.0 * f[0] + w[0]) * 1024.0, "launches": min(f[1], w[1])}
+        return out, None
+    except Exception as e:  # noqa: BLE001
+        return None, repr(e)
+
+
 class GpuState:
     """Shader clock and package power of THIS rank's GPU, read from the amdgpu hwmon files (freq1_input, power1_input) by a
     sampling thread while the timed regions run -- evidence for (or against) attributing box-to-box / run-to-run differences to
@@ -361,6 +398,7 @@ def main():
     ap.add_argument("--profile-repeats", type=int, default=2, help="extra regions with HIP events around every launch (kernel split)")
     ap.add_argument("--dim", type=int, default=256, help="grid edge (256 = the BASELINE metric's grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes that measure roofline.traffic (N = 1)")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: every rank solves its OWN grid (independent sequences, BASELINE config 5 style: no exchange, weak "
                          "scaling) instead of the default -- ONE grid cut into N tiles with RCCL halo exchange (strong scaling)")
@@ -455,12 +493,22 @@ def main():
             "last_max_update_norm": res.get("last_norm"),
             "solver_workspace_bytes": res.get("workspace"),
         }
+        traffic, traffic_err = (None, "not measured (--no-traffic, N > 1 or another grid path)")
+        if world == 1 and not args.no_traffic and not force_tiled and ms_b:
+            traffic, traffic_err = measure_traffic(args)
         if ms_b:
             out["roofline"] = {
                 "kernel": "fused_smooth_update_apply_kernel (pass B: sum of three 1-D Sobolev convolutions + psi update + phi_n o psi "
                           "warp + max-norm)",
                 "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBPS,
-                "traffic": None,  # PMC counters cannot be read from inside the process: see traffic_from_profiles
+                # L2 <-> fabric bytes per launch of this kernel from rocprofv3's FETCH_SIZE / WRITE_SIZE counters, measured NOW by two
+                # short PMC passes over this script (measure_traffic); null when that was not possible
+                "traffic": traffic["b"]["bytes"] if traffic else None,
+                "traffic_GBps": gbps(traffic["b"]["bytes"], ms_b) if traffic else None,
+                "traffic_frac": (gbps(traffic["b"]["bytes"], ms_b) / HBM_PEAK_GBPS) if traffic else None,
+                "traffic_how": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 20 iterations each) of this script just now; "
+                                "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the factors calibrated on this part; " +
+                                f"{traffic['b']['launches']} launches averaged") if traffic else traffic_err,
                 "algorithmic_bytes_per_launch": NL * B_PASS_B, "avg_launch_ms": ms_b, "launches_timed": res.get("n_prof"),
                 "how": "HIP events on the solver's stream around every pass-A / pass-B launch of the profiled regions"
                        + ("; per GPU: one launch produces the largest tile's owned cells (MAX over ranks of the averages)" if res.get("launch_cells") else ""),
@@ -471,6 +519,7 @@ def main():
                                           "stale": pmc_stale,  # true: the kernel source has changed since the counters were collected
                                           "note": "rocprofv3 PMC pass committed under profiles/, NOT measured in this run"},
                 "pass_a": {"avg_launch_ms": ms_a, "algorithmic_bytes_per_launch": NL * B_PASS_A, "physical_bytes_per_launch": NL * C_PASS_A,
+                           "traffic": traffic["a"]["bytes"] if traffic else None,
                            "physical_GBps": gbps(NL * C_PASS_A, ms_a), "frac_physical": gbps(NL * C_PASS_A, ms_a) / HBM_PEAK_GBPS},
                 "event_sum_vs_step": (ms_a + ms_b + (res.get("ms_exchange") or 0.0)) / (1e3 * med / K),
             }

@@ -568,6 +568,10 @@ class NativeTiledSolver:
         if grid[0] * grid[1] * grid[2] != self.world:
             raise ValueError(f"tile grid {grid} does not have {self.world} tiles")
         self.grid = grid
+        # the layout is validated HERE, identically on every rank (same dims, same grid), before any collective: a grid that is too
+        # thin for its halos raises everywhere instead of failing inside create3 on some ranks while the others sit in ncclCommInitRank
+        for q in range(self.world):
+            TileLayout(dims, grid, q)
         self.params = SolverParams(0, 0, s, max_update_norm, np.float32(lam), alpha, w_reg)
         self._h = C.c_void_p()
         X, Y, Z = (int(d) for d in dims)

@@ -7,7 +7,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_$tag/p$i -o r -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" >/dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_$tag/p$i -o r -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --frames 0 "$@" >/dev/null 2>&1
 done
 python - <<PY
 import sqlite3, glob

@@ -2,14 +2,14 @@
 # usage (on the GPU box): tools/profile_round.sh r01   -- bench line + rocprofv3 kernel stats + PMC passes -> gpurun_out/<tag>/
 R="$(cd "$(dirname "$0")/.." && pwd)"; tag=${1:-r01}; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline --no-traffic > $O/bench_under_rocprof.json 2>/dev/null
 python $R/tools/rocprof_summary.py $O/kt/r_results.db > $O/rocprof_kernel_stats.md
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace -d $O/pmc$i -o r -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline >/dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -d $O/pmc$i -o r -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic >/dev/null 2>&1
 done
 python - <<PY
 import sqlite3, glob, json

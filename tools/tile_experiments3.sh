@@ -12,7 +12,7 @@ run TILE_GRIDS=$g SOBFU_PIPE_B=1 SOBFU_TILED_DEBUG_SKIP=9
 for z in 6 8 16; do run TILE_GRIDS=$g SOBFU_PIPE_B=1 SOBFU_ZC_B=$z; done
 for z in 2 8; do run TILE_GRIDS=$g SOBFU_PIPE_B=1 SOBFU_ZC_A=$z; done
 done
-b() { echo "== bench $*"; env "$@" python bench.py --steps 50 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | grep metric | python -c "
+b() { echo "== bench $*"; env "$@" python bench.py --steps 50 --warmup 20 --repeats 5 --no-cpu-baseline --no-traffic --frames 0 2>/dev/null | grep metric | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%.0f it/s  passA %.1f us  passB %.1f us' % (d['value'], r['pass_a']['avg_launch_ms']*1e3, r['avg_launch_ms']*1e3))"; }
