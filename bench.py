@@ -16,7 +16,9 @@ reading the max-norm rows) is not an iteration and is reported separately (`per_
 regions, `--profile-repeats` more regions run with HIP events around every launch for the per-kernel split (`roofline`).
 
 Prints ONE JSON line (rank 0), last on stdout.  `roofline` = the dominant kernel (pass B: Sobolev smoothing + psi update +
-warp + max-norm), `cpu_baseline` = the oracle's OpenMP port of the same iteration timed on the host cores (N=1 only).
+warp + max-norm) incl. `traffic` (fabric bytes per launch from two live rocprofv3 PMC passes, N=1), `cpu_baseline` = the oracle's
+OpenMP port of the same iteration timed on the host cores (N=1 only), `per_frame` = the whole per-frame pipeline of the reference's
+SobFusion::operator() (frames/s), `gpu_state` = shader clock / package power sampled inside the timed regions.
 """
 import argparse
 import json
