@@ -461,7 +461,7 @@ def test_full_size_256_fused_equals_launchers_and_properties(ops, oracle):
 def test_tile_kernels_match_full_volume(ops, oracle, grid, compact):
     """One iteration on every tile of a cut (z-slabs, x / y splits, 2 x 2 x 2), with the single nabla_U exchange emulated by
     slicing the full-volume result: the owned cells and their one-cell shells of psi / phi_n o psi, and the owned max, must
-    equal the full-volume kernels.  The x shells run as transposed boxes."""
+    equal the full-volume kernels.  The x and y shells run as thin (lane-per-cell) boxes."""
     from sobfu_amd import tiled
 
     dims = (70, 24, 36)
@@ -487,7 +487,7 @@ def test_tile_kernels_match_full_volume(ops, oracle, grid, compact):
         psi_l, pg_l = (L.take(t).clone().contiguous() for t in (dev(psi0), dev(pg)))
         pnp_l = torch.zeros(L.local_shape(2), device="cuda")
         st = be.begin(L, pg_l, pn_d, pnp_l, psi_l)
-        # pass A on the owned cells, in three z ranges (as an overlapped schedule issues them); one of them transposed
+        # pass A on the owned cells, in three z ranges (as an overlapped schedule issues them); one of them as a thin box
         ob = L.own_box()
         z0, z1 = ob[4], ob[5]
         be.pass_a(st, ob[:4] + (z0, z0 + 2), w_reg, None, 0.0)

@@ -55,7 +55,7 @@ def test_slabs_match_single_process(oracle, tmp_path, world):
 
 @pytest.mark.parametrize("grid", ["2x1x1", "1x2x1", "2x2x1", "1x2x2"])
 def test_tiles_match_single_process(oracle, tmp_path, grid):
-    """x / y splits (non-contiguous faces, the transposed x shell) and 2-D grids (edge strips between diagonal neighbours)"""
+    """x / y splits (non-contiguous faces, the thin x shell) and 2-D grids (edge strips between diagonal neighbours)"""
     world = int(np.prod([int(v) for v in grid.split("x")]))
     got = _run(world, -1.0, tmp_path, grid)
     psi, r1, r2 = _reference(oracle, -1.0)
