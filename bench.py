@@ -192,6 +192,8 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler: no nested rocprofv3"
     vals = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
