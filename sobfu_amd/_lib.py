@@ -48,6 +48,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m sobfu_amd.build` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # The library needs libamdhip64, and so does PyTorch -- which ships its OWN copy.  Whichever is loaded first serves both (same
+    # soname); PyTorch goes first, so that the tensors this front end hands over and the library's kernels live in ONE HIP runtime
+    # (loaded the other way round, the library saw "no ROCm-capable device" in a process where torch.cuda was fine).
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     if missing:
