@@ -120,7 +120,7 @@ def run_world(dims, grid, psi0, pg, pn, n_iters, thr, schedule=None):
     return out, full
 
 
-def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1):
+def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, kw=None):
     """N ranks on the DIRECT transport in one process.  stepped: one host thread drives all ranks phase by phase (pass A incl.
     the pushes | pass B | ... | end-of-solve handshake) with the in-kernel waits off -- any number of ranks; else one thread
     per rank runs the real loop, in-kernel waits live (few ranks: every rank's stream needs a hardware queue of its own)."""
@@ -130,7 +130,8 @@ def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1):
 
     grid = as_grid(grid)
     world = grid[0] * grid[1] * grid[2]
-    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=thr, dry=(world, r), grid=grid) for r in range(world)]
+    kw = kw or dict(alpha=0.05, w_reg=0.4)
+    solvers = [tiled.NativeTiledSolver(dims, max_update_norm=thr, dry=(world, r), grid=grid, **kw) for r in range(world)]
     tiled.NativeTiledSolver.connect_local(solvers)
     torch.cuda.synchronize()
     pn_d = torch.from_numpy(pn).cuda()
@@ -526,3 +527,40 @@ def test_config4_256_cubed_on_2x2x2_tiles_loopback():
     for s in solvers:
         s.close()
     assert ok == [True] * 8, ok
+
+
+def test_config4_256_cubed_on_2x2x2_tiles_direct_transport():
+    """BASELINE config 4 at full size on the DIRECT transport: the 256^3 roofline workload cut into 2 x 2 x 2 tiles of 128^3, eight
+    ranks in this process (phase-stepped: pass A incl. the stores into the neighbours' arrays | pass B | ... | handshake), the ini's
+    1e-10 threshold live (max-norm rows made global by stores, the late gate reads them every iteration): psi, phi_n o psi and the
+    max-norm history equal the single-GPU solve bit for bit."""
+    import torch
+
+    import bench
+    from sobfu_amd import ops
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs ~16 GiB of HBM")
+    P = bench.boxing_params(256)
+    dims, n_iters = P["dims"], 8
+    c0, c1, r = bench.sphere_pair(P)
+    pg, pn = ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_sphere(pg, P["vs"], P["trunc"], P["eta"], c0, r)
+    ops.init_sphere(pn, P["vs"], P["trunc"], P["eta"], c1, r)
+    kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"])
+    ref = ops.Solver(dims, max_iter=n_iters, max_update_norm=P["max_update_norm"], **kw)
+    psi_r, pnp_r = ops.new_field(dims), ops.new_volume(dims)
+    ops.init_identity(psi_r)
+    rep, hist_r = ref.iterate(pg, pn, pnp_r, psi_r, n_iters)
+    ref.close()
+    assert rep.iterations == n_iters and float(hist_r.min()) > 0
+    psi0 = ops.new_field(dims)
+    ops.init_identity(psi0)
+    out, (psi_t, pnp_t) = run_world_direct(dims, (2, 2, 2), psi0.cpu().numpy(), pg.cpu().numpy(), pn.cpu().numpy(), n_iters,
+                                           P["max_update_norm"], True, 1, kw)
+    for done, hist, _, _ in out:
+        assert done == n_iters
+        assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), np.asarray(hist_r, np.float32).view(np.uint32))
+    assert np.array_equal(psi_t[..., :3].view(np.uint32), psi_r.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(pnp_t.view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
