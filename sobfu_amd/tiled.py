@@ -39,6 +39,12 @@ HALO = 4
 SLOTS = 256
 
 
+def _x_pad():
+    import os
+
+    return os.environ.get("SOBFU_TILE_XPAD", "0") == "1"
+
+
 def default_grid(world):
     """Tile grid for `world` ranks: as cubic as the factorisation allows, larger factors on the slower axes (x, the axis the
     64 lanes of a wave run along, is split last): 8 -> 2 x 2 x 2 (BASELINE config 4), 4 -> 1 x 2 x 2, 2 -> 1 x 1 x 2."""
@@ -88,6 +94,11 @@ class TileLayout:
             g1.append(g0[-1] + base + (1 if c < rem else 0))
             lo.append(halo if c > 0 else 0)
             hi.append(halo if c < grid[a] - 1 else 0)
+            if a == 0 and _x_pad() and grid[0] > 1 and base >= 64:  # aligned rows: see make_layout in csrc/tiled_capi.hip
+                if lo[-1]:
+                    lo[-1] = 32
+                if hi[-1]:
+                    hi[-1] = halo + (32 - (lo[-1] + (g1[-1] - g0[-1]) + halo) % 32) % 32
         self.g0, self.g1, self.lo3, self.hi3 = tuple(g0), tuple(g1), tuple(lo), tuple(hi)
         self.L = tuple(g1[a] - g0[a] + lo[a] + hi[a] for a in range(3))              # local extents
         self.o0 = tuple(lo)                                                           # owned local range [o0, o1)
