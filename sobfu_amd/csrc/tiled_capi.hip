@@ -933,6 +933,59 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
             // TILE PATH -- pass A's launch carries the exchange (push boxes first).  Direct transport: that is all of it -- the
             // launch retires when the neighbours' cells have landed too.  RCCL / callback: the packed buffer travels, one
             // kernel scatters what arrived.  No cross-stream events anywhere.
+            // OVERLAPPED schedule of the RCCL / callback transports (schedule 1 or 2; SOBFU_TILED_SERIAL=0): the push boxes are a launch of
+            // their own, the packed messages travel and are scattered on the communication stream while the owned block of pass A
+            // and the INTERIOR of pass B (cells whose +-3 taps are all owned) run; the rim of pass B -- up to six slabs, 3 owned cells
+            // + the shell cell thick, which may overlap at tile edges (same inputs, same values) -- follows the exchange:
+            //     A_push -> event -> [comm stream] send / recv, scatter (+ the previous row's all-reduce) -> event
+            //     A_own, B_int                                                   ... meanwhile
+            //     wait(comm) -> B_rim
+            const bool overlap = multi && !sync && phases == 3 && !ev && !dbg && (se ? se[0] == '0' : (t->schedule == 1 || t->schedule == 2)) &&
+                                 !t->msgs.empty();
+            if (overlap) {
+                const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[it & 1];
+                const int nm = (int) t->msgs.size();
+                SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, bx.data(), nm, nullptr, 0, 0, nullptr, 0, 0, st, true));
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
+                SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
+                SOBFU_TRY(exchange_packed(t, nu, t->comm_stream));
+                SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
+                const bool red_here = can_converge && !t->comm2;  // the row reduction rides behind the exchange, as on z-slabs
+                if (red_here && it >= 2 && it < n_iters && q.red_upto < it - 1) {
+                    const int first = q.red_upto + 1;
+                    SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (it - first) * kSlots, t->comm_stream));
+                    SOBFU_HIP_TRY(hipEventRecord(t->ev_red[(it - 1) & 1], t->comm_stream));
+                    red_issued[(it - 1) & 1] = true;
+                    q.red_upto = it - 1;
+                }
+                SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, &bx.back(), 1, nullptr, 0, 0, nullptr, 0, 0, st, true));
+                SOBFU_TRY(wait_gate());
+                // interior: owned cells at least 3 away from every face that has a neighbour
+                const int ix0 = ax0 + (t->lo[0] ? 3 : 0), ix1 = ax1 - (t->hi[0] ? 3 : 0), iy0 = ay0 + (t->lo[1] ? 3 : 0), iy1 = ay1 - (t->hi[1] ? 3 : 0);
+                const int iz0 = lo + (t->lo[2] ? 3 : 0), iz1 = hi - (t->hi[2] ? 3 : 0);
+                auto Bx = [&](const sobfu_hip::LaunchBox* bxs, int nb) {
+                    return sobfu_hip::launch_pass_b_boxes(nu, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y, Z,
+                                                          own, bxs, nb, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
+                };
+                if (ix1 > ix0 && iy1 > iy0 && iz1 > iz0) {
+                    const sobfu_hip::LaunchBox bi[1] = {{ix0, ix1, iy0, iy1, iz0, iz1, false}};
+                    SOBFU_TRY(Bx(bi, 1));
+                }
+                SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
+                const bool wide = ax1 - ax0 >= 64;  // rows wide enough for a march
+                const sobfu_hip::LaunchBox br[6] = {
+                    {ax0, ax1, ay0, ay1, t->lo[2] ? lo - 1 : lo, t->lo[2] ? std::min(lo + 3, hi) : lo, false},
+                    {ax0, ax1, ay0, ay1, t->hi[2] ? std::max(hi - 3, lo) : hi, t->hi[2] ? hi + 1 : hi, false},
+                    {ax0, ax1, t->lo[1] ? ay0 - 1 : ay0, t->lo[1] ? std::min(ay0 + 3, ay1) : ay0, lo, hi, !wide},
+                    {ax0, ax1, t->hi[1] ? std::max(ay1 - 3, ay0) : ay1, t->hi[1] ? ay1 + 1 : ay1, lo, hi, !wide},
+                    {t->lo[0] ? ax0 - 1 : ax0, t->lo[0] ? std::min(ax0 + 3, ax1) : ax0, ay0, ay1, lo, hi, true},
+                    {t->hi[0] ? std::max(ax1 - 3, ax0) : ax1, t->hi[0] ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
+                SOBFU_TRY(Bx(br, 6));
+                if (t->comm2) SOBFU_TRY(after_b());  // (own-communicator mode keeps its own reduction point)
+                q.launched = it;
+                if (t->comm && !t->first_checked) SOBFU_TRY(first_iteration_watchdog(t, st));
+                continue;
+            }
             if (phases & 1) {
                 if (ev) SOBFU_HIP_TRY(hipEventRecord(e[0], st));
                 const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[it & 1];

@@ -779,6 +779,8 @@ class NativeTiledSolver:
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)
 
+    # z-slabs: 1 / 2 = exchange overlapped, pass A split into boundary + interior launches or whole; 3-D tiles: 1 = 2 = push boxes as
+    # their own launch, exchange + scatter on the communication stream beside pass A's owned block and pass B's interior
     SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)"}
 
     def set_schedule(self, schedule):
@@ -790,7 +792,7 @@ class NativeTiledSolver:
         the fastest; every rank takes part and all agree (MAX over ranks).  Returns {schedule: us per iteration}."""
         pnp, psi = self.new_local(2), self.identity_psi()
         times = {}
-        for sched in self.SCHEDULES:
+        for sched in (self.SCHEDULES if self.layout.slab else (1, 3)):
             self.set_schedule(sched)
             self.iterate(phi_global_local, phi_n_full, pnp, psi, 4)
             torch.cuda.synchronize()
@@ -1079,8 +1081,8 @@ def _bench_tiled_once(args, P, ranks, timed_regions, want):
     pnp = solver.new_local(2)
     psi = solver.identity_psi()
     tuned = None
-    if native and L.slab and transport is None and transport_name == "rccl" and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
-        tuned = solver.autotune(pg, pn_full)  # outside the timed region: this machine's best z-slab schedule
+    if native and transport is None and transport_name == "rccl" and world > 1 and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
+        tuned = solver.autotune(pg, pn_full)  # outside the timed region: this machine's best schedule (serial / overlapped exchange)
     def timed_native():
         solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
         solver.step(W)
