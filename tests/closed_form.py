@@ -101,6 +101,43 @@ def update_case(S, alpha=0.25):
     return nU, psi0, phi, psi1, warped, alpha
 
 
+def inverse_case():
+    """psi = identity + a constant displacement c (dyadic): the fixed point psi_inv(x) = x - u(psi_inv(x)) (vector_fields.cu:111-138,
+    u = psi - id interpolated trilinearly) has u == c wherever the sample point and its 8 corners are inside the volume, so psi_inv =
+    x - c EXACTLY after the first sweep and for all 48 -- away from the faces the displacement points out of (there the sampler's
+    clamp changes the point)."""
+    x, y, z = grid()
+    c = np.array([1.5, -0.75, 2.25])
+    psi = np.stack([x + c[0], y + c[1], z + c[2]], -1)
+    inv = np.stack([x - c[0], y - c[1], z - c[2]], -1)
+    X, Y, Z = DIMS
+    ok = (inv[..., 0] >= 0) & (inv[..., 0] <= X - 1) & (inv[..., 1] >= 0) & (inv[..., 1] <= Y - 1) & (inv[..., 2] >= 0) & (inv[..., 2] <= Z - 1)
+    return psi, inv, ok
+
+
+def fuse_case(max_weight=4.0):
+    """integrate(phi_global, phi_n o psi) (tsdf_volume.cu:103-130): tsdf = fma(w_g, tsdf_g, tsdf_n) / (w_g + 1), w = min(w_g + 1, max); a
+    voxel is SKIPPED when w_n == 0, or when w_n == 1 and tsdf_n is 0 or -1.  Dyadic values: exact."""
+    X, Y, Z = DIMS
+    g = np.zeros((Z, Y, X, 2))
+    n = np.zeros((Z, Y, X, 2))
+    g[..., 0], g[..., 1] = 0.5, 1.0
+    n[..., 0], n[..., 1] = 0.25, 1.0
+    exp = np.zeros_like(g)
+    exp[..., 0], exp[..., 1] = (1.0 * 0.5 + 0.25) / 2.0, 2.0
+    n[0, :, :, 1] = 0.0                      # w_n == 0: untouched
+    n[1, :, :, 0] = 0.0                      # w_n == 1, tsdf_n == 0: untouched
+    n[2, :, :, 0] = -1.0                     # w_n == 1, tsdf_n == -1: untouched
+    for k in (0, 1, 2):
+        exp[k] = g[k]
+    g[3, :, :, 1] = max_weight               # weight saturates: tsdf = (4 * 0.5 + 0.25) / 5, w = min(5, 4)
+    exp[3, :, :, 0], exp[3, :, :, 1] = (max_weight * 0.5 + 0.25) / (max_weight + 1.0), max_weight
+    n[4, :, :, 1] = 2.0                      # w_n == 2 with tsdf_n == -1 is NOT skipped
+    n[4, :, :, 0] = -1.0
+    exp[4, :, :, 0], exp[4, :, :, 1] = (0.5 - 1.0) / 2.0, 2.0
+    return g, n, exp, max_weight
+
+
 def check_all(api, S):
     """runs every case through `api`; returns the worst deviations for the record"""
     out = {}
@@ -140,4 +177,11 @@ def check_all(api, S):
     e = interior(np.abs(gw[..., 0].astype(np.float64) - warped), 3)
     assert e.max() <= 32.0 * float(np.finfo(np.float32).eps) * float(np.abs(phi).max()), float(e.max())
     out["update_ulp"], out["update_warp_abs_err"] = float(u.max()), float(e.max())
+    psi, inv, ok = inverse_case()
+    got = api.run_inverse(psi.astype(np.float32), 48)
+    assert np.array_equal(got[..., :3][ok], inv.astype(np.float32)[ok]) and ok.sum() > 0.5 * ok.size
+    g, n, exp, mw = fuse_case()
+    got = api.run_fuse(g.astype(np.float32), n.astype(np.float32), mw)
+    u = ulps(got, exp)
+    assert u.max() <= 1.0, float(u.max())  # (the one inexact quotient, 2.25 / 5, is correctly rounded)
     return out

@@ -56,6 +56,18 @@ class OracleApi:
         return p, out
 
 
+    def run_inverse(self, psi, sweeps):
+        inv = self.O.new_field(cf.DIMS)
+        self.O.estimate_inverse(self._field(psi), inv, sweeps)
+        return inv
+
+    def run_fuse(self, g, n, max_weight):
+        vg, vn = self.O.new_volume(cf.DIMS), self.O.new_volume(cf.DIMS)
+        vg[...], vn[...] = g, n
+        self.O.integrate_fuse(vg, vn, max_weight)
+        return vg
+
+
 def test_closed_form_known_answers_oracle(oracle):
     S = oracle.sobolev_filter(7, 0.1)
     m0, m1, m2 = cf.taps_moments(S)

@@ -69,6 +69,17 @@ class HipApi:
         return p.cpu().numpy(), out.cpu().numpy()
 
 
+    def run_inverse(self, psi, sweeps):
+        inv = self.ops.new_field(cf.DIMS)
+        self.ops.estimate_inverse(self._field(psi), inv, sweeps)
+        return inv.cpu().numpy()
+
+    def run_fuse(self, g, n, max_weight):
+        vg, vn = dev(g.astype(np.float32)), dev(n.astype(np.float32))
+        self.ops.integrate_fuse(vg, vn, max_weight)
+        return vg.cpu().numpy()
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_closed_form_known_answers_hip(fused):
     from sobfu_amd import ops
