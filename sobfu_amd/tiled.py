@@ -1081,8 +1081,13 @@ def _bench_tiled_once(args, P, ranks, timed_regions, want):
     pnp = solver.new_local(2)
     psi = solver.identity_psi()
     tuned = None
-    if native and transport is None and transport_name == "rccl" and world > 1 and os.environ.get("SOBFU_TILED_AUTOTUNE", "1") == "1":
-        tuned = solver.autotune(pg, pn_full)  # outside the timed region: this machine's best schedule (serial / overlapped exchange)
+    # schedule autotuning (serial vs overlapped exchange; outside the timed region) runs only where RCCL was ASKED for: z-slabs by
+    # default, 3-D tiles with SOBFU_TILED_AUTOTUNE=tiles.  When RCCL is the fallback of a direct transport that just failed, the run
+    # takes the plainest schedule there is (serial, one stream) -- nothing that has never executed on >= 2 GPUs is tried first.
+    at = os.environ.get("SOBFU_TILED_AUTOTUNE", "1")
+    if (native and transport is None and transport_name == "rccl" and want == "rccl" and fallback is None and world > 1
+            and ((L.slab and at == "1") or at == "tiles")):
+        tuned = solver.autotune(pg, pn_full)
     def timed_native():
         solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
         solver.step(W)
