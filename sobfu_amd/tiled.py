@@ -1018,12 +1018,12 @@ def bench_tiled(args, P, ranks, timed_regions):
     if res.get("retry"):
         why = res["retry"]
         print(f"[rank {ranks.rank}] direct transport abandoned ({why}): repeating the run on RCCL", file=sys.stderr, flush=True)
-        res = _bench_tiled_once(args, P, ranks, timed_regions, "rccl")
+        res = _bench_tiled_once(args, P, ranks, timed_regions, "rccl", plain=True)
         res["transport_fallback"] = why
     return res
 
 
-def _bench_tiled_once(args, P, ranks, timed_regions, want):
+def _bench_tiled_once(args, P, ranks, timed_regions, want, plain=False):
     import os
 
     from . import ops
@@ -1085,7 +1085,7 @@ def _bench_tiled_once(args, P, ranks, timed_regions, want):
     # default, 3-D tiles with SOBFU_TILED_AUTOTUNE=tiles.  When RCCL is the fallback of a direct transport that just failed, the run
     # takes the plainest schedule there is (serial, one stream) -- nothing that has never executed on >= 2 GPUs is tried first.
     at = os.environ.get("SOBFU_TILED_AUTOTUNE", "1")
-    if (native and transport is None and transport_name == "rccl" and want == "rccl" and fallback is None and world > 1
+    if (native and transport is None and transport_name == "rccl" and want == "rccl" and fallback is None and not plain and world > 1
             and ((L.slab and at == "1") or at == "tiles")):
         tuned = solver.autotune(pg, pn_full)
     def timed_native():
