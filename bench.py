@@ -227,7 +227,7 @@ class GpuState:
         import glob
         import threading
 
-        self.dir, self.samples, self.marks, self._stop, self.why = None, [], [], threading.Event(), None
+        self.dir, self.samples, self.marks, self._stop, self.why, self.after = None, [], [], threading.Event(), None, []
         try:
             pr = torch.cuda.get_device_properties(device)
             bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
@@ -258,6 +258,8 @@ class GpuState:
 
     def mark(self, t0, t1):
         self.marks.append((t0, t1))
+        if self.dir:  # read right behind a region, outside every timed one: memory clock, junction / HBM temperature
+            self.after.append((self._read("freq2_input") / 1e6, self._read("temp2_input") / 1e3, self._read("temp3_input") / 1e3))
 
     def report(self):
         if not self.dir:
@@ -276,7 +278,12 @@ class GpuState:
                 "samples_in_timed_regions": len(inside),
                 "sclk_mhz": {"median": float(np.median(c)), "min": float(c.min()), "max": float(c.max())},
                 "power_w": {"median": float(np.nanmedian(p)), "min": float(np.nanmin(p)), "max": float(np.nanmax(p))},
-                "sclk_mhz_per_region": per}
+                "sclk_mhz_per_region": per,
+                "after_each_region": {"mclk_mhz": [round(a[0]) for a in self.after if a[0] == a[0]],
+                                      "junction_c": [round(a[1]) for a in self.after if a[1] == a[1]],
+                                      "hbm_c": [round(a[2]) for a in self.after if a[2] == a[2]]},
+                "note": "freq1_input is a slowly updated average: within one run it climbs by several hundred MHz from region to region while "
+                        "the regions' rates agree to 0.1 %, and SQ_BUSY_CYCLES / kernel time of the PMC passes says ~2.1 GHz under load"}
 
 
 GPU_STATE = None
