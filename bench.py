@@ -256,6 +256,17 @@ class GpuState:
             self.samples.append((time.perf_counter(), self._read("freq1_input") / 1e6, self._read("power1_input") / 1e6))
             time.sleep(0.002)
 
+    def _partition(self):
+        """compute / memory partition mode of the device (SPX / NPS1 ...) and its fabric clock -- static, read once"""
+        out, dev = {}, os.path.dirname(os.path.dirname(self.dir))
+        for key, name in (("compute", "current_compute_partition"), ("memory", "current_memory_partition"), ("fclk", "pp_dpm_fclk"), ("vbios", "vbios_version"), ("unique_id", "unique_id")):
+            try:
+                with open(os.path.join(dev, name)) as f:
+                    out[key] = " ".join(f.read().split())
+            except OSError:
+                out[key] = None
+        return out
+
     def mark(self, t0, t1):
         self.marks.append((t0, t1))
         if self.dir:  # read right behind a region, outside every timed one: memory clock, junction / HBM temperature
@@ -279,6 +290,7 @@ class GpuState:
                 "sclk_mhz": {"median": float(np.median(c)), "min": float(c.min()), "max": float(c.max())},
                 "power_w": {"median": float(np.nanmedian(p)), "min": float(np.nanmin(p)), "max": float(np.nanmax(p))},
                 "sclk_mhz_per_region": per,
+                "partition": self._partition(),
                 "after_each_region": {"mclk_mhz": [round(a[0]) for a in self.after if a[0] == a[0]],
                                       "junction_c": [round(a[1]) for a in self.after if a[1] == a[1]],
                                       "hbm_c": [round(a[2]) for a in self.after if a[2] == a[2]]},
