@@ -982,6 +982,40 @@ def direct_transport_precheck(P, ranks, kw, grid, iters=6):
     return None if ok else (why or "failed on another rank")
 
 
+def direct_transport_sandbox(P, ranks, kw, grid, timeout=240):
+    """The same check as direct_transport_precheck, one step earlier and somewhere safer: in a CHILD process of every rank
+    (sobfu_amd/ipc_probe.py).  A transport that stores into other GPUs' memory from inside a kernel fails, when the mapping is not
+    what it looks like, with a GPU memory fault -- which kills the process that launched the kernel.  The children take that risk;
+    the ranks themselves only learn the verdict.  Returns None when every rank's child exited 0, else a reason (collective)."""
+    import json
+    import os
+    import subprocess
+
+    from ._lib import ROOT
+
+    if os.environ.get("SOBFU_TILED_SANDBOX", "1") != "1":
+        return None
+    args = dict(addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), port=int(os.environ.get("MASTER_PORT", "29500")) + 23, grid=list(grid),
+                dims=list(P["dims"]), vs=[float(v) for v in P["vs"]], trunc=float(P["trunc"]), eta=float(P["eta"]), kw=kw, iters=4, timeout=int(os.environ.get("SOBFU_PROBE_TIMEOUT_S", "90")))
+    # the children rendezvous among themselves: without the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE would make rank 0's
+    # child a client of a store nobody serves on that port)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["SOBFU_PROBE_ARGS"] = json.dumps(args)
+    ok, why = False, None
+    try:
+        r = subprocess.run([sys.executable, "-m", "sobfu_amd.ipc_probe"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        ok = r.returncode == 0
+        if not ok:
+            tail = " | ".join((r.stderr or r.stdout or "").strip().splitlines()[-3:])
+            why = f"sandboxed probe exited {r.returncode}: {tail[-400:]}"
+    except subprocess.TimeoutExpired:
+        why = f"sandboxed probe did not finish in {timeout} s"
+    except OSError as e:
+        why = f"sandboxed probe could not start: {e!r}"
+    all_ok = ranks.min([1 if ok else 0])[0] == 1
+    return None if all_ok else (why or "sandboxed probe failed on another rank")
+
+
 def autotune_grid(P, ranks, kw, iters=40, transport="rccl"):
     """us per iteration of the native loop for every candidate tile grid on the machine at hand (MAX over ranks: all agree)"""
     from . import ops
@@ -1046,7 +1080,10 @@ def _bench_tiled_once(args, P, ranks, timed_regions, want, plain=False):
     # iterations before anything is timed); otherwise every rank falls back to "rccl" and the line says why
     transport_name, fallback = ("rccl" if want != "direct" else "direct"), None
     if native and transport_name == "direct":
-        fallback = direct_transport_precheck(P, ranks, kw, parse_grid("" if spec == "auto" else spec, world))
+        probe_grid = parse_grid("" if spec == "auto" else spec, world)
+        fallback = direct_transport_sandbox(P, ranks, kw, probe_grid)  # first in child processes (a GPU fault there costs nothing) ...
+        if fallback is None:
+            fallback = direct_transport_precheck(P, ranks, kw, probe_grid)  # ... then in this one
         if fallback is not None:
             print(f"[rank {rank}] direct transport not used: {fallback}", file=sys.stderr, flush=True)
             transport_name = "rccl"

@@ -106,3 +106,12 @@ def test_gpus_n_explicit_tiles_and_threshold():
     d = run_bench("--gpus", "4", "--tiles", "2x2x1", "--steps", "5", "--warmup", "1", "--dim", "64", "--repeats", "2",
                   env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})
     assert d["tiles"]["grid"] == [2, 2, 1] and d["tiled_parity_vs_single_gpu"] == "bit-exact"
+
+
+def test_direct_transport_probe_child_dies_falls_back():
+    """the direct transport is first exercised in a CHILD of every rank (sobfu_amd/ipc_probe.py): one child dying the way a GPU
+    memory fault would kill it must cost the run nothing but the transport -- every rank agrees on RCCL and the line says why"""
+    d = run_bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dim", "64", "--repeats", "2",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0", "SOBFU_PROBE_TEST_ABORT": "1", "SOBFU_PROBE_TIMEOUT_S": "20"})
+    assert d["transport"] == "rccl" and "sandboxed probe" in d["transport_fallback"], d
+    assert d["tiled_parity_vs_single_gpu"] == "bit-exact"
