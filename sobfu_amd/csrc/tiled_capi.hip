@@ -91,9 +91,13 @@ constexpr size_t kOwnBlock = (size_t) 8 << 20;
 struct PooledBlock {
     void* ptr;
     size_t bytes;
-    bool uncached, in_use;
+    bool uncached, in_use, has_handle;
+    hipIpcMemHandle_t handle;
 };
 std::vector<PooledBlock> g_pool;
+// The export handle is taken when a block is allocated, and a block the runtime refuses to export is parked for good and
+// replaced by another: hipIpcGetMemHandle now and then answers "invalid argument" for a perfectly ordinary fresh allocation
+// (seen once in ~100 allocations when processes that had used IPC themselves had just exited) -- a second block has always worked.
 int pool_take(void** out, size_t bytes, bool uncached) {
     for (PooledBlock& b : g_pool)
         if (!b.in_use && b.uncached == uncached && b.bytes >= bytes) {
@@ -101,21 +105,31 @@ int pool_take(void** out, size_t bytes, bool uncached) {
             *out     = b.ptr;
             return 0;
         }
-    void* p = nullptr;
-    bool unc = uncached;
-    if (uncached && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
-        (void) hipGetLastError();
-        p   = nullptr;
-        unc = false;  // plain device memory if the runtime refuses (the flags are polled with system-scope loads either way)
+    for (int attempt = 0;; ++attempt) {
+        void* p = nullptr;
+        if (uncached && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void) hipGetLastError();
+            p = nullptr;  // plain device memory if the runtime refuses (the flags are polled with system-scope loads either way)
+        }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return (int) e;
+        }
+        PooledBlock b{p, bytes, uncached, true, false, {}};
+        const hipError_t e = hipIpcGetMemHandle(&b.handle, p);
+        b.has_handle = e == hipSuccess;
+        if (!b.has_handle) (void) hipGetLastError();
+        if (b.has_handle || attempt == 3) {  // (after four refusals the block is used as it is: only the direct transport needs the handle)
+            g_pool.push_back(b);
+            *out = p;
+            return 0;
+        }
+        std::fprintf(stderr, "sobfu_hip: hipIpcGetMemHandle refused a fresh %zu-byte block (%s); parking it and taking another\n", bytes,
+                     hipGetErrorString(e));
+        b.uncached = !uncached;  // never matches a later request of this kind ...
+        b.bytes    = 0;          // ... or of any size
+        g_pool.push_back(b);
     }
-    if (!p) {
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return (int) e;
-    }
-    (void) unc;
-    g_pool.push_back(PooledBlock{p, bytes, uncached, true});
-    *out = p;
-    return 0;
 }
 void pool_give_back(void* p) {
     for (PooledBlock& b : g_pool)
@@ -524,6 +538,11 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
 int sobfu_hip_ipc_export(const void* d_ptr, char handle[64]) {
     SOBFU_CHECK_ARGS(d_ptr && handle);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    for (const PooledBlock& b : g_pool)  // the library's own blocks were exported when they were allocated
+        if (b.ptr == d_ptr && b.has_handle) {
+            std::memcpy(handle, &b.handle, 64);
+            return 0;
+        }
     hipIpcMemHandle_t h;
     SOBFU_HIP_TRY(hipIpcGetMemHandle(&h, const_cast<void*>(d_ptr)));
     std::memcpy(handle, &h, 64);
