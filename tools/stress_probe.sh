@@ -10,5 +10,5 @@ try:
 except Exception as e:
     print('run $i rc=$rc NO JSON LINE', e)"
   if ! grep -q '"transport": "direct"' /tmp/stress_$i.out; then mkdir -p gpurun_out/stress; cp /tmp/stress_$i.err gpurun_out/stress/run_$i.err; cp /tmp/stress_$i.out gpurun_out/stress/run_$i.out; fi
-  grep -h "refused a fresh" /tmp/stress_$i.err | head -3
+  grep -h "refused a fresh\|trying once more" /tmp/stress_$i.err | cut -c1-700 | head -4
 done
