@@ -67,6 +67,17 @@ def usable_cpus() -> int:
     return n
 
 
+def _load(path):
+    L = C.CDLL(path)
+    L.so_data_energy.restype = C.c_float
+    L.so_reg_energy_sobolev.restype = C.c_float
+    L.so_estimate_psi.restype = C.c_int
+    L.so_sobolev_filter.restype = C.c_int
+    L.so_num_threads.restype = C.c_int
+    L.so_set_num_threads(C.c_int(min(int(L.so_num_threads()), usable_cpus())))
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -74,14 +85,35 @@ def lib():
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
-        _lib = C.CDLL(path)
-        _lib.so_data_energy.restype = C.c_float
-        _lib.so_reg_energy_sobolev.restype = C.c_float
-        _lib.so_estimate_psi.restype = C.c_int
-        _lib.so_sobolev_filter.restype = C.c_int
-        _lib.so_num_threads.restype = C.c_int
-        _lib.so_set_num_threads(C.c_int(min(int(_lib.so_num_threads()), usable_cpus())))
+        _lib = _load(path)
     return _lib
+
+
+def build_mutant(k: int, out_dir: str) -> str:
+    """Negative control (tests/test_oracle_mutants.py): this restatement with ONE deliberate deviation on the hot path
+    (-DSO_MUTANT=k, see the top of sobfu_oracle.c), built into out_dir.  Never loaded by anything but that test."""
+    out = os.path.join(out_dir, f"liboracle_mutant{k}.so")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", f"-DSO_MUTANT={int(k)}",
+                           "-o", out, os.path.join(_HERE, "sobfu_oracle.c"), "-lm"])
+    return out
+
+
+class use_library:
+    """context manager: every function of this module calls the given build of the oracle instead of the regular one"""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.saved, _lib = _lib, _load(self.path)
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def _p(a):

@@ -42,6 +42,17 @@
 #include <omp.h>
 #endif
 
+/* Negative controls for the known-answer tests (tests/test_oracle_mutants.py): -DSO_MUTANT=k builds this restatement with ONE
+ * deliberate deviation from the reference on the hot path; the closed-form suite and the reference's own gtest cases must fail on
+ * every one of them.  0 (the default, the only build anything else uses) is the restatement itself.
+ *   1 the three 1-D passes COMPOSED instead of summed        2 tap S[3+j] instead of S[3-j]      3 lerp operands swapped
+ *   4 upper index g+1 also at coordinate exactly 0           5 psi += u                            6 Laplacian sign
+ *   7 gradient clamps at a face instead of mirroring          8 sqrtf for __fsqrt_rd               9 (phi_global - phi_n o psi)
+ *  10 zero padding instead of clamp-to-edge                  11 weight from the upper corner       12 Laplacian mirrors at a face */
+#ifndef SO_MUTANT
+#define SO_MUTANT 0
+#endif
+
 typedef struct { float x, y; } f2;
 typedef struct { float x, y, z, w; } f4;
 typedef struct { f4 r[4]; } m4;
@@ -61,13 +72,19 @@ static inline float norm_sq4(f4 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
 /* __fsqrt_rd: sqrt rounded toward -inf (utils.hpp:279-281 `norm`) */
 static inline float sqrt_rd(float s) {
     float r = sqrtf(s);
+#if SO_MUTANT != 8
     if (r > 0.f && (double) r * (double) r > (double) s) r = nextafterf(r, -INFINITY);
+#endif
     return r;
 }
 static inline float norm4(f4 v) { return sqrt_rd(norm_sq4(v)); }
 
 /* lerp -- utils.hpp:33-36 : fma(t, v0, fma(-t, v1, v1)), v0 = UPPER sample */
+#if SO_MUTANT == 3
+static inline float lerp1(float v0, float v1, float t) { return fmaf(t, v1, fmaf(-t, v0, v0)); }
+#else
 static inline float lerp1(float v0, float v1, float t) { return fmaf(t, v0, fmaf(-t, v1, v1)); }
+#endif
 static inline f4 lerp4(f4 a, f4 b, float t) {                                                    /* :42-44 */
     return mk4(lerp1(a.x, b.x, t), lerp1(a.y, b.y, t), lerp1(a.z, b.z, t), 0.f);
 }
@@ -77,7 +94,11 @@ static inline void tri_setup(float p, int dim, int *g, int *h, float *frac) {
     float cf = fminf(fmaxf(0.f, p), (float) dim - 1);
     int gi   = (int) floorf(cf);
     int hi   = gi + 1;
+#if SO_MUTANT == 4
+    if (cf == (float) dim - 1) hi--; /* (the top end stays inside the array) */
+#else
     if (cf == 0.f || cf == (float) dim - 1) hi--;
+#endif
     *g    = gi;
     *h    = hi;
     *frac = cf - (float) gi;
@@ -95,7 +116,11 @@ static inline f2 interp_tsdf(const f2 *v, int X, int Y, int Z, float px, float p
                     lerp1(lerp1(v[IDX(gx, hy, hz)].x, v[IDX(gx, hy, gz)].x, c),
                           lerp1(v[IDX(gx, gy, hz)].x, v[IDX(gx, gy, gz)].x, c), b),
                     a);
+#if SO_MUTANT == 11
+    f2 r = {t, v[IDX(hx, hy, hz)].y};
+#else
     f2 r = {t, v[IDX(gx, gy, gz)].y};
+#endif
     return r;
 }
 
@@ -388,12 +413,21 @@ void so_tsdf_gradient(const f2 *vol, f4 *grad, int X, int Y, int Z) {
     for (int z = 0; z < Z; ++z)
         for (int y = 0; y < Y; ++y) {
             int z1 = z + 1, z2 = z - 1;
-            if (z == 0) z2 = z + 1; else if (z == Z - 1) z1 = z - 1;
             int y1 = y + 1, y2 = y - 1;
+#if SO_MUTANT == 7
+            if (z == 0) z2 = z; else if (z == Z - 1) z1 = z;
+            if (y == 0) y2 = y; else if (y == Y - 1) y1 = y;
+#else
+            if (z == 0) z2 = z + 1; else if (z == Z - 1) z1 = z - 1;
             if (y == 0) y2 = y + 1; else if (y == Y - 1) y1 = y - 1;
+#endif
             for (int x = 0; x < X; ++x) {
                 int x1 = x + 1, x2 = x - 1;
+#if SO_MUTANT == 7
+                if (x == 0) x2 = x; else if (x == X - 1) x1 = x;
+#else
                 if (x == 0) x2 = x + 1; else if (x == X - 1) x1 = x - 1;
+#endif
                 float nx = (vol[IDX(x1, y, z)].x - vol[IDX(x2, y, z)].x) / 2.f;
                 float ny = (vol[IDX(x, y1, z)].x - vol[IDX(x, y2, z)].x) / 2.f;
                 float nz = (vol[IDX(x, y, z1)].x - vol[IDX(x, y, z2)].x) / 2.f;
@@ -408,12 +442,21 @@ void so_laplacian(const f4 *psi, f4 *L, int X, int Y, int Z) {
     for (int z = 0; z < Z; ++z)
         for (int y = 0; y < Y; ++y) {
             int z1 = z + 1, z2 = z - 1;
-            if (z == 0 || z == Z - 1) z1 = z2 = z;
             int y1 = y + 1, y2 = y - 1;
+#if SO_MUTANT == 12
+            if (z == 0) z2 = z1; else if (z == Z - 1) z1 = z2;
+            if (y == 0) y2 = y1; else if (y == Y - 1) y1 = y2;
+#else
+            if (z == 0 || z == Z - 1) z1 = z2 = z;
             if (y == 0 || y == Y - 1) y1 = y2 = y;
+#endif
             for (int x = 0; x < X; ++x) {
                 int x1 = x + 1, x2 = x - 1;
+#if SO_MUTANT == 12
+                if (x == 0) x2 = x1; else if (x == X - 1) x1 = x2;
+#else
                 if (x == 0 || x == X - 1) x1 = x2 = x;
+#endif
                 f4 v = mul4(psi[IDX(x, y, z)], -6.f);
                 v    = add4(v, psi[IDX(x1, y, z)]);
                 v    = add4(v, psi[IDX(x2, y, z)]);
@@ -421,7 +464,11 @@ void so_laplacian(const f4 *psi, f4 *L, int X, int Y, int Z) {
                 v    = add4(v, psi[IDX(x, y2, z)]);
                 v    = add4(v, psi[IDX(x, y, z1)]);
                 v    = add4(v, psi[IDX(x, y, z2)]);
+#if SO_MUTANT == 6
+                L[IDX(x, y, z)] = mul4(v, 1.f);
+#else
                 L[IDX(x, y, z)] = mul4(v, -1.f);
+#endif
             }
         }
 }
@@ -469,7 +516,11 @@ void so_potential_gradient(const f2 *phi_n_psi, const f2 *phi_global, const f4 *
     size_t N = (size_t) X * Y * Z;
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < N; ++i) {
+#if SO_MUTANT == 9
+        float d    = phi_global[i].x - phi_n_psi[i].x;
+#else
         float d    = phi_n_psi[i].x - phi_global[i].x;
+#endif
         nabla_U[i] = add4(mul4(grad[i], d), mul4(L[i], w_reg)); /* :31 */
     }
 }
@@ -479,6 +530,14 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 /* one 1-D pass: axis 0 rows (assign, solver.cu:237-293), 1 columns (+=, :309-369), 2 depth (+=, :385-446).
  * sum = 0; for j=-3..3: sum += S[3-j] * src(clamp(i+j))  (solver.cu:283-288, clamp-to-edge :246-271) */
 static void conv_axis(f4 *dst, const f4 *src, const float *S, int X, int Y, int Z, int axis) {
+#if SO_MUTANT == 1 /* columns / depth filter the PREVIOUS pass's result (a composition) instead of adding their own pass over src */
+    f4 *prev = NULL;
+    if (axis != 0) {
+        prev = (f4 *) malloc(sizeof(f4) * (size_t) X * Y * Z);
+        memcpy(prev, dst, sizeof(f4) * (size_t) X * Y * Z);
+        src = prev;
+    }
+#endif
 #pragma omp parallel for collapse(2) schedule(static)
     for (int z = 0; z < Z; ++z)
         for (int y = 0; y < Y; ++y)
@@ -490,13 +549,20 @@ static void conv_axis(f4 *dst, const f4 *src, const float *S, int X, int Y, int 
                     else if (axis == 1) yy = clampi(y + j, 0, Y - 1);
                     else zz = clampi(z + j, 0, Z - 1);
                     f4 v    = src[IDX(xx, yy, zz)];
+#if SO_MUTANT == 10
+                    if ((axis == 0 && xx != x + j) || (axis == 1 && yy != y + j) || (axis == 2 && zz != z + j)) v = mk4(0.f, 0.f, 0.f, 0.f);
+#endif
+#if SO_MUTANT == 2
+                    float s = S[3 + j];
+#else
                     float s = S[3 - j];
+#endif
                     sx += v.x * s;
                     sy += v.y * s;
                     sz += v.z * s;
                 }
                 f4 *d = &dst[IDX(x, y, z)];
-                if (axis == 0) {
+                if (axis == 0 || SO_MUTANT == 1) {
                     *d = mk4(sx, sy, sz, 0.f);
                 } else {
                     d->x += sx;
@@ -504,6 +570,9 @@ static void conv_axis(f4 *dst, const f4 *src, const float *S, int X, int Y, int 
                     d->z += sz;
                 }
             }
+#if SO_MUTANT == 1
+    free(prev);
+#endif
 }
 void so_convolution_rows(f4 *dst, const f4 *src, const float *S, int X, int Y, int Z) { conv_axis(dst, src, S, X, Y, Z, 0); }
 void so_convolution_columns(f4 *dst, const f4 *src, const float *S, int X, int Y, int Z) { conv_axis(dst, src, S, X, Y, Z, 1); }
@@ -516,9 +585,15 @@ void so_update_psi(f4 *psi, const f4 *nabla_U_S, f4 *updates, float alpha, int X
     for (size_t i = 0; i < N; ++i) {
         f4 u       = mul4(nabla_U_S[i], alpha);
         updates[i] = u;
+#if SO_MUTANT == 5
+        psi[i].x += u.x;
+        psi[i].y += u.y;
+        psi[i].z += u.z;
+#else
         psi[i].x -= u.x;
         psi[i].y -= u.y;
         psi[i].z -= u.z;
+#endif
     }
 }
 

@@ -260,10 +260,11 @@ struct Box {
     int zc;                      // marching: planes per march (z-chunk); direct: wx, the lanes of a wave that run along x
     int kind;                    // 0 marching, 1 direct
     int wpg;                     // direct: waves of a workgroup that take cells (the others leave at once) -- see direct_wpg()
+    int rem;                     // marching: the first `rem` z-chunks march zc + 1 planes (an even split of the planes over a chosen NUMBER of chunks)
 };
 struct BoxList {
     int n;
-    int n_march;  // workgroups [0, n_march) belong to marching boxes (listed first), the rest to direct boxes
+    int m0, m1;   // workgroups [m0, m1) belong to marching boxes, the rest to direct boxes
     Box b[kMaxBoxes];
     int first[kMaxBoxes + 1];  // first workgroup of box i; first[n] = workgroups in the launch
 };
@@ -276,6 +277,21 @@ SOBFU_DEV unsigned xcd_swizzle(unsigned t, unsigned nb) {
     const unsigned q = nb / 8u, rem = nb % 8u, xcd = t % 8u, slot = t / 8u;
     return xcd * q + min(xcd, rem) + slot;  // bijective for any nb
 }
+// Position of workgroup t inside a box of n workgroups numbered [first, first + n) in DISPATCH order -- which hands consecutive
+// workgroups to consecutive XCDs -- such that every XCD gets a CONTIGUOUS run of the box's own order (x fastest, then y, then z):
+// the workgroups of a thin box that share cache lines (the same rows one plane up or down, the rows next door) then share an L2
+// too, while the box as a whole stays spread over all eight XCDs and over time exactly as before.
+SOBFU_DEV unsigned box_xcd_order(unsigned t, unsigned first, unsigned n) {
+    const unsigned d = (t - first) % 8u, slot = (t - first) / 8u;  // d: which of the box's eight interleaved streams; same XCD <=> same d
+    unsigned pre = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 7u; ++k)
+        if (k < d) pre += n > k ? (n - k + 7u) / 8u : 0u;  // members of stream k
+    return pre + slot;
+}
+#ifndef SOBFU_BOX_XCD
+#define SOBFU_BOX_XCD 3  // bit 0: push / direct boxes of a tile's pass A, bit 1: direct boxes of pass B take the XCD-contiguous order
+#endif
 // marching geometry of workgroup t inside box b whose first workgroup is `first` (all scalar)
 SOBFU_DEV TileGeom geom_in_box(const Box& b, unsigned t, int first, const Dims& d, int ty) {
     t -= (unsigned) first;
@@ -287,8 +303,9 @@ SOBFU_DEV TileGeom geom_in_box(const Box& b, unsigned t, int first, const Dims& 
     const unsigned ntu = (unsigned) ((b.x1 - b.x0 + TX - 1) / TX), ntv = (unsigned) ((b.y1 - b.y0 + ty - 1) / ty);
     g.u0 = b.x0 + (int) (t % ntu) * TX;
     g.v0 = b.y0 + (int) ((t / ntu) % ntv) * ty;
-    g.zb = b.z0 + (int) (t / (ntu * ntv)) * b.zc;
-    g.ze = min(g.zb + b.zc, b.z1);
+    const int ck = (int) (t / (ntu * ntv));
+    g.zb = b.z0 + ck * b.zc + min(ck, b.rem);
+    g.ze = min(g.zb + b.zc + (ck < b.rem ? 1 : 0), b.z1);
     return g;
 }
 // the cell of this lane in a DIRECT box; false: the lane has none
@@ -305,15 +322,18 @@ SOBFU_DEV bool direct_cell(const Box& b, unsigned t, int first, int& x, int& y, 
     return z < b.z1 && x < b.x1 && y < b.y1;
 }
 // box of workgroup t (constant indices only: a dynamically indexed by-value argument would be copied to scratch)
-SOBFU_DEV Box find_box(const BoxList& L, unsigned t, int& first) {
+SOBFU_DEV Box find_box(const BoxList& L, unsigned t, int& first, int* count = nullptr) {
     Box b = L.b[0];
     first = 0;
+    int next = L.first[1];
 #pragma unroll
     for (int k = 1; k < kMaxBoxes; ++k)
         if (k < L.n && (int) t >= L.first[k]) {
             b     = L.b[k];
             first = L.first[k];
+            next  = L.first[k + 1];
         }
+    if (count) *count = next - first;
     return b;
 }
 
@@ -619,6 +639,32 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
     }
 }
 
+
+// --- buffer addressing (cache-resident launches) -------------------------------------------------------------------------------
+// A 128-bit buffer resource in SGPRs (base, bytes) + a 32-bit lane byte offset + a scalar byte offset (the plane): an address costs
+// no vector instruction and no 64-bit lane register pair.  Arrays below 4 GiB only (checked at launch).
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
+SOBFU_DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) bytes, 0x00020000);
+}
+// nt: the streaming (nontemporal) hint, bit 1 of the cache-policy operand on gfx94x / gfx950
+SOBFU_DEV float4 buf_ld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool nt = false) {
+    const v3u t = nt ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 2) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
+}
+SOBFU_DEV float buf_ld1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int) voff, (int) soff, 0));
+}
+SOBFU_DEV void buf_st3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float4& v, bool nt = false) {
+    const v3u t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+    if (nt) __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) voff, (int) soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) voff, (int) soff, 0);
+}
+SOBFU_DEV void buf_st1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float v, bool nt = false) {
+    if (nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int) voff, (int) soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int) voff, (int) soff, 0);
+}
+
 template <int RPT, int WY, bool COMPACT, int NTL>
 __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
     const GateRegs gate = gate_load(a.c.prev_slots, 1);
@@ -731,14 +777,17 @@ __global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePas
     if (!push_wg) t = (unsigned) L.n_push_wgs + xcd_swizzle(t - (unsigned) L.n_push_wgs, nb - (unsigned) L.n_push_wgs);
     Box b     = L.b[0].b;
     PushDst pd = L.b[0].push;
-    int first = 0;
+    int first = 0, next = L.first[1];
 #pragma unroll
     for (int k = 1; k < kMaxTileBoxes; ++k)
         if (k < L.n && (int) t >= L.first[k]) {
             b     = L.b[k].b;
             pd    = L.b[k].push;
             first = L.first[k];
+            next  = L.first[k + 1];
         }
+    // inside a push box every XCD takes a contiguous run of the box's cells (see box_xcd_order)
+    if (push_wg && (SOBFU_BOX_XCD & 1)) t = (unsigned) first + box_xcd_order(t, (unsigned) first, (unsigned) (next - first));
     const int tid = threadIdx.x + blockDim.x * threadIdx.y;
     // the max-norm of the previous iteration, made global without a collective (workgroup 0 is a push workgroup: the signal
     // below covers these stores)
@@ -927,14 +976,18 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
         const int gu = min(max(u0 - R + lc, 0), tg.DU - 1), gv = min(max(v0 - R + lr, 0), tg.DV - 1);
         h_off[k] = (uint32_t) ((size_t) gu + (size_t) gv * sv) * VB;
     }
-    auto nU_plane = [&](int z) { return (const char*) a.nU + (size_t) min(max(z, 0), d.z - 1) * plane * VB; };
+    // buffer addressing: a resource per array (SGPRs), the lane's 32-bit byte offset in the plane, the plane as a scalar byte offset
+    const uint32_t plane4 = (uint32_t) plane * TB, cells = (uint32_t) plane * (uint32_t) d.z;
+    const __amdgpu_buffer_rsrc_t r_nu = buf_rsrc(a.nU, cells * VB), r_psi = buf_rsrc(a.psi, cells * VB), r_out = buf_rsrc(a.psi_out, cells * VB),
+                                 r_f = buf_rsrc(a.pnp, cells * TB);
+    auto nU_plane = [&](int z) { return 3u * (uint32_t) min(max(z, 0), d.z - 1) * plane4; };
     // prologue: planes zb-3 .. zb+3 and the halo of plane zb, staged at once
     float4 q[7], hq[TPW];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) q[k] = ldvb<true>(nU_plane(zb - 3 + k), off);
+    for (int k = 0; k < 7; ++k) q[k] = buf_ld3(r_nu, off, nU_plane(zb - 3 + k));
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
-        if (h_on[k]) hq[k] = ldvb<true>(nU_plane(zb), h_off[k]);
+        if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(zb));
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
     tile[0][wy + R][lx + R] = q[3];
 #pragma unroll
@@ -944,15 +997,15 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
     float msq = 0.f;
     for (int z = zb; z < ze; ++z) {
         const int buf = (z - zb) & 1;
-        const size_t zcur = (size_t) z * plane;
+        const uint32_t zcur4 = (uint32_t) z * plane4;
         // this step's requests
-        const float4 pv = ldvb<true>((const char*) a.psi + zcur * VB, off, NTL >= 2);
+        const float4 pv = buf_ld3(r_psi, off, 3u * zcur4, NTL >= 2);
         float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
         if (z + 1 < ze) {
-            qn = ldvb<true>(nU_plane(z + 4), off);
+            qn = buf_ld3(r_nu, off, nU_plane(z + 4));
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) hq[k] = ldvb<true>(nU_plane(z + 1), h_off[k]);
+                if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(z + 1));
         }
         Gather8 g;
         if (mine && z > zb) g = gather_issue32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
@@ -984,12 +1037,9 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
         if (mine) {
             if (owned && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
             if (z > zb) {  // apply_kernel (vector_fields.cu:95-98) of the plane before
-                float* fo = (float*) ((char*) a.pnp + (zcur - plane) * TB + (size_t) offT);
-                const float f = gather_finish(g);
-                if (NTL >= 1) __builtin_nontemporal_store(f, fo);
-                else *fo = f;
+                buf_st1(r_f, offT, zcur4 - plane4, gather_finish(g), NTL >= 1);
             }
-            stvb<true>((char*) a.psi_out + zcur * VB, off, p, NTL >= 1);
+            buf_st3(r_out, off, 3u * zcur4, p, NTL >= 1);
         }
         p_prev = p;
         // shift the z pipeline (plain register moves: see the plain march) and stage plane z+1 into the other buffer
@@ -1007,10 +1057,7 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
         }
     }
     if (ze > zb && mine) {  // the last plane's warp
-        float* fo = (float*) ((char*) a.pnp + (size_t) (ze - 1) * plane * TB + (size_t) offT);
-        const float f = interp_tsdf_only32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
-        if (NTL >= 1) __builtin_nontemporal_store(f, fo);
-        else *fo = f;
+        buf_st1(r_f, offT, (uint32_t) (ze - 1) * plane4, interp_tsdf_only32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z), NTL >= 1);
     }
     maxnorm_tail<WY>(msq, a.slots, s_max);
 }
@@ -1034,15 +1081,17 @@ __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B)
     const int lx = threadIdx.x, wy = threadIdx.y;
     // marching workgroups are XCD-swizzled among themselves; direct ones (numbered behind them) keep the dispatch order, which
     // spreads them over all XCDs -- a thin box concentrated on one XCD's 32 CUs is bound by their address units
-    const unsigned wg = (SOBFU_SWIZZLE_B && (!DIRECT_OK || (int) blockIdx.x < a.boxes.n_march))
-                            ? xcd_swizzle(blockIdx.x, (unsigned) (DIRECT_OK ? a.boxes.n_march : a.boxes.first[a.boxes.n])) : blockIdx.x;
-    int first_wg;
-    const Box box = find_box(a.boxes, wg, first_wg);
+    const bool marching_wg = (int) blockIdx.x >= a.boxes.m0 && (int) blockIdx.x < a.boxes.m1;
+    const unsigned wg = (SOBFU_SWIZZLE_B && marching_wg)
+                            ? (unsigned) a.boxes.m0 + xcd_swizzle(blockIdx.x - (unsigned) a.boxes.m0, (unsigned) (a.boxes.m1 - a.boxes.m0)) : blockIdx.x;
+    int first_wg, count_wg;
+    const Box box = find_box(a.boxes, wg, first_wg, &count_wg);
     if (DIRECT_OK && box.kind != 0) {  // a thin box: one lane per cell
         if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
         int x, y, z;
         float msq = 0.f;
-        if (direct_cell(box, wg, first_wg, x, y, z)) msq = pass_b_direct_cell<WRITE_UPDATES, COMPACT, IDX32>(a, x, y, z);
+        const unsigned wd = (SOBFU_BOX_XCD & 2) ? (unsigned) first_wg + box_xcd_order(wg, (unsigned) first_wg, (unsigned) count_wg) : wg;
+        if (direct_cell(box, wd, first_wg, x, y, z)) msq = pass_b_direct_cell<WRITE_UPDATES, COMPACT, IDX32>(a, x, y, z);
         maxnorm_tail<WY>(msq, a.slots, s_max);
         return;
     }
@@ -1424,38 +1473,57 @@ static int direct_groups(const LaunchBox& s, int wx, bool spread) {
 static double box_cells(const LaunchBox& s) {
     return (s.x1 > s.x0 && s.y1 > s.y0 && s.z1 > s.z0) ? (double) (s.x1 - s.x0) * (s.y1 - s.y0) * (s.z1 - s.z0) : 0.0;
 }
-// geometry of one live box; returns its workgroups
-static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env, bool spread) {
+// geometry of one live box; returns its workgroups.  Marching boxes: zc_override > 0 fixes the planes per march; else, when the box's
+// xy tiles fit the share of the chip it gets (`even`: launches that are one resident round -- multi-GPU tiles, cache-resident grids),
+// the planes are split EVENLY over as many chunks as fill that share (chunk lengths differ by at most one plane: a launch of one
+// round lasts as long as its longest march); else the cost model picks a chunk length (pick_zc).
+static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env, bool spread, bool even = false,
+                      const char* env_nch = nullptr) {
     b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
     b.kind = s.direct ? 1 : 0;
     b.wpg = SOBFU_WY;
+    b.rem = 0;
     if (s.direct) {
         b.zc  = direct_wx(s.x1 - s.x0);
         b.wpg = direct_wpg(b.zc, spread);
         return direct_groups(s, b.zc, spread);
     }
     const int eu = s.x1 - s.x0, ev = s.y1 - s.y0, nz = s.z1 - s.z0;
+    const int tiles = ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty);
+    int nch = 0;
+    if (const char* e = env_nch ? getenv(env_nch) : nullptr) nch = atoi(e);  // tuning override: number of chunks
+    if (nch <= 0 && zc_override <= 0 && !getenv(env) && even && tiles <= share) nch = std::max(share / tiles, 1);
+    if (nch > 0 && zc_override <= 0) {
+        nch   = std::min(nch, std::max(nz / 2, 1));  // a march of one plane is all prologue
+        b.zc  = nz / nch;
+        b.rem = nz % nch;
+        return tiles * nch;
+    }
     b.zc = zc_override > 0 ? std::min(zc_override, nz) : pick_zc(eu, ev, nz, ty, share, refill, env);
-    return ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty) * ((nz + b.zc - 1) / b.zc);
+    return tiles * ((nz + b.zc - 1) / b.zc);
 }
 // Fills the launch geometry of a box list: z-chunk per marching box (cost model above, the chip's capacity shared between the
 // marching boxes; direct boxes are one short round trip and take no share) and the workgroup prefix -- marching boxes first.
 // Returns the workgroups.
-static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env) {
+static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env,
+                        const char* env_nch = nullptr, bool even = false) {
     L.n = 0;
     int live = 0;
     for (int i = 0; i < n; ++i) live += (box_cells(boxes[i]) > 0 && !boxes[i].direct) ? 1 : 0;
     int total = 0;
+    L.m0 = L.m1 = 0;
     for (int pass = 0; pass < 2; ++pass) {
+        const bool direct_pass = pass == 1;  // marching boxes first
+        if (!direct_pass) L.m0 = total;
         for (int i = 0; i < n && L.n < kMaxBoxes; ++i) {
-            if (box_cells(boxes[i]) == 0 || boxes[i].direct != (pass == 1)) continue;
+            if (box_cells(boxes[i]) == 0 || boxes[i].direct != direct_pass) continue;
             // the chip's workgroup slots are shared equally between the marching boxes (the two plane ranges of an overlapped slab
             // schedule): a thin range is latency-critical, so it gets as many short marches as the big one gets long ones
             L.first[L.n] = total;
-            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env, true);
+            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env, true, even, env_nch);
             ++L.n;
         }
-        if (pass == 0) L.n_march = total;
+        if (!direct_pass) L.m1 = total;
     }
     for (int k = L.n; k <= kMaxBoxes; ++k) L.first[k] = total;
     return total;
@@ -1537,9 +1605,11 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     // Cache; the pipelined march where the launch is latency-bound (cache-resident sizes; SOBFU_PIPE_B=0/1 overrides)
     const bool resident = cache_resident(X, Y, Z);
     const char* pipe_e = getenv("SOBFU_PIPE_B");
-    const bool pipe = compact && idx32 && !updates && (pipe_e ? atoi(pipe_e) != 0 : resident);
+    const bool pipe = compact && idx32 && !updates && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32) && (pipe_e ? atoi(pipe_e) != 0 : resident);  // (buffer addressing: arrays below 4 GiB)
     // workgroups a CU holds: <= 80 VGPR (launch bounds) and 32 - 48 KB LDS: 3 of 8 waves; the pipelined march (<= 128 VGPR): 2
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B");
+    // cache-resident launches are ONE resident round of workgroups, which lasts as long as its longest march: the planes are
+    // split evenly over as many z-chunks as fill the marching workgroups' share of the chip
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B", "SOBFU_NCH_B", resident && pipe);
     if (groups == 0) return 0;
     bool direct = false;
     int zc_max = 0;

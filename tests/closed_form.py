@@ -138,6 +138,48 @@ def fuse_case(max_weight=4.0):
     return g, n, exp, max_weight
 
 
+def lattice_case():
+    """sample points that sit EXACTLY on the lattice at coordinate 0 (include/sobfu/cuda/utils.hpp:61-72: the upper index is g + 1
+    except when the clamped coordinate is exactly 0 or dim - 1, where it is g): the sampler must not touch x = 1 at all.  The plane
+    x = 1 holds +inf, so an implementation that reads it gets 0 * inf = NaN; the expected value is phi(0, y, z) itself, exactly
+    (every lerp has t = 0: fma(0, hi, fma(-0, lo, lo)) = lo)."""
+    x, y, z = grid()
+    phi = 0.25 + 0.015625 * x - 0.03125 * y + 0.0078125 * z
+    phi[:, :, 1] = np.inf
+    psi = np.stack([0.0 * x, y, z], -1)  # every cell samples (0, y, z)
+    exp = np.broadcast_to(phi[:, :, :1], phi.shape)
+    return psi, phi, exp
+
+
+def boundary_case():
+    """the boundary rules of the two differentiators on the FACES of the volume (away from edges), for the quadratic fields of
+    potential_case (all arithmetic exact):
+      TsdfDifferentiator (vector_fields.cu:165-191): the missing neighbour is mirrored -> the component normal to a face is exactly 0,
+          the tangential ones are the central differences;
+      SecondOrderDifferentiator (vector_fields.cu:299-331): on a face both neighbours along the normal are the centre -> that axis
+          contributes nothing: the negative Laplacian there is -(sum of the OTHER axes' second derivatives)."""
+    x, y, z = grid()
+    F = 0.0625 * x * x + 0.125 * y + 0.25 * z * z - 0.5 * z
+    psi = np.stack([x + 0.0625 * x * x, y + 0.125 * y * z + 0.03125 * z * z, z - 0.0625 * x * y + 0.25 * y * y], -1)
+    gradF = np.stack([0.125 * x, 0.125 + 0 * x, 0.5 * z - 0.5], -1)
+    d2 = np.array([[0.125, 0.0, 0.0], [0.0, 0.0, 0.0625], [0.0, 0.5, 0.0]])  # d2[component][axis]: pure second derivatives
+    return F, psi, gradF, d2
+
+
+def maxnorm_case():
+    """Reductor::max_update_norm (reductor.cu:342-456, utils.hpp:279-281): ||u|| = __fsqrt_rd(ux^2 + uy^2 + uz^2), the square root
+    rounded DOWN.  u = (1, 2, 0): sqrt(5) = 2.2360679..., whose nearest float32 lies ABOVE it -- the expected value is one float below
+    what sqrtf returns.  Second-largest norm 2 elsewhere; the arg-max is the voxel's linear index."""
+    X, Y, Z = DIMS
+    u = np.zeros((Z, Y, X, 4), np.float32)
+    at = (Z // 3, Y // 2, X // 4)
+    u[at][:3] = (1.0, 2.0, 0.0)
+    u[1, 2, 3, 0] = 2.0
+    r = np.float32(np.sqrt(5.0))
+    assert float(r) ** 2 > 5.0
+    return u, float(np.nextafter(r, np.float32(0))), float(at[2] + X * (at[1] + Y * at[0]))
+
+
 def check_all(api, S):
     """runs every case through `api`; returns the worst deviations for the record"""
     out = {}
@@ -166,6 +208,14 @@ def check_all(api, S):
     err = np.abs(got[..., 0].astype(np.float64) - exp)
     assert err.max() <= atol and (got[..., 1] == 1).all(), float(err.max())
     out["warp_abs_err"] = float(err.max())
+    # the weight of a warped voxel is that of the LOWER corner, phi(floor(psi)).y (utils.hpp:78-85): every voxel carries its own linear
+    # index as weight (exact below 2^24), so the expected weight is the index of floor(psi)
+    X, Y, Z = DIMS
+    gx, gy, gz = grid()
+    widx = gx + X * (gy + Y * gz)
+    fl = np.floor(psi)
+    got = api.run_apply(phi.astype(np.float32), psi.astype(np.float32), widx.astype(np.float32))
+    assert np.array_equal(got[..., 1].astype(np.float64), fl[..., 0] + X * (fl[..., 1] + Y * fl[..., 2])), "warp weight is not phi(floor(psi)).y"
     F, G, psi, exp, w_reg = potential_case()
     got = api.run_potential_gradient(F.astype(np.float32), G.astype(np.float32), psi.astype(np.float32), w_reg)
     u = interior(ulps(got[..., :3], exp), 1)
@@ -184,4 +234,29 @@ def check_all(api, S):
     got = api.run_fuse(g.astype(np.float32), n.astype(np.float32), mw)
     u = ulps(got, exp)
     assert u.max() <= 1.0, float(u.max())  # (the one inexact quotient, 2.25 / 5, is correctly rounded)
+    # lattice hits at coordinate 0: no read of index 1
+    psi, phi, exp = lattice_case()
+    got = api.run_apply(phi.astype(np.float32), psi.astype(np.float32))
+    assert np.array_equal(got[..., 0], exp.astype(np.float32)), "the sampler touched index 1 at coordinate exactly 0 (or lerp(t = 0) is not the lower sample)"
+    # boundary rules of the two differentiators, face by face
+    F, psi, gradF, d2 = boundary_case()
+    zero = np.zeros_like(F)
+    g = api.run_potential_gradient(F.astype(np.float32), (F - 1.0).astype(np.float32), psi.astype(np.float32), 0.0)  # (F - G) = 1, w_reg = 0: grad F
+    L = api.run_potential_gradient(F.astype(np.float32), F.astype(np.float32), psi.astype(np.float32), 1.0)          # (F - G) = 0, w_reg = 1: -Lap psi
+    lap_full = -d2.sum(1)
+    for ax in range(3):  # array axis of coordinate ax: x -> 2, y -> 1, z -> 0
+        for side in (0, -1):
+            sl = [slice(1, -1)] * 3
+            sl[2 - ax] = side
+            sl = tuple(sl)
+            gf, ef = g[sl][..., :3].astype(np.float64), gradF[sl].copy()
+            ef[..., ax] = 0.0
+            assert np.array_equal(gf, ef), ("gradient on face", ax, side)
+            expL = lap_full + d2[:, ax]  # the normal axis drops out
+            assert np.array_equal(L[sl][..., :3].astype(np.float64), np.broadcast_to(expL, L[sl][..., :3].shape)), ("Laplacian on face", ax, side)
+    del zero
+    # max-norm: square root rounded down, arg-max index
+    u, norm, index = maxnorm_case()
+    got = api.run_max_norm(u)
+    assert got[0] == norm and got[1] == index, (got, norm, index)
     return out

@@ -28,9 +28,9 @@ class OracleApi:
         O.convolution_depth(dst, src, S)
         return dst
 
-    def run_apply(self, phi, psi):
+    def run_apply(self, phi, psi, weight=1.0):
         out = self.O.new_volume(cf.DIMS)
-        self.O.apply(self._vol(phi), out, self._field(psi))
+        self.O.apply(self._vol(phi, weight), out, self._field(psi))
         return out
 
     def run_potential_gradient(self, F, G, psi, w_reg):
@@ -60,6 +60,9 @@ class OracleApi:
         inv = self.O.new_field(cf.DIMS)
         self.O.estimate_inverse(self._field(psi), inv, sweeps)
         return inv
+
+    def run_max_norm(self, updates):
+        return self.O.max_update_norm(np.ascontiguousarray(updates, np.float32))
 
     def run_fuse(self, g, n, max_weight):
         vg, vn = self.O.new_volume(cf.DIMS), self.O.new_volume(cf.DIMS)

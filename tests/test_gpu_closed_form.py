@@ -37,9 +37,9 @@ class HipApi:
         ops.convolution_depth(dst, src, S)
         return dst.cpu().numpy()
 
-    def run_apply(self, phi, psi):
+    def run_apply(self, phi, psi, weight=1.0):
         out = self.ops.new_volume(cf.DIMS)
-        self.ops.apply(self._vol(phi), out, self._field(psi))
+        self.ops.apply(self._vol(phi, weight), out, self._field(psi))
         return out.cpu().numpy()
 
     def run_potential_gradient(self, F, G, psi, w_reg):
@@ -73,6 +73,9 @@ class HipApi:
         inv = self.ops.new_field(cf.DIMS)
         self.ops.estimate_inverse(self._field(psi), inv, sweeps)
         return inv.cpu().numpy()
+
+    def run_max_norm(self, updates):
+        return self.ops.max_update_norm(dev(updates.astype(np.float32)))
 
     def run_fuse(self, g, n, max_weight):
         vg, vn = dev(g.astype(np.float32)), dev(n.astype(np.float32))
