@@ -424,7 +424,8 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes that measure roofline.traffic (N = 1)")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: every rank solves its OWN grid (independent sequences, BASELINE config 5 style: no exchange, weak "
-                         "scaling) instead of the default -- ONE grid cut into N tiles with RCCL halo exchange (strong scaling)")
+                         "scaling) instead of the default -- ONE grid cut into N tiles with a halo exchange per iteration (strong scaling; "
+                         "both transports, peer-mapped stores and RCCL, are timed: bench_tiled.py)")
     ap.add_argument("--tiles", type=str, default="", help="N > 1, strong scaling: tile grid PxxPyxPz (default sobfu_amd.tiled.default_grid: "
                                                          "2x2x2 at N=8, 1x2x2 at N=4, 1x1x2 at N=2), or 'auto': time every grid of N "
                                                          "tiles on this machine before the timed region and keep the fastest")
@@ -437,7 +438,7 @@ def main():
     ap.add_argument("--frame-iters", type=int, default=50, help="solver iterations per frame (MAX_ITER; BASELINE config 3 states 50)")
     args = ap.parse_args()
     if args.frames < 0:
-        args.frames = 5 if (args.gpus == 1 or args.replicas) else 0
+        args.frames = 5 if (args.gpus == 1 or args.replicas) else 4  # tiles: frame 0 + three timed frames of the tiled pipeline
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
 
@@ -460,9 +461,9 @@ def main():
     P = boxing_params(args.dim)
     force_tiled = os.environ.get("SOBFU_FORCE_TILED") == "1"  # exercise the tile path on one GPU (debugging)
     if (world > 1 and not args.replicas) or force_tiled:
-        from sobfu_amd import tiled
+        import bench_tiled
 
-        res = tiled.bench_tiled(args, P, ranks, timed_regions)
+        res = bench_tiled.bench_tiled(args, P, ranks, timed_regions)
     else:
         res = bench_single(args, P, ranks, torch)
         if args.frames >= 2 and not force_tiled:
@@ -555,7 +556,7 @@ def main():
                                 "iterations_per_s_incl_fixed": 50 / s50,
                                 "note": "one whole sobfu_hip_solver_iterate call of 50 iterations (BASELINE config 3's frame): enter the "
                                         "compact format + 50 iterations + max-norm rows to the host + leave, host-synchronised"}
-        for k in ("tiles", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame"):
+        for k in ("tiles", "legs", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame", "topology"):
             if res.get(k):
                 out[k] = res[k]
         if GPU_STATE is not None:

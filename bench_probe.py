@@ -1,10 +1,10 @@
-"""Sandboxed check of the direct transport: `python -m sobfu_amd.ipc_probe`, started by tiled.direct_transport_sandbox() as a CHILD
+"""Sandboxed check of the direct transport: `python bench_probe.py`, started by bench_tiled.direct_transport_sandbox() as a CHILD
 of every rank of a multi-GPU run before the run itself touches the transport.
 
 The direct transport stores into other processes' (other GPUs') memory from inside a kernel.  If peer mapping is not what it looks
 like on a machine, the symptom is not an error code but a GPU memory fault -- which aborts the process.  The children take that
 risk: they rendezvous among themselves (gloo, a port of their own), run a few iterations of the same workload on the same tile
-grid with the direct transport and compare every tile bit for bit with the single-GPU solver (tiled.direct_transport_precheck).
+grid with the direct transport and compare every tile bit for bit with the single-GPU solver (bench_tiled.direct_transport_precheck).
 Exit code 0 on every rank = the transport works here; anything else (a fault, a missed deadline, a mismatch, a child that
 never came up) and the parents run the whole leg on RCCL.  Reads SOBFU_PROBE_ARGS (JSON) and the launcher's RANK / WORLD_SIZE /
 LOCAL_RANK."""
@@ -40,7 +40,8 @@ def main() -> int:
     import torch
     import torch.distributed as dist
 
-    from . import tiled
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_tiled
 
     a = json.loads(os.environ["SOBFU_PROBE_ARGS"])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -52,7 +53,7 @@ def main() -> int:
         os.abort()
     vs = np.array(a["vs"], np.float32)
     P = dict(dims=tuple(a["dims"]), vs=vs, trunc=np.float32(a["trunc"]), eta=np.float32(a["eta"]))
-    why = tiled.direct_transport_precheck(P, _Ranks(torch, dist, rank, world), a["kw"], tuple(a["grid"]), iters=int(a.get("iters", 4)))
+    why = bench_tiled.direct_transport_precheck(P, _Ranks(torch, dist, rank, world), a["kw"], tuple(a["grid"]), iters=int(a.get("iters", 4)))
     if why is not None:
         print(f"direct transport probe, rank {rank}: {why}", file=sys.stderr, flush=True)
     dist.destroy_process_group()

@@ -386,6 +386,20 @@ int sobfu_hip_ipc_open(const char handle[64], void** d_ptr);
 int sobfu_hip_ipc_close(void* d_ptr);
 /* 0, or SOBFU_E_TIMEOUT with the rank that was missing (-1: unknown) */
 int sobfu_hip_tiled_status(sobfu_hip_tiled* t, int* missing_peer);
+/* Iterations ONE solve may run on this handle: the direct transport's max-norm rows are mapped by the peers, so their number is
+ * fixed when the handle is created (16384); other transports grow their rows on demand. */
+int sobfu_hip_tiled_max_iterations(const sobfu_hip_tiled* t);
+/* What the runtime says about the path from `device` to `peer_device`: out = {hipDeviceCanAccessPeer, link type
+ * (hipExtGetLinkTypeAndHopCount: 0 HyperTransport, 1 QPI, 2 PCIe, 3 InfiniBand, 4 xGMI), hops, hipDevP2PAttrPerformanceRank}; -1 = unknown. */
+int sobfu_hip_p2p_info(int device, int peer_device, int out[4]);
+/* Diagnostics of the direct transport (every rank of the world makes the same calls in the same order, outside a solve):
+ *   wait_stats  microseconds the signalling workgroup of pass A has spent waiting for its peers' arrival flags, and how many waits --
+ *               the part of the exchange an iteration did NOT hide behind its own compute
+ *   pingpong    `reps` flag round trips between rank_a and rank_b inside one launch (the other ranks only advance their sequence numbers)
+ *   probe_push  pass A's push boxes alone (the production store path into the peers' halo cells + signalling), `reps` launches */
+int sobfu_hip_tiled_wait_stats(sobfu_hip_tiled* t, double* wait_us, int* waits, int reset);
+int sobfu_hip_tiled_pingpong(sobfu_hip_tiled* t, int rank_a, int rank_b, int reps, void* stream);
+int sobfu_hip_tiled_probe_push(sobfu_hip_tiled* t, int reps, void* stream);
 /* test hooks: wait = 0 turns the in-kernel wait for the peers' flags off (a harness that drives N ranks from ONE process steps
  * them phase by phase with host barriers instead: phase 0 = pass A incl. the pushes, phase 1 = pass B; after the last iteration
  * phase 2 = the end-of-solve handshake, then sobfu_hip_tiled_end) */

@@ -29,6 +29,8 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
 constexpr int kMaxSync = 64;
 struct TileSync {
     uint32_t ticket_push, reserved;    // 0 at rest
+    uint64_t wait_ticks;               // diagnostics: wall_clock64 ticks the signalling workgroup has spent waiting for peers' flags ...
+    uint32_t wait_count, pad0;         // ... over this many waits (sobfu_hip_tiled_wait_stats)
     uint32_t err;                      // 0, or 1 + the rank whose flag did not arrive before the deadline
     uint32_t n_sync;                   // ranks this rank signals and waits for
     uint32_t my_rank, world;
@@ -42,12 +44,22 @@ struct TileSync {
 // sync: device pointer to the handle's TileSync (null: no signalling); seq / wait / row / row_index: see TilePassAArgs
 int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
                        int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact);
+// the same launch planned once (compact format): the box list is uploaded to device memory at plan time, a launch passes ~100 bytes
+struct TilePassAPlan;
+int tile_pass_a_plan_create(TilePassAPlan** out, const TileLaunchBox* boxes, int n, int X, int Y, int Z);
+void tile_pass_a_plan_destroy(TilePassAPlan* p);
+int launch_tile_pass_a_plan(const TilePassAPlan* p, const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, TileSync* sync,
+                            uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream);
 // end of a solve on the direct transport: push the last max-norm row (row may be null), raise the flags with `seq`, wait
 int launch_tile_flush(TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream);
+// diagnostics: `reps` flag round trips between this rank and sync-set member `q` (both sides launch it; `first` serves); sequence
+// numbers seq0 .. seq0 + 2 * reps - 1
+int launch_tile_pingpong(TileSync* sync, int q, int first, uint32_t seq0, int reps, hipStream_t stream);
 int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots, const float taps[7],
                         float alpha, int X, int Y, int Z, int pX, int pY, int pZ, const int own[6], const LaunchBox* boxes, int n,
                         const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact,
-                        float* psi_out = nullptr /* null: update psi in place */, int prev_rows = 1);
+                        float* psi_out = nullptr /* null: update psi in place */, int prev_rows = 1,
+                        bool sys_acquire = false /* the launch reads cells other GPUs stored: invalidate at system scope first */);
 // Pass A / pass B over planes [z_lo, z_hi) (z_hi <= 0: the whole grid) and, optionally, a second range [z_lo2, z_hi2)
 // in the same launch (both boundary regions of a multi-GPU slab).  zc <= 0: z-chunk chosen by the cost model.
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,

@@ -261,6 +261,9 @@ struct Box {
     int kind;                    // 0 marching, 1 direct
     int wpg;                     // direct: waves of a workgroup that take cells (the others leave at once) -- see direct_wpg()
     int rem;                     // marching: the first `rem` z-chunks march zc + 1 planes (an even split of the planes over a chosen NUMBER of chunks)
+    int pair;                    // marching, pass B: z-chunks march in alternating directions (even chunks top-down, odd ones bottom-up), so that
+                                 // two neighbours start at -- or arrive at -- their common boundary TOGETHER: the 6 planes either side of it,
+                                 // which both read, are fetched once where the two share an XCD (and its L2) instead of a march apart
 };
 struct BoxList {
     int n;
@@ -272,6 +275,7 @@ struct TileGeom {
     int u0, v0, zb, ze;  // tile origin along x / y, planes [zb, ze) of this march
     int u_hi, v_hi;      // cells with x >= u_hi or y >= v_hi are outside the box (computed, not stored)
     int DU, DV;          // array extents along x / y
+    bool down;           // the march runs from plane ze - 1 down to zb (Box::pair)
 };
 SOBFU_DEV unsigned xcd_swizzle(unsigned t, unsigned nb) {
     const unsigned q = nb / 8u, rem = nb % 8u, xcd = t % 8u, slot = t / 8u;
@@ -306,6 +310,7 @@ SOBFU_DEV TileGeom geom_in_box(const Box& b, unsigned t, int first, const Dims& 
     const int ck = (int) (t / (ntu * ntv));
     g.zb = b.z0 + ck * b.zc + min(ck, b.rem);
     g.ze = min(g.zb + b.zc + (ck < b.rem ? 1 : 0), b.z1);
+    g.down = b.pair != 0 && (ck & 1) == 0;
     return g;
 }
 // the cell of this lane in a DIRECT box; false: the lane has none
@@ -700,16 +705,6 @@ struct TileBoxList {
     TileBox b[kMaxTileBoxes];
     int first[kMaxTileBoxes + 1];
 };
-struct TilePassAArgs {
-    PassACore c;
-    TileBoxList boxes;
-    TileSync* sync;          // null: no signalling (single-box launches, RCCL / callback transports)
-    uint32_t seq;            // sequence number of this iteration
-    int wait;                // the last workgroup waits for the peers' flags
-    const uint32_t* row;     // this rank's max-norm slot row of the PREVIOUS iteration (null: none) ...
-    uint32_t row_index;      // ... which is row `row_index` of the global rows
-};
-
 // ---- stores that leave the GPU ----------------------------------------------------------------------------------------------
 // What travels to a peer (message cells, row maxima, flags) is stored WRITE-THROUGH at system scope (sc0 sc1): it never sits
 // dirty in this GPU's write-back L2, so "everything I sent has arrived" is `s_waitcnt vmcnt(0)` -- the stores' acknowledgements --
@@ -758,6 +753,28 @@ SOBFU_DEV void tile_wait(TileSync* sy, uint32_t seq) {
             }
         }
     }
+    // diagnostics (one lane per launch gets here): how long the launch sat waiting for its peers -- what of the exchange was NOT hidden
+    sy->wait_ticks += wall_clock64() - t0;
+    sy->wait_count += 1u;
+}
+// diagnostics: flag round trips with ONE peer (sync-set member q), `reps` of them inside one launch: the side that serves stores seq,
+// the other answers seq + 1, ...; one lane each.  Both sides observe the same deadline as every other wait.
+__global__ void __launch_bounds__(64) tile_pingpong_kernel(TileSync* sy, int q, int first, uint32_t seq0, int reps) {
+    if (threadIdx.x != 0) return;
+    uint32_t* theirs = sy->peer_flags[q] + sy->my_rank;
+    const uint32_t* mine = sy->my_flags + sy->sync_rank[q];
+    const uint64_t t0 = wall_clock64();
+    for (int r = 0; r < reps; ++r) {
+        const uint32_t s_ping = seq0 + 2u * (uint32_t) r, s_pong = s_ping + 1u;
+        if (first) st1_system(theirs, s_ping);
+        while ((int32_t) (ld1_system(mine) - (first ? s_pong : s_ping)) < 0) {
+            if (wall_clock64() - t0 > sy->timeout_ticks) {
+                __hip_atomic_store(&sy->err, 1u + (uint32_t) sy->sync_rank[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        if (!first) st1_system(theirs, s_pong);
+    }
 }
 __global__ void __launch_bounds__(64) tile_flush_kernel(TileSync* sy, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index) {
     if (row != nullptr) tile_row_push(sy, row, row_index);
@@ -767,9 +784,29 @@ __global__ void __launch_bounds__(64) tile_flush_kernel(TileSync* sy, uint32_t s
     if (wait) tile_wait(sy, seq);
 }
 
+// the signalling part of a tile launch's arguments
+struct TileSignal {
+    TileSync* sync;       // null: no signalling (single-box launches, RCCL / callback transports)
+    uint32_t seq;         // sequence number of this iteration
+    int wait;             // the last workgroup waits for the peers' flags
+    const uint32_t* row;  // this rank's max-norm slot row of the PREVIOUS iteration (null: none) ...
+    uint32_t row_index;   // ... which is row `row_index` of the global rows
+};
+// the same launch with its box list in DEVICE memory (a list is fixed for the life of a handle: uploaded once, read through the scalar
+// cache) instead of in the kernel-argument segment: a 1.5 KB argument block costs a launch 0.6 us (tools/calib/launch_cost.hip:
+// 2.9 -> 3.5 us back to back)
+struct TilePassAArgs {
+    PassACore c;
+    TileBoxList boxes;
+    TileSignal s;
+};
+struct TilePassAArgsP {
+    PassACore c;
+    const TileBoxList* boxes;
+    TileSignal s;
+};
 template <int RPT, int WY, bool COMPACT, int NTL>
-__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePassAArgs a) {
-    const TileBoxList& L = a.boxes;
+SOBFU_DEV void tile_potential_gradient_body(const PassACore& core, const TileBoxList& L, const TileSignal& sg) {
     const unsigned nb = (unsigned) L.first[L.n];
     // push workgroups keep their launch order (they go out first); the others are XCD-swizzled among themselves
     unsigned t = blockIdx.x;
@@ -791,38 +828,47 @@ __global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePas
     const int tid = threadIdx.x + blockDim.x * threadIdx.y;
     // the max-norm of the previous iteration, made global without a collective (workgroup 0 is a push workgroup: the signal
     // below covers these stores)
-    if (a.sync != nullptr && a.row != nullptr && blockIdx.x == 0 && threadIdx.y == 0) tile_row_push(a.sync, a.row, a.row_index);
+    if (sg.sync != nullptr && sg.row != nullptr && blockIdx.x == 0 && threadIdx.y == 0) tile_row_push(sg.sync, sg.row, sg.row_index);
     if (b.kind != 0) {
         int x, y, z;
         if (direct_cell(b, t, first, x, y, z)) {
-            const float4 o = pass_a_direct_cell<COMPACT>(a.c, x, y, z);
+            const float4 o = pass_a_direct_cell<COMPACT>(core, x, y, z);
             if (pd.base != nullptr) {
                 const size_t i = (size_t) (x + pd.ox) + (size_t) pd.px * ((size_t) (y + pd.oy) + (size_t) pd.py * (size_t) (z + pd.oz));
                 st3_system(pd.base + 3 * i, o);  // messages are always 12-byte cells
             } else {
-                stv<COMPACT>(a.c.nU, vidx(a.c.d, x, y, z), o);
+                stv<COMPACT>(core.nU, vidx(core.d, x, y, z), o);
             }
         }
     } else {
         GateRegs gate;
 #pragma unroll
         for (int k = 0; k < 8; ++k) gate.v[k] = 0xffffffffu;  // pass A of a tile writes scratch only: never gated
-        pass_a_march<RPT, WY, COMPACT, NTL, true>(a.c, geom_in_box(b, t, first, a.c.d, RPT * WY), gate, &pd);
+        pass_a_march<RPT, WY, COMPACT, NTL, true>(core, geom_in_box(b, t, first, core.d, RPT * WY), gate, &pd);
     }
-    if (a.sync == nullptr || !push_wg) return;
+    if (sg.sync == nullptr || !push_wg) return;
     // the push workgroups count themselves out; the LAST one raises this rank's flag at its peers and then waits for theirs: a
     // launch retires when all its workgroups have, so pass B cannot start before every neighbour's cells have landed -- while the
     // owned block's workgroups never touch the synchronisation at all
-    TileSync* sy = a.sync;
+    TileSync* sy = sg.sync;
     stores_acknowledged();  // every lane: what it stored at the peers has arrived ...
     __syncthreads();        // ... before lane 0 takes the workgroup's ticket
     if (tid != 0) return;
     const uint32_t k = __hip_atomic_fetch_add(&sy->ticket_push, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == (uint32_t) L.n_push_wgs - 1u) {
         __hip_atomic_store(&sy->ticket_push, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tile_signal(sy, a.seq);
-        if (a.wait) tile_wait(sy, a.seq);
+        tile_signal(sy, sg.seq);
+        if (sg.wait) tile_wait(sy, sg.seq);
     }
+}
+
+template <int RPT, int WY, bool COMPACT, int NTL>
+__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePassAArgs a) {
+    tile_potential_gradient_body<RPT, WY, COMPACT, NTL>(a.c, a.boxes, a.s);
+}
+template <int RPT, int WY, bool COMPACT, int NTL>
+__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_planned_kernel(TilePassAArgsP a) {
+    tile_potential_gradient_body<RPT, WY, COMPACT, NTL>(a.c, *a.boxes, a.s);
 }
 
 // --- pass B ----------------------------------------------------------------------------------------------------
@@ -845,8 +891,12 @@ struct PassBArgs {
     int own[6];     // x0, x1, y0, y1, z0, z1
     int prev_rows;  // rows the gate looks at (see solver_converged)
     void* psi_out;  // where the updated psi goes: == psi (in place) or the other half of a ping-pong pair (native tiled loop)
+    int sys_acquire;  // direct transport: halo cells and max-norm entries of this launch's inputs were stored by OTHER GPUs (see the kernel's entry)
 };
 
+#ifndef SOBFU_PAIR_B
+#define SOBFU_PAIR_B 1  // cache-resident launches of the pipelined pass B: z-chunks march in alternating directions (Box::pair)
+#endif
 #ifndef SOBFU_HLEAD
 #define SOBFU_HLEAD 3  // planes the halo requests of pass B run ahead on long marches (0: never; one plane ahead, straight from registers)
 #endif
@@ -940,7 +990,7 @@ SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
 // No request is in flight across the loop's back edge (the compiler would wait for all of them there anyway, to copy the
 // loop-carried registers), one barrier per plane as before (a wave writes buffer b^1 only behind the barrier that followed the
 // last reads of b^1).  Same arithmetic, same bits.
-template <int WY, int NTL>
+template <int WY, int NTL, bool DOWN>
 SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const GateRegs& gate, float4 (*tile)[WY + 6][TX + 8], uint32_t* s_max) {
     constexpr int R = 3, TY = WY;
     constexpr int NXH = (2 * R * TY + TX - 1) / TX, NTASK = 2 * R + NXH, TPW = (NTASK + WY - 1) / WY;
@@ -983,11 +1033,14 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
     auto nU_plane = [&](int z) { return 3u * (uint32_t) min(max(z, 0), d.z - 1) * plane4; };
     // prologue: planes zb-3 .. zb+3 and the halo of plane zb, staged at once
     float4 q[7], hq[TPW];
+    // DOWN: the march runs from the chunk's top plane to its bottom one (see Box::pair); q[k] is plane z - 3 + k either way
+    constexpr int DZ = DOWN ? -1 : 1;
+    const int z_first = DOWN ? ze - 1 : zb, n_steps = ze - zb;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) q[k] = buf_ld3(r_nu, off, nU_plane(zb - 3 + k));
+    for (int k = 0; k < 7; ++k) q[k] = buf_ld3(r_nu, off, nU_plane(z_first - 3 + k));
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
-        if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(zb));
+        if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(z_first));
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
     tile[0][wy + R][lx + R] = q[3];
 #pragma unroll
@@ -995,20 +1048,21 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
         if (h_on[k]) tile[0][h_lr[k]][h_lc[k]] = hq[k];
     float4 p_prev = make_float4(0.f, 0.f, 0.f, 0.f);
     float msq = 0.f;
-    for (int z = zb; z < ze; ++z) {
-        const int buf = (z - zb) & 1;
+    for (int st = 0; st < n_steps; ++st) {
+        const int z = z_first + DZ * st;
+        const int buf = st & 1;
         const uint32_t zcur4 = (uint32_t) z * plane4;
         // this step's requests
         const float4 pv = buf_ld3(r_psi, off, 3u * zcur4, NTL >= 2);
         float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (z + 1 < ze) {
-            qn = buf_ld3(r_nu, off, nU_plane(z + 4));
+        if (st + 1 < n_steps) {
+            qn = buf_ld3(r_nu, off, nU_plane(z + 4 * DZ));
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(z + 1));
+                if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(z + DZ));
         }
         Gather8 g;
-        if (mine && z > zb) g = gather_issue32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
+        if (mine && st > 0) g = gather_issue32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
         __syncthreads();
         // the taps of plane z: x and y from the LDS tile, z from the register planes (sum = 0; ascending j; products not contracted)
         v2f l01 = {0.f, 0.f}, l23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, z01 = {0.f, 0.f}, z23 = {0.f, 0.f};
@@ -1036,20 +1090,29 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
         pin3<2>(p);
         if (mine) {
             if (owned && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
-            if (z > zb) {  // apply_kernel (vector_fields.cu:95-98) of the plane before
-                buf_st1(r_f, offT, zcur4 - plane4, gather_finish(g), NTL >= 1);
+            if (st > 0) {  // apply_kernel (vector_fields.cu:95-98) of the plane of the step before
+                buf_st1(r_f, offT, DOWN ? zcur4 + plane4 : zcur4 - plane4, gather_finish(g), NTL >= 1);
             }
             buf_st3(r_out, off, 3u * zcur4, p, NTL >= 1);
         }
         p_prev = p;
-        // shift the z pipeline (plain register moves: see the plain march) and stage plane z+1 into the other buffer
+        // shift the z pipeline (plain register moves: see the plain march) and stage the next plane into the other buffer
+        if (DOWN) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            q[k] = q[k + 1];
-            asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z));
+            for (int k = 6; k > 0; --k) {
+                q[k] = q[k - 1];
+                asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z));
+            }
+            q[0] = qn;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                q[k] = q[k + 1];
+                asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z));
+            }
+            q[6] = qn;
         }
-        q[6] = qn;
-        if (z + 1 < ze) {
+        if (st + 1 < n_steps) {
             tile[buf ^ 1][wy + R][lx + R] = q[3];
 #pragma unroll
             for (int k = 0; k < TPW; ++k)
@@ -1057,7 +1120,7 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
         }
     }
     if (ze > zb && mine) {  // the last plane's warp
-        buf_st1(r_f, offT, (uint32_t) (ze - 1) * plane4, interp_tsdf_only32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z), NTL >= 1);
+        buf_st1(r_f, offT, (uint32_t) (DOWN ? zb : ze - 1) * plane4, interp_tsdf_only32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z), NTL >= 1);
     }
     maxnorm_tail<WY>(msq, a.slots, s_max);
 }
@@ -1075,6 +1138,12 @@ __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B)
     __shared__ uint32_t s_max[WY];
     __shared__ P3 hfifo[HL > 0 ? HL : 1][HL > 0 ? NTASK * TX : 1];  // 12-byte entries: with the 32 KB tile, 3 workgroups still fit a CU's 160 KB
 
+    // Direct transport: the 4-cell halo rims of nabla_U and the other ranks' entries of the max-norm rows were stored into this GPU's
+    // memory by kernels of OTHER GPUs (write-through at system scope, acknowledged before their arrival flag went out, and the flag
+    // was seen by this rank's pass A before it retired: DESIGN.md section 6.1).  What this launch must not do is serve such a cell from
+    // a line its own caches kept from two iterations ago.  The acquire the runtime attaches to a dispatch is its business; this
+    // kernel does not rely on its scope: every wave invalidates at SYSTEM scope before its first load.
+    if (a.sys_acquire) asm volatile("buffer_inv sc0 sc1" ::: "memory");
     const GateRegs gate = gate_load(a.prev_slots, a.prev_rows);
 
     const Dims d = a.d;
@@ -1097,7 +1166,8 @@ __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B)
     }
     const TileGeom tg = geom_in_box(box, wg, first_wg, d, TY);
     if constexpr (PIPE) {
-        pass_b_march_pipe<WY, NTL>(a, tg, gate, tile, s_max);
+        if (tg.down) pass_b_march_pipe<WY, NTL, true>(a, tg, gate, tile, s_max);
+        else pass_b_march_pipe<WY, NTL, false>(a, tg, gate, tile, s_max);
         return;
     }
     const int u0 = tg.u0, v0 = tg.v0, zb = tg.zb, ze = tg.ze;
@@ -1425,11 +1495,13 @@ namespace sobfu_hip {
 // workgroups (measured at 256^3, pass B: 768 groups = exactly 3 per CU: 166 us; 512 groups: 184 us; 1024: 195 us) and
 // refill = planes re-read when a march starts (2 for pass A, 6 for pass B).  Small grids end up with many short
 // marches, which is what the latency-bound regime wants (64^3: zc = 2 is 1.4x faster than zc = 8).
+static int env_zc(const char* env) {  // tuning override (SOBFU_ZC_A / SOBFU_ZC_B): planes per march, 0 = none
+    const char* e = getenv(env);
+    const int v   = e ? atoi(e) : 0;
+    return v > 0 ? v : 0;
+}
 int pick_zc(int X, int Y, int nz, int ty, int capacity, int refill, const char* env) {
-    if (const char* e = getenv(env)) {  // tuning override
-        int v = atoi(e);
-        if (v > 0) return v < nz ? v : nz;
-    }
+    if (const int v = env_zc(env)) return v < nz ? v : nz;
     const long tiles = (long) ((X + TX - 1) / TX) * ((Y + ty - 1) / ty);
     int best_zc = nz;
     double best = 1e30;
@@ -1477,12 +1549,12 @@ static double box_cells(const LaunchBox& s) {
 // xy tiles fit the share of the chip it gets (`even`: launches that are one resident round -- multi-GPU tiles, cache-resident grids),
 // the planes are split EVENLY over as many chunks as fill that share (chunk lengths differ by at most one plane: a launch of one
 // round lasts as long as its longest march); else the cost model picks a chunk length (pick_zc).
-static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env, bool spread, bool even = false,
-                      const char* env_nch = nullptr) {
+static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env, bool spread, bool even = false) {
     b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
     b.kind = s.direct ? 1 : 0;
     b.wpg = SOBFU_WY;
     b.rem = 0;
+    b.pair = 0;
     if (s.direct) {
         b.zc  = direct_wx(s.x1 - s.x0);
         b.wpg = direct_wpg(b.zc, spread);
@@ -1491,8 +1563,7 @@ static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill,
     const int eu = s.x1 - s.x0, ev = s.y1 - s.y0, nz = s.z1 - s.z0;
     const int tiles = ((eu + TX - 1) / TX) * ((ev + ty - 1) / ty);
     int nch = 0;
-    if (const char* e = env_nch ? getenv(env_nch) : nullptr) nch = atoi(e);  // tuning override: number of chunks
-    if (nch <= 0 && zc_override <= 0 && !getenv(env) && even && tiles <= share) nch = std::max(share / tiles, 1);
+    if (zc_override <= 0 && env_zc(env) == 0 && even && tiles <= share) nch = std::max(share / tiles, 1);
     if (nch > 0 && zc_override <= 0) {
         nch   = std::min(nch, std::max(nz / 2, 1));  // a march of one plane is all prologue
         b.zc  = nz / nch;
@@ -1506,10 +1577,17 @@ static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill,
 // marching boxes; direct boxes are one short round trip and take no share) and the workgroup prefix -- marching boxes first.
 // Returns the workgroups.
 static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int capacity, int refill, int zc_override, const char* env,
-                        const char* env_nch = nullptr, bool even = false) {
+                        bool even = false) {
     L.n = 0;
     int live = 0;
-    for (int i = 0; i < n; ++i) live += (box_cells(boxes[i]) > 0 && !boxes[i].direct) ? 1 : 0;
+    bool thin = false;
+    for (int i = 0; i < n; ++i) {
+        live += (box_cells(boxes[i]) > 0 && !boxes[i].direct) ? 1 : 0;
+        thin = thin || (box_cells(boxes[i]) > 0 && boxes[i].direct);
+    }
+    // an even split fills the marching share exactly -- then the thin boxes' workgroups would start only when a march ends, and end the
+    // launch: they keep a sixteenth of the slots (2 x 2 x 2 tile of 256^3: 15 chunks -> 480 + 288 workgroups, 43.0 us; 16 -> 512 + 288, 44.1)
+    if (even && thin) capacity -= capacity / 16;
     int total = 0;
     L.m0 = L.m1 = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -1520,7 +1598,7 @@ static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int c
             // the chip's workgroup slots are shared equally between the marching boxes (the two plane ranges of an overlapped slab
             // schedule): a thin range is latency-critical, so it gets as many short marches as the big one gets long ones
             L.first[L.n] = total;
-            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env, true, even, env_nch);
+            total += finish_box(L.b[L.n], boxes[i], ty, std::max(capacity / std::max(live, 1), 1), refill, zc_override, env, true, even);
             ++L.n;
         }
         if (!direct_pass) L.m1 = total;
@@ -1551,11 +1629,9 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
 
 // Pass A of a multi-GPU tile (see tile_potential_gradient_kernel): the boxes with a destination (push boxes: direct, their
 // result goes to `dst` only) are numbered first, then the others.  sync / seq / wait / row: the direct transport's signalling.
-int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
-                       int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact) {
+// the launch geometry of a tile's pass A: push boxes first; returns the workgroups (< 0: too many boxes)
+static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, int X, int Y, int Z, int zc) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
-    TilePassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, nullptr, 0.f}, {}, sync, seq, wait, row, row_index};
-    TileBoxList& L = a.boxes;
     L.n = 0;
     int live = 0, total = 0;
     for (int i = 0; i < n; ++i) live += (box_cells(boxes[i].box) > 0 && !boxes[i].box.direct && boxes[i].dst == nullptr) ? 1 : 0;
@@ -1563,7 +1639,7 @@ int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, floa
         for (int i = 0; i < n; ++i) {
             const TileLaunchBox& s = boxes[i];
             if ((s.dst != nullptr) != (pass == 0) || box_cells(s.box) == 0) continue;
-            if (L.n >= kMaxTileBoxes) return SOBFU_E_BADARG;
+            if (L.n >= kMaxTileBoxes) return -1;
             TileBox& t = L.b[L.n];
             L.first[L.n] = total;
             // z-chunks: a marching push box (a face with wide rows) marches up to 8 planes; the owned block of a cache-resident
@@ -1579,11 +1655,60 @@ int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, floa
     }
     for (int k = L.n; k <= kMaxTileBoxes; ++k) L.first[k] = total;
     for (int k = L.n; k < kMaxTileBoxes; ++k) L.b[k] = TileBox{};
+    return total;
+}
+
+int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
+                       int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact) {
+    TilePassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, nullptr, 0.f}, {}, {sync, seq, wait, row, row_index}};
+    const int total = fill_tile_boxes(a.boxes, boxes, n, X, Y, Z, zc);
+    if (total < 0) return SOBFU_E_BADARG;
     if (total == 0) return 0;
     const dim3 grid((unsigned) total), block(TX, SOBFU_WY);
     if (compact && cache_resident(X, Y, Z)) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, 0>), grid, block, 0, stream, a);
     else if (compact) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, SOBFU_NT>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, 0>), grid, block, 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+// A PLANNED launch of the same pass (compact format): the box list lives in device memory (built once per handle and half of the
+// nabla_U ping-pong), the kernel arguments shrink from 1.6 KB to ~100 bytes.
+struct TilePassAPlan {
+    TileBoxList* d_boxes = nullptr;
+    int groups = 0, X = 0, Y = 0, Z = 0;
+};
+int tile_pass_a_plan_create(TilePassAPlan** out, const TileLaunchBox* boxes, int n, int X, int Y, int Z) {
+    TileBoxList L{};
+    const int total = fill_tile_boxes(L, boxes, n, X, Y, Z, 0);
+    if (total < 0) return SOBFU_E_BADARG;
+    auto* p = new TilePassAPlan();
+    p->groups = total; p->X = X; p->Y = Y; p->Z = Z;
+    hipError_t e = hipMalloc((void**) &p->d_boxes, sizeof(TileBoxList));
+    if (e == hipSuccess) e = hipMemcpy(p->d_boxes, &L, sizeof(TileBoxList), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        tile_pass_a_plan_destroy(p);
+        return (int) e;
+    }
+    *out = p;
+    return 0;
+}
+void tile_pass_a_plan_destroy(TilePassAPlan* p) {
+    if (!p) return;
+    if (p->d_boxes) (void) hipFree(p->d_boxes);
+    delete p;
+}
+int launch_tile_pass_a_plan(const TilePassAPlan* p, const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, TileSync* sync,
+                            uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream) {
+    if (p->groups == 0) return 0;
+    TilePassAArgsP a{{pnp, pg, psi, nU, {p->X, p->Y, p->Z}, w_reg, nullptr, 0.f}, p->d_boxes, {sync, seq, wait, row, row_index}};
+    const dim3 grid((unsigned) p->groups), block(TX, SOBFU_WY);
+    if (cache_resident(p->X, p->Y, p->Z)) hipLaunchKernelGGL((tile_potential_gradient_planned_kernel<SOBFU_RPT, SOBFU_WY, true, 0>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((tile_potential_gradient_planned_kernel<SOBFU_RPT, SOBFU_WY, true, SOBFU_NT>), grid, block, 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+int launch_tile_pingpong(TileSync* sync, int q, int first, uint32_t seq0, int reps, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_pingpong_kernel, dim3(1), dim3(64), 0, stream, sync, q, first, seq0, reps);
     return (int) hipGetLastError();
 }
 
@@ -1594,10 +1719,11 @@ int launch_tile_flush(TileSync* sync, uint32_t seq, int wait, const uint32_t* ro
 
 int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* pnp, float* updates, uint32_t* slots, const float taps[7],
                         float alpha, int X, int Y, int Z, int pX, int pY, int pZ, const int own[6], const LaunchBox* boxes, int n,
-                        const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, float* psi_out, int prev_rows) {
+                        const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, float* psi_out, int prev_rows,
+                        bool sys_acquire) {
     constexpr int TY = SOBFU_RPT * SOBFU_WY;
     PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, {}, prev_slots, max_update_norm, {pX, pY, pZ},
-                {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi};
+                {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi, sys_acquire ? 1 : 0};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
     const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
@@ -1609,21 +1735,20 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     // workgroups a CU holds: <= 80 VGPR (launch bounds) and 32 - 48 KB LDS: 3 of 8 waves; the pipelined march (<= 128 VGPR): 2
     // cache-resident launches are ONE resident round of workgroups, which lasts as long as its longest march: the planes are
     // split evenly over as many z-chunks as fill the marching workgroups' share of the chip
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B", "SOBFU_NCH_B", resident && pipe);
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B", resident && pipe);
     if (groups == 0) return 0;
     bool direct = false;
     int zc_max = 0;
     for (int i = 0; i < a.boxes.n; ++i) {
         direct = direct || a.boxes.b[i].kind != 0;
         if (a.boxes.b[i].kind == 0) zc_max = std::max(zc_max, a.boxes.b[i].zc);
+        if (a.boxes.b[i].kind == 0 && pipe && resident && SOBFU_PAIR_B) a.boxes.b[i].pair = 1;  // neighbouring z-chunks march towards / away from each other
     }
     const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
 #define SOBFU_LAUNCH_B(UPD, CMP, DIR) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, DIR>), grid, block, 0, stream, a)
 #define SOBFU_LAUNCH_BX(DIR, HLV, NTV, PIP) \
-    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, lds_pad, stream, a)
-    const char* pad_e = getenv("SOBFU_LDS_PAD_B");  // experiment: unused dynamic LDS, to cap the workgroups a CU takes
-    const unsigned lds_pad = pad_e ? (unsigned) atoi(pad_e) : 0u;
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, 0, stream, a)
     if (direct) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);

@@ -40,6 +40,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -77,6 +78,9 @@ struct Rccl {
 } g_rccl;
 
 constexpr int kHalo = 4, kSlots = 256;
+// iterations one solve may run on a handle whose max-norm rows other processes map (direct transport): the rows are part of the arena
+// the peers open once, so their number is fixed at creation (16 MiB)
+constexpr int kRowsIters = 16384;
 constexpr int kSplitAMaxPlanes = 64;  // owned planes up to which pass A is split into boundary + interior launches
 constexpr int kMaxSync = sobfu_hip::kMaxSync;
 // The runtime carves allocations of up to GPU_MAX_SUBALLOC_SIZE (4 MiB by default) out of shared blocks, and hipIpcGetMemHandle
@@ -91,20 +95,27 @@ constexpr size_t kOwnBlock = (size_t) 8 << 20;
 struct PooledBlock {
     void* ptr;
     size_t bytes;
+    int device;
     bool uncached, in_use, has_handle;
     hipIpcMemHandle_t handle;
 };
 std::vector<PooledBlock> g_pool;
+std::mutex g_pool_mutex;
 // The export handle is taken when a block is allocated, and a block the runtime refuses to export is parked for good and
 // replaced by another: hipIpcGetMemHandle now and then answers "invalid argument" for a perfectly ordinary fresh allocation
 // (seen once in ~100 allocations when processes that had used IPC themselves had just exited) -- a second block has always worked.
 int pool_take(void** out, size_t bytes, bool uncached) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int) hipGetLastError();
+    PooledBlock* best = nullptr;  // best fit among the parked blocks of THIS device
     for (PooledBlock& b : g_pool)
-        if (!b.in_use && b.uncached == uncached && b.bytes >= bytes) {
-            b.in_use = true;
-            *out     = b.ptr;
-            return 0;
-        }
+        if (!b.in_use && b.device == dev && b.uncached == uncached && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) {
+        best->in_use = true;
+        *out         = best->ptr;
+        return 0;
+    }
     for (int attempt = 0;; ++attempt) {
         void* p = nullptr;
         if (uncached && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
@@ -115,7 +126,7 @@ int pool_take(void** out, size_t bytes, bool uncached) {
             hipError_t e = hipMalloc(&p, bytes);
             if (e != hipSuccess) return (int) e;
         }
-        PooledBlock b{p, bytes, uncached, true, false, {}};
+        PooledBlock b{p, bytes, dev, uncached, true, false, {}};
         const hipError_t e = hipIpcGetMemHandle(&b.handle, p);
         b.has_handle = e == hipSuccess;
         if (!b.has_handle) (void) hipGetLastError();
@@ -132,6 +143,7 @@ int pool_take(void** out, size_t bytes, bool uncached) {
     }
 }
 void pool_give_back(void* p) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (PooledBlock& b : g_pool)
         if (b.ptr == p) b.in_use = false;
 }
@@ -167,10 +179,6 @@ struct TileLay {
     std::vector<MsgGeom> msgs;
     bool ok = true;
 };
-bool x_pad() {
-    const char* e = std::getenv("SOBFU_TILE_XPAD");
-    return e ? e[0] == '1' : false;
-}
 TileLay make_layout(const int dims[3], const int P[3], int rank) {
     TileLay t;
     const int c[3] = {rank % P[0], (rank / P[0]) % P[1], rank / (P[0] * P[1])};  // x fastest
@@ -183,14 +191,6 @@ TileLay make_layout(const int dims[3], const int P[3], int rank) {
         a.g1   = a.g0 + base + (c[k] < rem ? 1 : 0);
         a.lo   = c[k] > 0 ? kHalo : 0;
         a.hi   = c[k] < P[k] - 1 ? kHalo : 0;
-        // x (the axis rows run along): halo STORAGE is widened so that the owned cells start on a 128-byte boundary and rows are a
-        // multiple of 128 bytes in every field (32 cells: 384 B of a 12-byte field, 128 B of a 4-byte one) -- a wave's row access
-        // then touches 6 + 2 + 2 cache lines instead of 7 + 3 + 3.  Only 4 halo cells per side are ever exchanged or read; the
-        // rest is padding.  Needs neighbours that own at least 32 cells (sobfu_amd.tiled.TileLayout computes the same).
-        if (k == 0 && x_pad() && P[0] > 1 && base >= 64) {
-            if (a.lo) a.lo = 32;
-            if (a.hi) a.hi = kHalo + (32 - (a.lo + (a.g1 - a.g0) + kHalo) % 32) % 32;
-        }
         a.L    = (a.g1 - a.g0) + a.lo + a.hi;
         a.o0   = a.lo;
         a.o1   = a.lo + (a.g1 - a.g0);
@@ -258,7 +258,8 @@ struct sobfu_hip_tiled {
     std::vector<int> sboxes, rboxes;  // 6 ints per message: the cells sent / the halo cells received
     float *sendbuf = nullptr, *recvbuf = nullptr;
     // direct transport (sobfu_hip_tiled_connect): push destinations in the peers, signalling state
-    bool direct = false, dead = false, first_checked = false, dry_packed = false;
+    bool direct = false, dead = false, first_checked = false, dry_packed = false, force_comm = false;
+    int debug_skip = 0;  // timing experiments only (results are wrong): see tiled_step_impl
     int wait_enabled = 1;
     sobfu_hip::TileSync* sync_d = nullptr;
     // what the peers map (direct transport): ONE arena [nabla_U half 0 | half 1 | global max-norm rows ((slots_iters + 2) x 256)] and
@@ -269,6 +270,7 @@ struct sobfu_hip_tiled {
     uint32_t seq_total = 0;                        // sequence numbers used so far (every rank counts the same)
     uint64_t timeout_ticks = 0;                    // deadline of the in-kernel waits (100 MHz ticks; SOBFU_TILED_DEADLINE_S at create)
     std::vector<sobfu_hip::TileLaunchBox> a_boxes[2];  // pass A's boxes per nabla_U half: one push box per message + the owned block
+    sobfu_hip::TilePassAPlan* a_plan[2] = {nullptr, nullptr};  // ... and their launch plans (box lists in device memory)
     int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
     // optional timing of the serial schedule's three pieces with HIP events on the loop's stream (sobfu_hip_tiled_set_profiling)
@@ -306,8 +308,7 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
             sobfu_hip::TileLaunchBox b{};
             // wide rows (y / z faces): a short march costs a fifth of the loads of a lane-per-cell evaluation (1 x 1 x 8 slabs: pass A
             // 26.6 -> 18.4 us); thin in x: direct
-            const char* pm = std::getenv("SOBFU_TILE_PUSH_MARCH");
-            const bool march = (pm ? pm[0] == '1' : true) && (m.sb[1] - m.sb[0]) >= 64;
+            const bool march = (m.sb[1] - m.sb[0]) >= 64;
             b.box = sobfu_hip::LaunchBox{m.sb[0], m.sb[1], m.sb[2], m.sb[3], m.sb[4], m.sb[5], !march};
             float* const* dst = h ? dst1 : dst0;
             if (dst && dst[i]) {  // the matching message of the peer: direction -dir; its receive box is where these cells live there
@@ -326,9 +327,11 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
             v.push_back(b);
         }
         sobfu_hip::TileLaunchBox own{};
-        const char* ad = std::getenv("SOBFU_TILE_A_DIRECT");  // experiment: the owned block lane per cell too
-        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], ad && ad[0] == '1'};
+        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], false};
         v.push_back(own);
+        sobfu_hip::tile_pass_a_plan_destroy(t->a_plan[h]);
+        t->a_plan[h] = nullptr;
+        if (sobfu_hip::tile_pass_a_plan_create(&t->a_plan[h], v.data(), (int) v.size(), t->L[0], t->L[1], t->L[2]) != 0) t->a_plan[h] = nullptr;
     }
 }
 
@@ -392,6 +395,7 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     if (t->grows_own) (void) hipFree(t->grows_own);
     if (t->flags) pool_give_back(t->flags);
     if (t->sync_d) (void) hipFree(t->sync_d);
+    for (int h = 0; h < 2; ++h) sobfu_hip::tile_pass_a_plan_destroy(t->a_plan[h]);
     for (hipEvent_t e : t->prof_ev) (void) hipEventDestroy(e);
     if (t->sendbuf) (void) hipFree(t->sendbuf);
     if (t->recvbuf) (void) hipFree(t->recvbuf);
@@ -426,8 +430,13 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
         t->o0[a] = lay.a[a].o0; t->o1[a] = lay.a[a].o1; t->base[a] = lay.a[a].base;
     }
     t->slab = Px == 1 && Py == 1;
+    // bring-up / timing settings of this handle, read once ("environment")
     const char* dp = std::getenv("SOBFU_TILED_DRY_PACKED");
     t->dry_packed = dp && dp[0] == '1';
+    const char* fc = std::getenv("SOBFU_TILED_FORCE_COMM");
+    t->force_comm = fc && fc[0] == '1';
+    const char* ds = std::getenv("SOBFU_TILED_DEBUG_SKIP");
+    t->debug_skip = ds ? std::atoi(ds) : 0;
     t->z0 = t->g0[2]; t->z1 = t->g1[2]; t->Lz = t->L[2]; t->own_lo = t->o0[2]; t->own_hi = t->o1[2]; t->zbase = t->base[2];
     t->NL = (size_t) t->L[0] * t->L[1] * t->L[2];
     t->NF = (size_t) X * Y * Z;
@@ -458,7 +467,7 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
         t->nu_off[0] = 0;
         t->nu_off[1] = up(t->NL * 12);
         t->rows_off  = t->nu_off[1] + up(t->NL * 12);
-        t->arena_bytes = std::max(t->rows_off + up((size_t) (4096 + 2) * kSlots * 4), kOwnBlock);
+        t->arena_bytes = std::max(t->rows_off + up((size_t) (kRowsIters + 2) * kSlots * 4), kOwnBlock);
         rc = pool_take((void**) &t->arena, t->arena_bytes, false);
         if (rc == 0) {
             t->nUb[0] = (float*) (t->arena + t->nu_off[0]);
@@ -475,9 +484,9 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_f2, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_g, t->NL * 4);
     if (rc == 0) rc = (int) hipMalloc((void**) &t->c_n, t->NF * 4);
-    if (rc == 0) {  // max-norm slot rows for 4096 iterations up front: a solve never reallocates inside a timed region
-        rc = (int) hipMalloc((void**) &t->slots, (size_t) (4096 + 1) * kSlots * 4);
-        if (rc == 0) t->slots_iters = 4096;
+    if (rc == 0) {  // max-norm slot rows for kRowsIters iterations up front: a solve never reallocates inside a timed region
+        rc = (int) hipMalloc((void**) &t->slots, (size_t) (kRowsIters + 1) * kSlots * 4);
+        if (rc == 0) t->slots_iters = kRowsIters;
     }
     if (rc == 0) {
         // arrival flags: written by the peers over xGMI, polled here -- uncached memory, so that neither side's L2 sits between
@@ -501,10 +510,8 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_first, hipEventDisableTiming);
     // the max-norm rows are written by pass B's atomics on this device, but a real RCCL all-reduce may let PEERS write the
     // reduced row straight into this buffer (direct / registered-buffer paths): every event keeps the system-scope fence
-    // until the fence-less variant has been validated on >= 2 real GPUs.  SOBFU_TILED_LOCAL_EVENTS=1 opts into events
-    // without the fence (an L2 write-back + invalidate less per edge) for the row hand-offs.
-    const char* le = std::getenv("SOBFU_TILED_LOCAL_EVENTS");
-    const unsigned local_ev = hipEventDisableTiming | ((le && le[0] == '1') ? hipEventDisableSystemFence : 0u);
+    // (a fence-less variant -- an L2 write-back + invalidate less per edge -- would have to be validated on >= 2 real GPUs first).
+    const unsigned local_ev = hipEventDisableTiming;
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red[0], local_ev);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_red[1], local_ev);
     if (rc == 0) rc = (int) hipEventCreateWithFlags(&t->ev_row, local_ev);
@@ -538,11 +545,14 @@ int sobfu_hip_tiled_create(sobfu_hip_tiled** out, int X, int Y, int Z, int world
 int sobfu_hip_ipc_export(const void* d_ptr, char handle[64]) {
     SOBFU_CHECK_ARGS(d_ptr && handle);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-    for (const PooledBlock& b : g_pool)  // the library's own blocks were exported when they were allocated
-        if (b.ptr == d_ptr && b.has_handle) {
-            std::memcpy(handle, &b.handle, 64);
-            return 0;
-        }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (const PooledBlock& b : g_pool)  // the library's own blocks were exported when they were allocated
+            if (b.ptr == d_ptr && b.has_handle) {
+                std::memcpy(handle, &b.handle, 64);
+                return 0;
+            }
+    }
     hipIpcMemHandle_t h;
     SOBFU_HIP_TRY(hipIpcGetMemHandle(&h, const_cast<void*>(d_ptr)));
     std::memcpy(handle, &h, 64);
@@ -571,6 +581,14 @@ int sobfu_hip_tiled_exports_get(const sobfu_hip_tiled* t, sobfu_hip_tiled_export
 int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ranks, const sobfu_hip_tiled_exports* peers) {
     SOBFU_CHECK_ARGS(t && n_peers >= 0 && (n_peers == 0 || (peer_ranks && peers)) && !t->q.active && !t->comm);
     if (t->world > kMaxSync) return SOBFU_E_UNSUPPORTED;
+    if (t->grows_own) {  // a longer solve on the unconnected handle moved the rows to a private array: back to the exported ones
+        SOBFU_HIP_TRY(hipFree(t->grows_own));
+        if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
+        t->grows_own = t->slots = nullptr;
+        SOBFU_HIP_TRY(hipMalloc((void**) &t->slots, (size_t) (kRowsIters + 1) * kSlots * 4));
+        t->slots_iters = kRowsIters;
+        t->grows       = (uint32_t*) (t->arena + t->rows_off);
+    }
     const int dims[3] = {t->X, t->Y, t->Z};
     auto find = [&](int r) -> const sobfu_hip_tiled_exports* {
         for (int i = 0; i < n_peers; ++i)
@@ -606,6 +624,64 @@ int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ran
     SOBFU_HIP_TRY(hipDeviceSynchronize());
     build_a_boxes(t, d0.data(), d1.data(), pl.data());
     t->direct = true;
+    return 0;
+}
+
+int sobfu_hip_tiled_max_iterations(const sobfu_hip_tiled* t) { return t ? (t->direct ? kRowsIters : 0x7fffffff) : 0; }
+
+int sobfu_hip_p2p_info(int device, int peer_device, int out[4]) {
+    SOBFU_CHECK_ARGS(out && device >= 0 && peer_device >= 0);
+    int can = 0, rank = -1;
+    uint32_t link = 0, hops = 0;
+    out[0] = out[1] = out[2] = out[3] = -1;
+    if (device == peer_device) {
+        out[0] = 1; out[1] = 0; out[2] = 0; out[3] = 0;
+        return 0;
+    }
+    if (hipDeviceCanAccessPeer(&can, device, peer_device) != hipSuccess) (void) hipGetLastError(); else out[0] = can;
+    if (hipExtGetLinkTypeAndHopCount(device, peer_device, &link, &hops) != hipSuccess) (void) hipGetLastError();
+    else { out[1] = (int) link; out[2] = (int) hops; }
+    if (hipDeviceGetP2PAttribute(&rank, hipDevP2PAttrPerformanceRank, device, peer_device) != hipSuccess) (void) hipGetLastError(); else out[3] = rank;
+    return 0;
+}
+
+int sobfu_hip_tiled_wait_stats(sobfu_hip_tiled* t, double* wait_us, int* waits, int reset) {
+    SOBFU_CHECK_ARGS(t);
+    sobfu_hip::TileSync sy;
+    SOBFU_HIP_TRY(hipMemcpy(&sy, t->sync_d, sizeof sy, hipMemcpyDeviceToHost));
+    if (wait_us) *wait_us = (double) sy.wait_ticks / 100.0;  // wall_clock64: 100 MHz
+    if (waits) *waits = (int) sy.wait_count;
+    if (reset) {
+        const uint64_t z[2] = {0, 0};
+        SOBFU_HIP_TRY(hipMemcpy(&t->sync_d->wait_ticks, z, 16, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// diagnostics of a CONNECTED handle outside a solve; every rank of the world makes the same calls in the same order (the sequence
+// numbers of the arrival flags advance in step)
+int sobfu_hip_tiled_pingpong(sobfu_hip_tiled* t, int rank_a, int rank_b, int reps, void* stream) {
+    SOBFU_CHECK_ARGS(t && t->direct && !t->q.active && reps > 0 && rank_a != rank_b && rank_a >= 0 && rank_b >= 0 && rank_a < t->world && rank_b < t->world);
+    if (t->dead) return SOBFU_E_TIMEOUT;
+    const uint32_t seq0 = t->seq_total + 1u;
+    t->seq_total += 2u * (uint32_t) reps;
+    if (t->rank != rank_a && t->rank != rank_b) return 0;
+    const int other = t->rank == rank_a ? rank_b : rank_a;
+    const int q     = other < t->rank ? other : other - 1;  // the sync set lists every other rank in rank order
+    return sobfu_hip::launch_tile_pingpong(t->sync_d, q, t->rank == rank_a ? 1 : 0, seq0, reps, (hipStream_t) stream);
+}
+
+int sobfu_hip_tiled_probe_push(sobfu_hip_tiled* t, int reps, void* stream) {
+    SOBFU_CHECK_ARGS(t && (t->direct || (!t->comm && !t->xfn && !t->dry_packed)) && !t->q.active && reps > 0);  // handles whose pass A signals
+    if (t->dead) return SOBFU_E_TIMEOUT;
+    for (int r = 0; r < reps; ++r) {
+        const uint32_t seq = ++t->seq_total;
+        const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[seq & 1u];
+        if (bx.size() < 2) continue;  // no messages
+        // pass A's push boxes alone, on whatever the compact state holds (the halo rims they fill are scratch between solves)
+        SOBFU_TRY(sobfu_hip::launch_tile_pass_a(t->c_f, t->c_g, t->c_psi, t->nUb[seq & 1u], t->p.w_reg, t->L[0], t->L[1], t->L[2], bx.data(),
+                                                (int) bx.size() - 1, t->sync_d, seq, t->wait_enabled, nullptr, 0, 0, (hipStream_t) stream, true));
+    }
     return 0;
 }
 
@@ -803,7 +879,11 @@ static int tiled_begin(sobfu_hip_tiled* t, const float* d_phi_global_local, cons
     float* P[2] = {t->c_psi, t->c_psi2};
     float* F[2] = {t->c_f, t->c_f2};
     if (max_iters > t->slots_iters) {
-        if (t->direct) return SOBFU_E_UNSUPPORTED;  // the global rows are mapped by the peers: their size is fixed (4096 iterations per solve)
+        if (t->direct) {  // the global rows are mapped by the peers: their number is fixed (sobfu_hip_tiled_max_iterations)
+            std::fprintf(stderr, "sobfu_hip: a solve of %d iterations exceeds the %d the direct transport's peer-mapped max-norm rows hold; "
+                                 "split the solve or use the RCCL transport\n", max_iters, t->slots_iters);
+            return SOBFU_E_UNSUPPORTED;
+        }
         if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
         if (t->grows_own) SOBFU_HIP_TRY(hipFree(t->grows_own));
         t->slots = t->grows_own = nullptr;
@@ -865,10 +945,9 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
     float* P[2] = {t->c_psi, t->c_psi2};
     float* F[2] = {t->c_f, t->c_f2};
     const int n_iters = q.cap;  // the last iteration this solve can reach (rows past cap - 2 gate nothing)
-    // SOBFU_TILED_FORCE_COMM=1 runs the communication choreography (streams, events, empty exchange group, world-1
-    // all-reduce) on a single rank too: bring-up / test hook for 1-GPU machines
-    const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
-    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
+    // (SOBFU_TILED_FORCE_COMM=1 at create runs the communication choreography -- streams, events, empty exchange group, world-1
+    // all-reduce -- on a single rank too: bring-up / test hook for 1-GPU machines)
+    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || t->force_comm;
     const int lo = t->own_lo, hi = t->own_hi, H = kHalo;
     const int a_lo = t->lo[2] ? std::min(lo + H, hi) : lo, a_hi = t->hi[2] ? std::max(hi - H, a_lo) : hi;
     const int b_lo = t->lo[2] ? std::min(lo + 3, hi) : lo, b_hi = t->hi[2] ? std::max(hi - 3, b_lo) : hi;
@@ -878,19 +957,15 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
     const bool tiles = tile_path(t), sync = uses_sync(t);
     // timing experiments only (results are wrong): bit 0 no push boxes, bit 1 no thin shells, bit 2 no pass A, bit 3 no pass B,
     // bit 4 no owned block in pass B, bit 5 no y shells, bit 6 no x shells
-    const char* bd_e = std::getenv("SOBFU_TILE_B_DIRECT");  // experiment: pass B's owned block lane per cell too
-    const bool b_direct = bd_e && bd_e[0] == '1';
-    const char* dbg_e = std::getenv("SOBFU_TILED_DEBUG_SKIP");
-    const int dbg = dbg_e ? std::atoi(dbg_e) : 0;
+    const bool b_direct = false;
+    const int dbg = t->debug_skip;
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
     // the whole pass: an extra launch (+6-7 us per iteration in the compute-only timing at N = 4 and 8), worth it only where
     // the slab is so thin that the 3.1 MB face messages cannot hide behind B_int alone (N >= 4 at 256^3, if a face takes the ~65 us that ~60 GB/s per xGMI direction implies)
-    // the schedule (results do not depend on it): environment (debugging) > sobfu_hip_tiled_set_schedule (autotuner) > heuristic
-    const char* sa = std::getenv("SOBFU_TILED_SPLIT_A");
-    const char* se = std::getenv("SOBFU_TILED_SERIAL");
-    const bool want_split = sa ? sa[0] == '1' : (t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes));
+    // the schedule (results do not depend on it): sobfu_hip_tiled_set_schedule (autotuner, tests) > heuristic
+    const bool want_split = t->schedule == 1 ? true : (t->schedule == 2 ? false : (hi - lo) <= kSplitAMaxPlanes);
     const bool split_a = (t->lo[2] || t->hi[2]) && a_hi > a_lo && want_split;
-    const bool serial = se ? se[0] == '1' : t->schedule == 3;  // z-slab path only
+    const bool serial = t->schedule == 3;  // z-slab path only
     // Where the all-reduce of a max-norm row runs on the RCCL / callback transports (the late gate gives row j until pass B of
     // iteration j+2): in line behind pass B (serial / tile path), on the comm stream behind the next exchange (overlapped slab
     // schedules), or -- opt-in, sobfu_hip_tiled_add_reduce_comm -- on a communicator and stream of its own.
@@ -919,7 +994,7 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
                                                 {ax0 - 1, (xsh && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
                                                 {ax1, (xsh && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
             return sobfu_hip::launch_pass_b_boxes(nu, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y,
-                                                  Z, own, bx, 6, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
+                                                  Z, own, bx, 6, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1, t->direct);
         };
         auto wait_gate = [&]() -> int {  // row it-2 must be global before the first pass-B launch of this iteration
             if (prev && red_issued[it & 1]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[it & 1], 0));
@@ -952,68 +1027,20 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
             // TILE PATH -- pass A's launch carries the exchange (push boxes first).  Direct transport: that is all of it -- the
             // launch retires when the neighbours' cells have landed too.  RCCL / callback: the packed buffer travels, one
             // kernel scatters what arrived.  No cross-stream events anywhere.
-            // OVERLAPPED schedule of the RCCL / callback transports (schedule 1 or 2; SOBFU_TILED_SERIAL=0): the push boxes are a launch of
-            // their own, the packed messages travel and are scattered on the communication stream while the owned block of pass A
-            // and the INTERIOR of pass B (cells whose +-3 taps are all owned) run; the rim of pass B -- up to six slabs, 3 owned cells
-            // + the shell cell thick, which may overlap at tile edges (same inputs, same values) -- follows the exchange:
-            //     A_push -> event -> [comm stream] send / recv, scatter (+ the previous row's all-reduce) -> event
-            //     A_own, B_int                                                   ... meanwhile
-            //     wait(comm) -> B_rim
-            const bool overlap = multi && !sync && phases == 3 && !ev && !dbg && (se ? se[0] == '0' : (t->schedule == 1 || t->schedule == 2)) &&
-                                 !t->msgs.empty();
-            if (overlap) {
-                const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[it & 1];
-                const int nm = (int) t->msgs.size();
-                SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, bx.data(), nm, nullptr, 0, 0, nullptr, 0, 0, st, true));
-                SOBFU_HIP_TRY(hipEventRecord(t->ev_bnd, st));
-                SOBFU_HIP_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_bnd, 0));
-                SOBFU_TRY(exchange_packed(t, nu, t->comm_stream));
-                SOBFU_HIP_TRY(hipEventRecord(t->ev_xchg, t->comm_stream));
-                const bool red_here = can_converge && !t->comm2;  // the row reduction rides behind the exchange, as on z-slabs
-                if (red_here && it >= 2 && it < n_iters && q.red_upto < it - 1) {
-                    const int first = q.red_upto + 1;
-                    SOBFU_TRY(allreduce_max(t, t->slots + (size_t) first * kSlots, (size_t) (it - first) * kSlots, t->comm_stream));
-                    SOBFU_HIP_TRY(hipEventRecord(t->ev_red[(it - 1) & 1], t->comm_stream));
-                    red_issued[(it - 1) & 1] = true;
-                    q.red_upto = it - 1;
-                }
-                SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, &bx.back(), 1, nullptr, 0, 0, nullptr, 0, 0, st, true));
-                SOBFU_TRY(wait_gate());
-                // interior: owned cells at least 3 away from every face that has a neighbour
-                const int ix0 = ax0 + (t->lo[0] ? 3 : 0), ix1 = ax1 - (t->hi[0] ? 3 : 0), iy0 = ay0 + (t->lo[1] ? 3 : 0), iy1 = ay1 - (t->hi[1] ? 3 : 0);
-                const int iz0 = lo + (t->lo[2] ? 3 : 0), iz1 = hi - (t->hi[2] ? 3 : 0);
-                auto Bx = [&](const sobfu_hip::LaunchBox* bxs, int nb) {
-                    return sobfu_hip::launch_pass_b_boxes(nu, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y, Z,
-                                                          own, bxs, nb, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1);
-                };
-                if (ix1 > ix0 && iy1 > iy0 && iz1 > iz0) {
-                    const sobfu_hip::LaunchBox bi[1] = {{ix0, ix1, iy0, iy1, iz0, iz1, false}};
-                    SOBFU_TRY(Bx(bi, 1));
-                }
-                SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_xchg, 0));
-                const bool wide = ax1 - ax0 >= 64;  // rows wide enough for a march
-                const sobfu_hip::LaunchBox br[6] = {
-                    {ax0, ax1, ay0, ay1, t->lo[2] ? lo - 1 : lo, t->lo[2] ? std::min(lo + 3, hi) : lo, false},
-                    {ax0, ax1, ay0, ay1, t->hi[2] ? std::max(hi - 3, lo) : hi, t->hi[2] ? hi + 1 : hi, false},
-                    {ax0, ax1, t->lo[1] ? ay0 - 1 : ay0, t->lo[1] ? std::min(ay0 + 3, ay1) : ay0, lo, hi, !wide},
-                    {ax0, ax1, t->hi[1] ? std::max(ay1 - 3, ay0) : ay1, t->hi[1] ? ay1 + 1 : ay1, lo, hi, !wide},
-                    {t->lo[0] ? ax0 - 1 : ax0, t->lo[0] ? std::min(ax0 + 3, ax1) : ax0, ay0, ay1, lo, hi, true},
-                    {t->hi[0] ? std::max(ax1 - 3, ax0) : ax1, t->hi[0] ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
-                SOBFU_TRY(Bx(br, 6));
-                if (t->comm2) SOBFU_TRY(after_b());  // (own-communicator mode keeps its own reduction point)
-                q.launched = it;
-                if (t->comm && !t->first_checked) SOBFU_TRY(first_iteration_watchdog(t, st));
-                continue;
-            }
             if (phases & 1) {
                 if (ev) SOBFU_HIP_TRY(hipEventRecord(e[0], st));
                 const std::vector<sobfu_hip::TileLaunchBox>& bx = t->a_boxes[it & 1];
                 const bool pushes = (multi || sync) && !(dbg & 1);  // a world of one has no messages
-                if (!(dbg & 4))
-                SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, pushes ? bx.data() : &bx.back(),
-                                                        pushes ? (int) bx.size() : 1, sync ? t->sync_d : nullptr, q.seq_base + (uint32_t) it,
-                                                        t->wait_enabled, (sync && it >= 2) ? t->slots + (size_t) (it - 1) * kSlots : nullptr,
-                                                        (uint32_t) (it - 1), 0, st, true));
+                const uint32_t* row_prev = (sync && it >= 2) ? t->slots + (size_t) (it - 1) * kSlots : nullptr;
+                if (dbg & 4) {
+                } else if (pushes && t->a_plan[it & 1]) {  // the planned launch: box list in device memory
+                    SOBFU_TRY(sobfu_hip::launch_tile_pass_a_plan(t->a_plan[it & 1], f_in, t->c_g, psi_in, nu, p.w_reg, sync ? t->sync_d : nullptr,
+                                                                 q.seq_base + (uint32_t) it, t->wait_enabled, row_prev, (uint32_t) (it - 1), st));
+                } else {
+                    SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, pushes ? bx.data() : &bx.back(),
+                                                            pushes ? (int) bx.size() : 1, sync ? t->sync_d : nullptr, q.seq_base + (uint32_t) it,
+                                                            t->wait_enabled, row_prev, (uint32_t) (it - 1), 0, st, true));
+                }
                 if (ev) SOBFU_HIP_TRY(hipEventRecord(e[1], st));
                 if (multi && !sync) SOBFU_TRY(exchange_packed(t, nu, st));
             }
@@ -1092,8 +1119,8 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
 static int tiled_step(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int phases = 3) {
     const int rc = tiled_step_impl(t, n_steps, st, phases);
     if (rc != 0 && rc != SOBFU_E_BADARG && rc != SOBFU_E_UNSUPPORTED) {
+        abort_comms(t);  // FIRST: the stream may hold an RCCL kernel waiting for a peer this rank will never answer; the abort releases it
         (void) hipStreamSynchronize(st);
-        abort_comms(t);
         t->q.active = false;
     }
     return rc;
@@ -1120,8 +1147,7 @@ static int tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, float*
     float* P[2] = {t->c_psi, t->c_psi2};
     sobfu_hip_solver_report r{};
     r.last_max_update_norm = r.last_max_update_index = r.last_e_data = r.last_e_reg = NAN;
-    const char* force = std::getenv("SOBFU_TILED_FORCE_COMM");
-    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || (force && force[0] == '1');
+    const bool can_converge = p.max_update_norm >= 0.f, multi = t->world > 1 || t->force_comm;
     const bool sync = uses_sync(t);
     const int n_iters = q.launched;
     const uint32_t* rows = t->slots;

@@ -21,8 +21,10 @@ z-slabs overlap E with the interior compute (the kernels take the range of plane
 Halo cells further out are never read.  Clamp / mirror rules act at a tile's array edge, which is the volume boundary exactly
 where the tile has no halo, so the result equals the single-GPU run bit for bit (the max is order-independent).
 
-The kernel backend is pluggable: `HipBackend` (product; C ABI on torch CUDA tensors over RCCL) -- the CPU tests inject an
-oracle-backed backend over gloo to check the decomposition logic without a GPU.
+This module is the PRODUCT side: the tile layout, the native loop's Python handle (NativeTiledSolver: the whole iteration runs in
+C++, sobfu_amd/csrc/tiled_capi.hip), one frame on tiles (estimate_psi_tiled, TiledFusion).  The slow torch.distributed restatement of
+the loop that the CPU tests drive with an oracle backend lives in tests/tiled_reference.py; everything bench.py needs around a
+multi-GPU run (transport probing, grid timing, diagnostics) in bench_tiled.py.
 """
 from __future__ import annotations
 
@@ -37,12 +39,6 @@ import torch.distributed as dist
 
 HALO = 4
 SLOTS = 256
-
-
-def _x_pad():
-    import os
-
-    return os.environ.get("SOBFU_TILE_XPAD", "0") == "1"
 
 
 def default_grid(world):
@@ -94,11 +90,6 @@ class TileLayout:
             g1.append(g0[-1] + base + (1 if c < rem else 0))
             lo.append(halo if c > 0 else 0)
             hi.append(halo if c < grid[a] - 1 else 0)
-            if a == 0 and _x_pad() and grid[0] > 1 and base >= 64:  # aligned rows: see make_layout in csrc/tiled_capi.hip
-                if lo[-1]:
-                    lo[-1] = 32
-                if hi[-1]:
-                    hi[-1] = halo + (32 - (lo[-1] + (g1[-1] - g0[-1]) + halo) % 32) % 32
         self.g0, self.g1, self.lo3, self.hi3 = tuple(g0), tuple(g1), tuple(lo), tuple(hi)
         self.L = tuple(g1[a] - g0[a] + lo[a] + hi[a] for a in range(3))              # local extents
         self.o0 = tuple(lo)                                                           # owned local range [o0, o1)
@@ -184,252 +175,12 @@ class SlabLayout(TileLayout):
             raise ValueError("a slab must own at least `halo` planes")
 
 
-def _cut(t, box):
-    return t[box[4]:box[5], box[2]:box[3], box[0]:box[1]]
-
-
-def halo_ops(layout: TileLayout, fields, group=None):
-    """P2P op list of one exchange (built once per solve: the buffers stay valid while the solve lives).
-    fields: list of (tensor (Lz, Ly, Lx, ...), width).  z-slabs: zero-copy views of the planes.  3-D tiles: staging buffers;
-    returns (ops, pack, unpack) where pack() copies the send boxes out before the ops start and unpack() scatters the received
-    boxes after they finished."""
-    L = layout
-    ops, packs, unpacks = [], [], []
-    for t, w in fields:
-        assert tuple(t.shape[:3]) == L.local_shape() and t.is_contiguous() and 0 < w <= L.halo
-        for peer, sb, rb in L.messages(w):
-            src, dst = _cut(t, sb), _cut(t, rb)
-            if src.is_contiguous() and dst.is_contiguous():
-                ops.append(dist.P2POp(dist.isend, src, peer, group))
-                ops.append(dist.P2POp(dist.irecv, dst, peer, group))
-            else:
-                sbuf, rbuf = torch.empty_like(src, memory_format=torch.contiguous_format), torch.empty_like(dst, memory_format=torch.contiguous_format)
-                packs.append((sbuf, src))
-                unpacks.append((dst, rbuf))
-                ops.append(dist.P2POp(dist.isend, sbuf, peer, group))
-                ops.append(dist.P2POp(dist.irecv, rbuf, peer, group))
-
-    def pack():
-        for buf, view in packs:
-            buf.copy_(view)
-
-    def unpack():
-        for view, buf in unpacks:
-            view.copy_(buf)
-
-    return ops, pack, unpack
-
-
-def start_halo_ops(ops):
-    """One grouped RCCL launch on RCCL's own stream, ordered after everything queued so far on the current stream."""
-    return dist.batch_isend_irecv(ops) if ops else []
-
-
-def finish_halo_ops(works):
-    for w in works:  # for RCCL this only makes the current stream wait; the host does not block
-        w.wait()
-
-
-def run_halo_ops(ops):
-    finish_halo_ops(start_halo_ops(ops))
-
-
-def exchange_halos(layout: TileLayout, fields, group=None):
-    """fields: list of (tensor (Lz, Ly, Lx, ...), width): neighbour exchange of the `width`-cell faces / edge strips."""
-    ops, pack, unpack = halo_ops(layout, fields, group)
-    pack()
-    run_halo_ops(ops)
-    unpack()
-
-
-class _SlabState:
-    """What a backend keeps for one solve: nabla_U (exchanged by the driver) + whatever format it iterates in."""
-
-    def __init__(self, layout, nabla_U):
-        self.layout, self.nabla_U = layout, nabla_U
-
-
-class HipBackend:
-    """Per-tile kernels through the C ABI (include/sobfu_hip.h `sobfu_hip_tile3_*`).
-
-    Iterates in the compact format (12-byte psi / nabla_U, tsdf-only phi_global / phi_n / phi_n o psi -- fewer bytes both
-    through HBM and over xGMI); `begin` converts the caller's API-format arrays, `end` rebuilds them."""
-
-    device = "cuda"
-
-    def __init__(self, compact=True):
-        from . import _lib, ops
-
-        self._lib, self._ops, self.compact = _lib, ops, bool(compact)
-        self._cache = {}
-
-    def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def _call(self, name, *args):
-        self._lib.check(getattr(self._lib.lib(), name)(*args, self._stream()), name)
-
-    @staticmethod
-    def _p(t):
-        return C.c_void_p(t.data_ptr())
-
-    def init_identity(self, psi, layout):
-        self._call("sobfu_hip_tile3_init_identity", self._p(psi), *layout.L, *layout.base)
-
-    def _buf(self, key, shape):
-        t = self._cache.get(key)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.zeros(shape, dtype=torch.float32, device="cuda")
-            self._cache[key] = t
-        return t
-
-    def begin(self, layout, pg_local, pn_full, pnp_local, psi_local):
-        X, Y, Z = layout.dims
-        Lx, Ly, Lz = layout.L
-        st = _SlabState(layout, None)
-        st.pn_full, st.pnp, st.psi = pn_full, pnp_local, psi_local
-        if not self.compact:
-            st.nabla_U = self._buf("nU4", (Lz, Ly, Lx, 4))
-            st.c_psi, st.c_f, st.c_g, st.c_n = psi_local, pnp_local, pg_local, pn_full
-            self._call("sobfu_hip_tile3_apply", self._p(pn_full), X, Y, Z, self._p(pnp_local), self._p(psi_local), Lx, Ly, Lz)
-            return st
-        st.nabla_U = self._buf("nU3", (Lz, Ly, Lx, 3))
-        st.c_psi, st.c_f, st.c_g = self._buf("psi3", (Lz, Ly, Lx, 3)), self._buf("f", (Lz, Ly, Lx)), self._buf("g", (Lz, Ly, Lx))
-        st.c_n = self._buf("n", (Z, Y, X))
-        nl, nf = C.c_size_t(Lz * Ly * Lx), C.c_size_t(Z * Y * X)
-        self._call("sobfu_hip_pack_vec3", self._p(psi_local), self._p(st.c_psi), nl)
-        self._call("sobfu_hip_extract_tsdf", self._p(pg_local), self._p(st.c_g), nl)
-        self._call("sobfu_hip_extract_tsdf", self._p(pn_full), self._p(st.c_n), nf)
-        self._call("sobfu_hip_tile3_apply_tsdf_only", self._p(st.c_n), X, Y, Z, self._p(st.c_f), self._p(st.c_psi), Lx, Ly, Lz)  # solver.cu:106
-        return st
-
-    def pass_a(self, st, box, w_reg, prev_slots, thr, thin=False):
-        """nabla_U on the local cells of `box` = (x0, x1, y0, y1, z0, z1)"""
-        if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0:
-            return
-        prev = self._p(prev_slots) if prev_slots is not None else None
-        self._call("sobfu_hip_tile3_potential_gradient", self._p(st.c_f), self._p(st.c_g), self._p(st.c_psi), self._p(st.nabla_U),
-                   C.c_float(w_reg), *st.layout.L, (C.c_int * 6)(*box), 1 if thin else 0, prev, C.c_float(thr), 1 if self.compact else 0)
-
-    def pass_b(self, st, box, slots, taps, alpha, prev_slots, thr, thin=False):
-        """psi update + warp on the local cells of `box`"""
-        if min(box[1] - box[0], box[3] - box[2], box[5] - box[4]) <= 0:
-            return
-        L = st.layout
-        prev = self._p(prev_slots) if prev_slots is not None else None
-        self._call("sobfu_hip_tile3_smooth_update_apply", self._p(st.nabla_U), self._p(st.c_psi), self._p(st.c_n), self._p(st.c_f), None,
-                   self._p(slots), (C.c_float * 7)(*[float(v) for v in taps[:7]]), C.c_float(alpha), *L.L, *L.dims, (C.c_int * 6)(*L.own_box()),
-                   (C.c_int * 6)(*box), 1 if thin else 0, prev, C.c_float(thr), 1 if self.compact else 0)
-
-    def end(self, st):
-        if not self.compact:
-            return
-        L = st.layout
-        self._call("sobfu_hip_unpack_vec3", self._p(st.c_psi), self._p(st.psi), C.c_size_t(L.L[0] * L.L[1] * L.L[2]))
-        self._call("sobfu_hip_tile3_apply", self._p(st.pn_full), *L.dims, self._p(st.pnp), self._p(st.psi), *L.L)  # state of solver.cu:168
-
-    def sobolev_filter(self, s, lam):
-        return self._ops.sobolev_filter(s, lam)
-
-    def synchronize(self):
-        torch.cuda.synchronize()
-
-
 def _sqrt_rd(m_bits: int) -> float:
     m = np.array([m_bits], np.uint32).view(np.float32)[0]
     r = np.sqrt(m, dtype=np.float32)
     if r > 0 and np.float64(r) * np.float64(r) > np.float64(m):
         r = np.nextafter(r, np.float32(-np.inf), dtype=np.float32)
     return float(r)
-
-
-class TiledSolver:
-    """The gradient-descent loop of sobfu::device::estimate_psi (reference src/sobfu/cuda/solver.cu:106-193) on tiles."""
-
-    def __init__(self, dims, *, alpha, w_reg, s=7, lam=0.1, max_update_norm=-1.0, backend=None, group=None, grid=None):
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.group = group
-        self.backend = backend or HipBackend()
-        self.layout = TileLayout(dims, grid or (1, 1, self.world), self.rank)
-        if self.layout.world != self.world:
-            raise ValueError(f"tile grid {grid} needs {self.layout.world} ranks, the group has {self.world}")
-        self.alpha, self.w_reg, self.thr = float(alpha), float(w_reg), float(max_update_norm)
-        if s < 7:
-            raise ValueError("S < 7 is unsupported (the kernels use 7 taps, reference solver.cu:211-234)")
-        self.taps = np.asarray(self.backend.sobolev_filter(s, lam), np.float32)[:7]
-        self.slots = None
-
-    # -- state helpers ------------------------------------------------------------------------------------------
-    def new_local(self, channels):
-        return torch.zeros(self.layout.local_shape(channels), dtype=torch.float32, device=self.backend.device)
-
-    def identity_psi(self):
-        psi = self.new_local(4)
-        self.backend.init_identity(psi, self.layout)
-        return psi
-
-    def iterate(self, phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters):
-        """Runs n_iters iterations (fewer if the convergence test fires).  Returns (iterations, per-iteration max norms)."""
-        L, be = self.layout, self.backend
-        can_converge = self.thr >= 0.0
-        st = be.begin(L, phi_global_local, phi_n_full, phi_n_psi_local, psi_local)  # includes the warp of solver.cu:106
-        slots = torch.zeros((n_iters + 1, SLOTS), dtype=torch.int32, device=be.device)
-        self.slots = slots
-        xch, pack, unpack = halo_ops(L, [(st.nabla_U, HALO)], self.group) if self.world > 1 else ([], lambda: None, lambda: None)
-        ox, oy = (L.o0[0], L.o1[0]), (L.o0[1], L.o1[1])
-        lo, hi, H = L.own_lo, L.own_hi, HALO
-        b_boxes = L.pass_b_boxes()
-        if L.slab:
-            # z-slabs: planes next to an interior face (sent to the neighbour) vs the rest, so that the exchange overlaps the
-            # interior compute; ranges are local plane indices
-            a_lo = min(lo + H, hi) if L.lo else lo          # [lo, a_lo)  : lower boundary planes of pass A
-            a_hi = max(hi - H, a_lo) if L.hi else hi        # [a_hi, hi)  : upper boundary planes of pass A
-            b_lo = min(lo + 3, hi) if L.lo else lo          # pass B planes >= b_lo have all -3 taps inside the owned range
-            b_hi = max(hi - 3, b_lo) if L.hi else hi
-            b_first = lo - 1 if L.lo else lo                # pass B also refreshes the first halo plane (owned +-1)
-            b_last = hi + 1 if L.hi else hi
-        for it in range(1, n_iters + 1):
-            prev = slots[it - 1] if (it > 1 and can_converge) else None
-            row = slots[it]
-            if L.slab:
-                be.pass_a(st, ox + oy + (lo, a_lo), self.w_reg, prev, self.thr)
-                be.pass_a(st, ox + oy + (a_hi, hi), self.w_reg, prev, self.thr)
-                works = start_halo_ops(xch)
-                be.pass_a(st, ox + oy + (a_lo, a_hi), self.w_reg, prev, self.thr)
-                be.pass_b(st, ox + oy + (b_lo, b_hi), row, self.taps, self.alpha, prev, self.thr)
-                finish_halo_ops(works)
-                be.pass_b(st, ox + oy + (b_first, b_lo), row, self.taps, self.alpha, prev, self.thr)
-                be.pass_b(st, ox + oy + (b_hi, b_last), row, self.taps, self.alpha, prev, self.thr)
-            else:
-                be.pass_a(st, L.own_box(), self.w_reg, prev, self.thr)
-                pack()
-                finish_halo_ops(start_halo_ops(xch))
-                unpack()
-                for box, tr in b_boxes:
-                    be.pass_b(st, box, row, self.taps, self.alpha, prev, self.thr, thin=tr)
-            if self.world > 1 and can_converge:
-                dist.all_reduce(slots[it], op=dist.ReduceOp.MAX, group=self.group)  # the gate needs the GLOBAL max
-        if self.world > 1 and not can_converge:
-            dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=self.group)
-        be.end(st)
-        be.synchronize()
-        mx = slots[1:].max(dim=1).values.cpu().numpy().view(np.uint32)
-        norms = np.array([_sqrt_rd(int(b)) for b in mx], np.float32)
-        done = n_iters
-        if can_converge:
-            for k, v in enumerate(norms):
-                if v <= self.thr:  # solver.cu:183 -- later iterations were device-side no-ops
-                    done = k + 1
-                    break
-        return done, norms[:done]
-
-    def estimate_psi(self, *args, **kw):
-        return estimate_psi_tiled(self, *args, **kw)
-
-    def gather_owned(self, local):
-        """all_gather of the owned cells -> full volume on every rank"""
-        return gather_owned(self.layout, local, self.group)
 
 
 def gather_owned(layout, local, group=None):
@@ -660,6 +411,7 @@ class NativeTiledSolver:
                     _IPC_EXPORTED[ptr] = bytes(h)
                 mine.append(_IPC_EXPORTED[ptr])
             mine.append((e.nabla_u_off[0], e.nabla_u_off[1], e.rows_off))
+            mine.append(int(torch.cuda.current_device()))
         except Exception as ex:  # noqa: BLE001
             err = f"rank {self.rank}: export: {ex!r}"
         allh = [None] * self.world
@@ -667,6 +419,19 @@ class NativeTiledSolver:
         errs = [a[1] for a in allh if a[1]]
         if not errs:
             try:
+                # can this GPU reach every rank it stores to at all?  (asked BEFORE anything is mapped: a missing peer path fails here,
+                # with its reason, and the run takes RCCL -- not later with a memory fault inside a kernel)
+                me = int(torch.cuda.current_device())
+                self.peer_links = {}
+                for q in range(self.world):
+                    if q == self.rank:
+                        continue
+                    info = (C.c_int * 4)()
+                    check(lib.sobfu_hip_p2p_info(C.c_int(me), C.c_int(int(allh[q][0][3])), info), "p2p_info")
+                    self.peer_links[q] = dict(device=int(allh[q][0][3]), can_access=info[0], link_type=info[1], hops=info[2], perf_rank=info[3])
+                    if info[0] == 0:
+                        raise RuntimeError(f"device {me} cannot access device {allh[q][0][3]} of rank {q} as a peer "
+                                           f"(hipDeviceCanAccessPeer = 0, link type {info[1]}, hops {info[2]})")
                 ranks, exps = [], []
                 for q in range(self.world):
                     if q == self.rank:
@@ -698,6 +463,25 @@ class NativeTiledSolver:
         m = C.c_int(-1)
         rc = self._lib.lib().sobfu_hip_tiled_status(self._h, C.byref(m))
         return rc == 0, m.value
+
+    def max_iterations(self):
+        """iterations one solve may run on this handle (the direct transport's peer-mapped max-norm rows are fixed at creation)"""
+        return int(self._lib.lib().sobfu_hip_tiled_max_iterations(self._h))
+
+    # diagnostics of the direct transport (collective: every rank makes the same calls in the same order, outside a solve)
+    def wait_stats(self, reset=True):
+        """(microseconds pass A's signalling workgroup has spent waiting for the peers' arrival flags, number of waits)"""
+        us, n = C.c_double(), C.c_int()
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_wait_stats(self._h, C.byref(us), C.byref(n), C.c_int(1 if reset else 0)), "tiled_wait_stats")
+        return us.value, n.value
+
+    def pingpong(self, rank_a, rank_b, reps):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_pingpong(self._h, C.c_int(rank_a), C.c_int(rank_b), C.c_int(reps),
+                                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tiled_pingpong")
+
+    def probe_push(self, reps):
+        self._lib.check(self._lib.lib().sobfu_hip_tiled_probe_push(self._h, C.c_int(reps), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "tiled_probe_push")
 
     def set_wait(self, wait):
         self._lib.check(self._lib.lib().sobfu_hip_tiled_set_wait(self._h, C.c_int(1 if wait else 0)), "tiled_set_wait")
@@ -783,8 +567,8 @@ class NativeTiledSolver:
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)
 
-    # z-slabs: 1 / 2 = exchange overlapped, pass A split into boundary + interior launches or whole; 3-D tiles: 1 = 2 = push boxes as
-    # their own launch, exchange + scatter on the communication stream beside pass A's owned block and pass B's interior
+    # z-slabs on the RCCL transport: 1 / 2 = exchange overlapped, pass A split into boundary + interior launches or whole; 3-D tiles and
+    # the direct transport have ONE way of issuing an iteration
     SCHEDULES = {1: "overlapped exchange, pass A split", 2: "overlapped exchange, pass A whole", 3: "serial (no overlap, no events)"}
 
     def set_schedule(self, schedule):
@@ -796,7 +580,7 @@ class NativeTiledSolver:
         the fastest; every rank takes part and all agree (MAX over ranks).  Returns {schedule: us per iteration}."""
         pnp, psi = self.new_local(2), self.identity_psi()
         times = {}
-        for sched in (self.SCHEDULES if self.layout.slab else (1, 3)):
+        for sched in (self.SCHEDULES if self.layout.slab else (3,)):
             self.set_schedule(sched)
             self.iterate(phi_global_local, phi_n_full, pnp, psi, 4)
             torch.cuda.synchronize()
@@ -811,464 +595,3 @@ class NativeTiledSolver:
             times[sched] = float(t.item())
         self.set_schedule(min(times, key=times.get))
         return times
-
-
-class GlooTransport:
-    """Transport of a communicator-less native handle over a gloo process group, staged through host memory: lets N ranks that
-    SHARE one GPU (bench.py with SOBFU_BENCH_SHARE_GPU=1, bring-up on a machine with fewer GPUs than ranks -- RCCL refuses two
-    ranks on one device) run the real multi-process tile loop.  Not a performance path."""
-
-    def __init__(self, group=None):
-        self.group = group
-        self.hip = C.CDLL("libamdhip64.so")
-        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-
-    def _ok(self, rc):
-        if rc != 0:
-            raise RuntimeError(f"hip call failed: {rc}")
-
-    def exchange(self, rank, send, recv, msgs, stream):
-        try:
-            self._ok(self.hip.hipStreamSynchronize(stream))
-            ops, bufs = [], []
-            for peer, soff, roff, cnt in msgs:
-                out, inn = torch.empty(cnt, dtype=torch.float32), torch.empty(cnt, dtype=torch.float32)
-                self._ok(self.hip.hipMemcpy(out.data_ptr(), send + 4 * soff, 4 * cnt, 2))
-                ops.append(dist.P2POp(dist.isend, out, peer, self.group))
-                ops.append(dist.P2POp(dist.irecv, inn, peer, self.group))
-                bufs.append((inn, roff, cnt, out))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            for inn, roff, cnt, _ in bufs:
-                self._ok(self.hip.hipMemcpy(recv + 4 * roff, inn.data_ptr(), 4 * cnt, 1))
-            return 0
-        except Exception as e:  # noqa: BLE001
-            print("gloo transport: exchange failed:", repr(e), file=sys.stderr, flush=True)
-            return -1
-
-    def allreduce(self, rank, buf, n, stream):
-        try:
-            self._ok(self.hip.hipStreamSynchronize(stream))
-            h = torch.empty(n, dtype=torch.int32)  # max ||u||^2 bit patterns of non-negative floats order like int32
-            self._ok(self.hip.hipMemcpy(h.data_ptr(), buf, 4 * n, 2))
-            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
-            self._ok(self.hip.hipMemcpy(buf, h.data_ptr(), 4 * n, 1))
-            return 0
-        except Exception as e:  # noqa: BLE001
-            print("gloo transport: allreduce failed:", repr(e), file=sys.stderr, flush=True)
-            return -1
-
-
-def _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks, reps=30, iters=60):
-    """Per-piece timings of the native loop on the machine at hand (microseconds; rank 0's view after a MAX over ranks)."""
-    import os
-
-    L, lib, check = solver.layout, solver._lib.lib(), solver._lib.check
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    out = {}
-
-    def timed(fn, n):
-        fn()
-        torch.cuda.synchronize()
-        ranks.barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return ranks.max([(time.perf_counter() - t0) / n * 1e6])[0]
-
-    direct = solver.transport == "direct"
-    if not direct:  # (the direct transport has no separate exchange step: the stores are part of pass A's launch)
-        field = torch.zeros(L.local_shape(3), dtype=torch.float32, device="cuda")
-        for planes in ((1, 2, HALO) if L.slab else (HALO,)):  # latency vs bandwidth of a face message (z-slabs: 1/4, 1/2 and all of the halo)
-            out[f"exchange_{planes}_cells_us"] = timed(
-                lambda: check(lib.sobfu_hip_tiled_exchange(solver._h, C.c_void_p(field.data_ptr()), C.c_int(planes), st), "exchange"), reps)
-    msgs = L.messages()
-    out["exchange_messages"] = len(msgs)
-    out["exchange_bytes_out"] = sum((m[1][1] - m[1][0]) * (m[1][3] - m[1][2]) * (m[1][5] - m[1][4]) for m in msgs) * 12
-    out["exchange_largest_message_bytes"] = max([(m[1][1] - m[1][0]) * (m[1][3] - m[1][2]) * (m[1][5] - m[1][4]) for m in msgs] or [0]) * 12
-    if solver.has_comm:
-        slots = torch.zeros(SLOTS, dtype=torch.int32, device="cuda")
-        out["allreduce_256_slots_us"] = timed(lambda: check(lib.sobfu_hip_tiled_allreduce_max_u32(solver._h, C.c_void_p(slots.data_ptr()), C.c_size_t(SLOTS), st), "allreduce"), reps)
-    pnp, psi = solver.new_local(2), solver.identity_psi()
-
-    def loop(s):
-        return lambda: s.iterate(pg, pn_full, pnp, psi, iters)
-
-    if L.slab and not direct:
-        prev = os.environ.get("SOBFU_TILED_SPLIT_A")
-        for name, val in (("iteration_us_pass_a_unsplit", "0"), ("iteration_us_pass_a_split", "1")):
-            os.environ["SOBFU_TILED_SPLIT_A"] = val
-            out[name] = timed(loop(solver), 2) / iters
-        if prev is None:
-            os.environ.pop("SOBFU_TILED_SPLIT_A", None)
-        else:
-            os.environ["SOBFU_TILED_SPLIT_A"] = prev
-        os.environ["SOBFU_TILED_SERIAL"] = "1"  # pass A, exchange, pass B in line on one stream (no overlap, no events)
-        out["iteration_us_serial_schedule"] = timed(loop(solver), 2) / iters
-        os.environ.pop("SOBFU_TILED_SERIAL", None)
-    out["iteration_us_default_schedule"] = timed(loop(solver), 2) / iters
-    lib.sobfu_hip_tiled_last_enqueue_us.restype = C.c_double
-    out["host_enqueue_us_per_iteration"] = float(lib.sobfu_hip_tiled_last_enqueue_us(solver._h))
-    dry = NativeTiledSolver(dims, dry=(world, rank), grid=grid, **kw)  # same tile, no peers: the compute side alone
-    out["iteration_us_compute_only"] = timed(loop(dry), 2) / iters
-    dry.close()
-    return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}
-
-
-def candidate_grids(world, dims):
-    """every (Px, Py, Pz) with Px * Py * Pz == world whose tiles keep >= HALO cells per split axis, x split last (Px <= Py <= Pz
-    is not required: 1 x 2 x 4 and 2 x 2 x 2 and 1 x 1 x 8 are all candidates at 8; permutations that split x more than z are not)"""
-    out = []
-    for px in range(1, world + 1):
-        for py in range(1, world + 1):
-            if world % (px * py):
-                continue
-            pz = world // (px * py)
-            if px <= py <= pz and all(g == 1 or dims[a] // g >= HALO for a, g in enumerate((px, py, pz))):
-                out.append((px, py, pz))
-    return out
-
-
-def make_native_solver(dims, grid, ranks, kw, transport):
-    """NativeTiledSolver on the given transport ("direct" / "rccl"); ranks that SHARE a GPU (bring-up) cannot use RCCL -- their
-    "rccl" is the same buffers over gloo (GlooTransport).  Returns (solver, keep-alive)."""
-    if transport == "direct":
-        return NativeTiledSolver(dims, grid=grid, transport="direct", **kw), None
-    if ranks.share and ranks.world > 1:
-        sv = NativeTiledSolver(dims, dry=(ranks.world, ranks.rank), grid=grid, **kw)
-        tr = GlooTransport()
-        sv.set_transport(tr.exchange, tr.allreduce)
-        return sv, tr
-    return NativeTiledSolver(dims, grid=grid, **kw), None
-
-
-def direct_transport_precheck(P, ranks, kw, grid, iters=6):
-    """The direct transport on THIS machine, before anything is timed: a few iterations of the bench workload on tiles against the
-    single-GPU solver, bit for bit on every rank (peer mapping, flags and deadline all exercised).  Returns None when every rank
-    agrees it works, else a reason string (collective: every rank gets the same verdict)."""
-    from . import ops
-
-    dims = P["dims"]
-    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
-    why, sv = None, None
-    try:
-        sv = NativeTiledSolver(dims, grid=grid, transport="direct", **kw)
-    except Exception as e:  # noqa: BLE001
-        why = f"setup failed: {e!r}"
-    if ranks.min([0 if why else 1])[0] == 0:  # some rank could not map its peers: nobody uses the transport
-        if sv is not None:
-            sv.close()
-        return why or "setup failed on another rank"
-    try:
-        pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
-        ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
-        ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
-        L = sv.layout
-        pg = L.take(pg_full).clone().contiguous()
-        pnp, psi = sv.new_local(2), sv.identity_psi()
-        done, norms = sv.iterate(pg, pn_full, pnp, psi, iters)
-        one = ops.Solver(dims, max_iter=iters, **kw)
-        psi_f, pnp_f = ops.new_field(dims), ops.new_volume(dims)
-        ops.init_identity(psi_f)
-        _, norms_one = one.iterate(pg_full, pn_full, pnp_f, psi_f, iters)
-        one.close()
-        same = (np.array_equal(np.asarray(norms_one, np.float32).view(np.uint32), np.asarray(norms, np.float32).view(np.uint32))
-                and torch.equal(L.owned_global(psi_f)[..., :3].contiguous().view(torch.int32), L.owned(psi)[..., :3].contiguous().view(torch.int32))
-                and torch.equal(L.owned_global(pnp_f).contiguous().view(torch.int32), L.owned(pnp).contiguous().view(torch.int32)))
-        if not same:
-            dn = int((np.asarray(norms_one, np.float32).view(np.uint32) != np.asarray(norms, np.float32).view(np.uint32)).sum())
-            dp = int((L.owned_global(psi_f)[..., :3].contiguous().view(torch.int32) != L.owned(psi)[..., :3].contiguous().view(torch.int32)).sum())
-            df = int((L.owned_global(pnp_f).contiguous().view(torch.int32) != L.owned(pnp).contiguous().view(torch.int32)).sum())
-            why = (f"tiles differ from the single-GPU solve (rank {ranks.rank}: {dn} of {len(norms)} max-norms, {dp} psi words, {df} phi_n o psi words; "
-                   f"iterations done {done}; norms {[float(v) for v in norms]} vs {[float(v) for v in norms_one]})")
-    except Exception as e:  # noqa: BLE001 -- e.g. SOBFU_E_TIMEOUT: a peer's flag did not arrive
-        why = f"{e!r}"
-    ok = ranks.min([0 if why else 1])[0]
-    sv.close()
-    return None if ok else (why or "failed on another rank")
-
-
-def direct_transport_sandbox(P, ranks, kw, grid, timeout=240):
-    """The same check as direct_transport_precheck, one step earlier and somewhere safer: in a CHILD process of every rank
-    (sobfu_amd/ipc_probe.py).  A transport that stores into other GPUs' memory from inside a kernel fails, when the mapping is not
-    what it looks like, with a GPU memory fault -- which kills the process that launched the kernel.  The children take that risk;
-    the ranks themselves only learn the verdict.  Returns None when every rank's child exited 0, else a reason (collective)."""
-    import json
-    import os
-    import subprocess
-
-    from ._lib import ROOT
-
-    if os.environ.get("SOBFU_TILED_SANDBOX", "1") != "1":
-        return None
-    import socket
-
-    port = 0
-    if ranks.rank == 0:  # a port that is free right now, agreed on through the ranks' own process group
-        with socket.socket() as sk:
-            sk.bind(("", 0))
-            port = sk.getsockname()[1]
-    port = int(ranks.max([port])[0])
-    args = dict(addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), port=port, grid=list(grid),
-                dims=list(P["dims"]), vs=[float(v) for v in P["vs"]], trunc=float(P["trunc"]), eta=float(P["eta"]), kw=kw, iters=4, timeout=int(os.environ.get("SOBFU_PROBE_TIMEOUT_S", "90")))
-    # the children rendezvous among themselves: without the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE would make rank 0's
-    # child a client of a store nobody serves on that port)
-    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
-    env["SOBFU_PROBE_ARGS"] = json.dumps(args)
-    ok, why = False, None
-    try:
-        r = subprocess.run([sys.executable, "-m", "sobfu_amd.ipc_probe"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-        ok = r.returncode == 0
-        if not ok:
-            tail = " | ".join((r.stderr or r.stdout or "").strip().splitlines()[-3:])
-            why = f"sandboxed probe exited {r.returncode}: {tail[-400:]}"
-    except subprocess.TimeoutExpired:
-        why = f"sandboxed probe did not finish in {timeout} s"
-    except OSError as e:
-        why = f"sandboxed probe could not start: {e!r}"
-    all_ok = ranks.min([1 if ok else 0])[0] == 1
-    if all_ok:
-        time.sleep(float(os.environ.get("SOBFU_TILED_SETTLE_S", "0.5")))  # the children's device memory and IPC state are torn down asynchronously
-    return None if all_ok else (why or "sandboxed probe failed on another rank")
-
-
-def autotune_grid(P, ranks, kw, iters=40, transport="rccl"):
-    """us per iteration of the native loop for every candidate tile grid on the machine at hand (MAX over ranks: all agree)"""
-    from . import ops
-
-    dims = P["dims"]
-    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
-    pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
-    ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
-    ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
-    times = {}
-    for grid in candidate_grids(ranks.world, dims):
-        sv, _ = make_native_solver(dims, grid, ranks, kw, transport)
-        pg = sv.layout.take(pg_full).clone().contiguous()
-        pnp, psi = sv.new_local(2), sv.identity_psi()
-        sv.iterate(pg, pn_full, pnp, psi, 4)
-        torch.cuda.synchronize()
-        ranks.barrier()
-        t0 = time.perf_counter()
-        sv.iterate(pg, pn_full, pnp, psi, iters)
-        torch.cuda.synchronize()
-        times[grid] = ranks.max([(time.perf_counter() - t0) / iters * 1e6])[0]
-        sv.close()
-    return times
-
-
-def bench_tiled(args, P, ranks, timed_regions):
-    """bench.py leg for --gpus N > 1: the SAME 256^3 solve cut into N tiles (strong scaling; 2 x 2 x 2 at N = 8).  The direct
-    transport is the default; should it -- after passing its precheck -- still break during the run (a peer missing its deadline,
-    or tiles that differ from the single-GPU solve in the final bitwise self-check), every rank repeats the whole leg on RCCL
-    and the line says so: a wrong or wedged transport never becomes the reported number."""
-    import os
-
-    res = _bench_tiled_once(args, P, ranks, timed_regions, os.environ.get("SOBFU_TILED_TRANSPORT", "direct"))
-    if res.get("retry"):
-        why = res["retry"]
-        print(f"[rank {ranks.rank}] direct transport abandoned ({why}): repeating the run on RCCL", file=sys.stderr, flush=True)
-        res = _bench_tiled_once(args, P, ranks, timed_regions, "rccl", plain=True)
-        res["transport_fallback"] = why
-    return res
-
-
-def _bench_tiled_once(args, P, ranks, timed_regions, want, plain=False):
-    import os
-
-    from . import ops
-
-    rank, world = ranks.rank, ranks.world
-    dims = P["dims"]
-    X, Y, Z = dims
-    spec = args.tiles or os.environ.get("SOBFU_TILES", "")
-    c0, c1, r = (0.375,) * 3, (0.375 + 1.3 * float(P["vs"][0]), 0.375, 0.375), 0.2
-    kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
-    K, W, R, PR = args.steps, args.warmup, args.repeats, args.profile_repeats
-    total = W + (R + PR) * K
-    native = os.environ.get("SOBFU_TILED_NATIVE", "1") == "1"
-    if world == 1 and not dist.is_initialized():  # SOBFU_FORCE_TILED=1 on one GPU: a world of one
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", ranks.device))
-    # transport of the native loop: "direct" (default: peer-mapped stores over xGMI, no RCCL in the loop) is taken only after
-    # it has reproduced the single-GPU solve bit for bit on THIS machine on every rank (direct_transport_precheck, a few
-    # iterations before anything is timed); otherwise every rank falls back to "rccl" and the line says why
-    transport_name, fallback = ("rccl" if want != "direct" else "direct"), None
-    if native and transport_name == "direct":
-        probe_grid = parse_grid("" if spec == "auto" else spec, world)
-        fallback = direct_transport_sandbox(P, ranks, kw, probe_grid)  # first in child processes (a GPU fault there costs nothing) ...
-        if fallback is None:
-            fallback = direct_transport_precheck(P, ranks, kw, probe_grid)  # ... then in this one
-            if fallback is not None:
-                # seen twice in ~35 multi-process start-ups right behind the children's exit (one refused export, one mismatch), never
-                # in 360 start-ups without children: a second attempt, on fresh state, before the transport is given up
-                print(f"[rank {rank}] direct transport precheck failed ({fallback}); trying once more", file=sys.stderr, flush=True)
-                time.sleep(1.0)
-                first, fallback = fallback, direct_transport_precheck(P, ranks, kw, probe_grid)
-                if fallback is not None:
-                    fallback = f"{fallback} (first attempt: {first})"
-        if fallback is not None:
-            print(f"[rank {rank}] direct transport not used: {fallback}", file=sys.stderr, flush=True)
-            transport_name = "rccl"
-    grid_times = None
-    if spec == "auto":  # time every tile grid of `world` tiles on THIS machine (real exchange included) and keep the fastest
-        grid_times = autotune_grid(P, ranks, kw, transport=transport_name)
-        grid = min(grid_times, key=grid_times.get)
-    else:
-        grid = parse_grid(spec, world)
-    # if ANY rank fails to set the native loop up, every rank falls back to the torch.distributed loop (same decomposition, same
-    # results).  Ranks that share a GPU (bring-up) run "rccl" over the gloo transport.
-    solver, transport = None, None
-    if native:
-        try:
-            solver, transport = make_native_solver(dims, grid, ranks, kw, transport_name)
-        except Exception as e:  # noqa: BLE001 -- report and agree on the fallback collectively
-            print(f"[rank {rank}] native tiled loop unavailable: {e!r}", file=sys.stderr, flush=True)
-        ok = ranks.min([1 if solver is not None else 0])[0]
-        if ok == 0:
-            if solver is not None:
-                solver.close()
-            solver, native = None, False
-    if solver is None:
-        solver = TiledSolver(dims, grid=grid, **kw)
-    L = solver.layout
-    # every rank builds the full analytic TSDFs (replicated phi_n; phi_global is then cut to the local tile)
-    pg_full, pn_full = ops.new_volume(dims), ops.new_volume(dims)
-    ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
-    ops.init_sphere(pn_full, P["vs"], P["trunc"], P["eta"], c1, r)
-    pg = L.take(pg_full).clone().contiguous()
-    del pg_full
-    pnp = solver.new_local(2)
-    psi = solver.identity_psi()
-    tuned = None
-    # schedule autotuning (serial vs overlapped exchange; outside the timed region) runs only where RCCL was ASKED for: z-slabs by
-    # default, 3-D tiles with SOBFU_TILED_AUTOTUNE=tiles.  When RCCL is the fallback of a direct transport that just failed, the run
-    # takes the plainest schedule there is (serial, one stream) -- nothing that has never executed on >= 2 GPUs is tried first.
-    at = os.environ.get("SOBFU_TILED_AUTOTUNE", "1")
-    if (native and transport is None and transport_name == "rccl" and want == "rccl" and fallback is None and not plain and world > 1
-            and ((L.slab and at == "1") or at == "tiles")):
-        tuned = solver.autotune(pg, pn_full)
-    def timed_native():
-        solver.begin(pg, pn_full, pnp, psi, total)  # the solve is open and its state resident before anything is timed
-        solver.step(W)
-        secs = timed_regions(ranks, torch, lambda: solver.step(K), R)
-        prof = None
-        if PR > 0:  # the split of an iteration (pass A incl. the message stores / transfer + scatter / pass B), outside the timed regions
-            sched = getattr(solver, "schedule", 0)
-            slab_sched = L.slab and transport_name == "rccl"
-            if slab_sched:
-                solver.set_schedule(3)  # the split is measured on the serial schedule (same results whatever the schedule)
-            solver.set_profiling(1, PR * K)
-            solver.get_profile(reset=True)
-            for _ in range(PR):
-                solver.step(K)
-            torch.cuda.synchronize()
-            pa, px, pb, n = solver.get_profile()
-            solver.set_profiling(0)
-            if slab_sched:
-                solver.set_schedule(sched)
-            if n > 0:
-                prof = ranks.max([pa / n, px / n, pb / n]) + [n]
-        done, norms = solver.end()
-        assert done == total and np.isfinite(norms).all() and float(norms.max()) > 0, (done, total)
-        return secs, prof, norms
-
-    if native:
-        broke = None
-        try:
-            secs, prof, norms = timed_native()
-        except Exception as e:  # noqa: BLE001
-            if transport_name != "direct":
-                raise
-            broke = repr(e)  # e.g. SOBFU_E_TIMEOUT: a peer's flag did not arrive within the deadline
-        if transport_name == "direct" and ranks.max([1 if broke else 0])[0] > 0:  # every rank leaves the transport together
-            solver.close()
-            return {"retry": broke or "another rank's direct transport broke"}
-    else:  # the torch loop has no open-solve form: a region is a whole iterate() of K iterations
-        prof, total = None, W + R * K
-        if W > 0:
-            solver.iterate(pg, pn_full, pnp, psi, W)
-        hist = []
-        secs = timed_regions(ranks, torch, lambda: hist.append(solver.iterate(pg, pn_full, pnp, psi, K)), R)
-        norms = np.concatenate([h[1] for h in hist])
-        assert all(h[0] == K for h in hist) and np.isfinite(norms).all()
-    # self-check, outside the timed region: every rank repeats the WHOLE solve on its own GPU with the single-GPU solver
-    # handle and compares its owned cells and the max-norm history bit for bit (tiling must not change a single bit)
-    parity = None
-    if os.environ.get("SOBFU_TILED_SELFCHECK", "1") == "1":
-        pg_full = ops.new_volume(dims)
-        ops.init_sphere(pg_full, P["vs"], P["trunc"], P["eta"], c0, r)
-        psi_full, pnp_full = ops.new_field(dims), ops.new_volume(dims)
-        ops.init_identity(psi_full)
-        one = ops.Solver(dims, max_iter=max(total, 1), **kw)
-        if native:
-            _, norms_one = one.iterate(pg_full, pn_full, pnp_full, psi_full, total)
-        else:
-            parts = [one.iterate(pg_full, pn_full, pnp_full, psi_full, n)[1] for n in ([W] if W > 0 else []) + [K] * R]
-            norms_one = np.concatenate(parts[(1 if W > 0 else 0):])
-        one.close()
-        same = (np.array_equal(np.asarray(norms_one, np.float32).view(np.uint32), np.asarray(norms, np.float32).view(np.uint32))
-                and torch.equal(L.owned_global(psi_full)[..., :3].contiguous().view(torch.int32), L.owned(psi)[..., :3].contiguous().view(torch.int32))
-                and torch.equal(L.owned_global(pnp_full).contiguous().view(torch.int32), L.owned(pnp).contiguous().view(torch.int32)))
-        parity = bool(ranks.min([1 if same else 0])[0])
-        if not parity:
-            print(f"[rank {rank}] tiled self-check: tile differs from the single-GPU solve (local: {same})", file=sys.stderr, flush=True)
-        del pg_full, psi_full, pnp_full
-        if not parity and native and transport_name == "direct":
-            solver.close()
-            return {"retry": "tiles differed from the single-GPU solve in the final bitwise self-check"}
-    # diagnostics for the next tuning round, outside the timed region (every rank takes part in the collective ones):
-    # what one halo exchange, one slot all-reduce and the compute side alone cost on THIS machine
-    diag, hung = None, False
-    if native and os.environ.get("SOBFU_TILED_DIAG", "1") == "1":
-        # in a worker thread with a deadline: whatever happens in there (an exception on one rank would leave the others
-        # waiting in a collective), the benchmark line is still printed
-        import threading
-
-        box, dev_index = {}, torch.cuda.current_device()
-
-        def work():
-            try:
-                torch.cuda.set_device(dev_index)
-                box["diag"] = _tiled_diagnostics(solver, kw, dims, grid, pg, pn_full, world, rank, ranks)
-            except Exception as e:  # noqa: BLE001
-                box["error"] = repr(e)
-
-        th = threading.Thread(target=work, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("SOBFU_TILED_DIAG_TIMEOUT", "120")))
-        hung = th.is_alive()
-        diag = box.get("diag") or {"error": "timed out" if hung else box.get("error", "unknown")}
-        if "error" in diag:
-            print(f"[rank {rank}] tiled diagnostics: {diag['error']}", file=sys.stderr, flush=True)
-    # whether ANY rank hung is agreed over the rendezvous store, not over the (possibly wedged) communicator: every rank then
-    # takes the same exit path (no rank waits in a barrier the hung rank never reaches)
-    hung_any = hung
-    if world > 1 and native and os.environ.get("SOBFU_TILED_DIAG", "1") == "1":
-        try:
-            store = dist.distributed_c10d._get_default_store()
-            store.set(f"sobfu_diag_hung_{rank}", "1" if hung else "0")
-            hung_any = any(store.get(f"sobfu_diag_hung_{q}") == b"1" for q in range(world))
-        except Exception as e:  # noqa: BLE001
-            print(f"[rank {rank}] could not agree on the diagnostics verdict: {e!r}", file=sys.stderr, flush=True)
-            hung_any = True
-    own = tuple(L.g1[a] - L.g0[a] for a in range(3))
-    what = (f"{world} z-slabs of {own[2]} planes" if L.slab else f"{grid[0]}x{grid[1]}x{grid[2]} tiles of {own[0]}x{own[1]}x{own[2]} cells")
-    via = {"direct": "peer-mapped stores over xGMI issued by pass A's own launch (no pack / unpack, no RCCL in the loop; arrival flags "
-                     "and max-norm rows travel the same way)",
-           "rccl": "gloo (ranks share a GPU: bring-up transport)" if transport else "RCCL send/recv (packed by pass A's launch, one scatter kernel)"}
-    return dict(diag_hung=hung, diag_hung_any=hung_any, transport=(transport_name if native else "torch.distributed"),
-                transport_fallback=fallback, region_seconds=secs, N=X * Y * Z, ms_a=(prof[0] if prof else None), ms_b=(prof[2] if prof else None),
-                ms_exchange=(prof[1] if prof else None), n_prof=(prof[3] if prof else None),
-                launch_cells=max((l.g1[0] - l.g0[0]) * (l.g1[1] - l.g0[1]) * (l.g1[2] - l.g0[2]) for l in (TileLayout(dims, grid, q) for q in range(world))), last_norm=float(norms[-1]), workspace=None, tiled_parity=parity,
-                tiled_diag=diag, tiles={"grid": list(grid), "owned_cells_rank0": list(own), "halo": HALO,
-                                        "messages_per_exchange_rank0": len(L.messages())},
-                parallelism=f"{what} (+{HALO}-cell halos), one nabla_U halo exchange per iteration over "
-                            + (via[transport_name] if native else "RCCL send/recv") + ", "
-                            + ("native C++ loop" if native else "torch.distributed loop")
-                            + (f", schedule: {solver.SCHEDULES[solver.schedule]} (autotuned)" if tuned else ""),
-                tiled_autotune_us=({solver.SCHEDULES[k]: round(v, 2) for k, v in tuned.items()} if tuned else None)
-                if not grid_times else {"x".join(map(str, g)): round(v, 2) for g, v in grid_times.items()})

@@ -1,4 +1,4 @@
-"""Worker for tests/test_tiled_cpu.py: runs sobfu_amd.tiled.TiledSolver over gloo with an ORACLE-backed per-tile kernel
+"""Worker for tests/test_tiled_cpu.py: runs tests/tiled_reference.TiledSolver over gloo with an ORACLE-backed per-tile kernel
 backend (test infrastructure: checks the decomposition / halo-exchange / reduction logic on CPU, bit for bit against the
 single-process oracle solve).  Usage: python _tiled_worker.py <rank> <world> <port> <out.npz> <thr> [PxxPyxPz]"""
 import os
@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 
 import oracle as O  # noqa: E402
 from sobfu_amd import tiled  # noqa: E402
+import tiled_reference  # noqa: E402
 from sobfu_amd.synthetic import hash_field  # noqa: E402
 
 DIMS = (20, 12, 24)
@@ -115,7 +116,7 @@ def main():
     O.set_num_threads(1)
     torch.set_num_threads(1)
     pg, pn = inputs()
-    sv = tiled.TiledSolver(DIMS, alpha=0.05, w_reg=0.4, max_update_norm=thr, backend=OracleBackend(), grid=grid)
+    sv = tiled_reference.TiledSolver(DIMS, alpha=0.05, w_reg=0.4, max_update_norm=thr, backend=OracleBackend(), grid=grid)
     L = sv.layout
     pg_l = torch.from_numpy(np.ascontiguousarray(L.take(pg)))
     pn_full = torch.from_numpy(pn)

@@ -98,8 +98,9 @@ def test_gpus_n_strong_scaling_self_launch(n, grid, transport):
 def test_gpus_n_tiles_auto():
     d = run_bench("--gpus", "4", "--tiles", "auto", "--steps", "5", "--warmup", "1", "--dim", "64", "--repeats", "2",
                   env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0"})
-    assert set(d["tiled_autotune_us"]) == {"1x1x4", "1x2x2"} and "x".join(map(str, d["tiles"]["grid"])) in d["tiled_autotune_us"]
-    assert d["tiled_parity_vs_single_gpu"] == "bit-exact"
+    t = d["tiled_autotune_us"]["direct"]  # the grid is chosen on the first usable transport
+    assert set(t) == {"1x1x4", "1x2x2"} and "x".join(map(str, d["tiles"]["grid"])) in t and all(v > 0 for v in t.values())
+    assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and set(d["legs"]) == {"direct", "rccl"}
 
 
 def test_gpus_n_explicit_tiles_and_threshold():
@@ -109,9 +110,39 @@ def test_gpus_n_explicit_tiles_and_threshold():
 
 
 def test_direct_transport_probe_child_dies_falls_back():
-    """the direct transport is first exercised in a CHILD of every rank (sobfu_amd/ipc_probe.py): one child dying the way a GPU
+    """the direct transport is first exercised in a CHILD of every rank (bench_probe.py): one child dying the way a GPU
     memory fault would kill it must cost the run nothing but the transport -- every rank agrees on RCCL and the line says why"""
     d = run_bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dim", "64", "--repeats", "2",
                   env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_TILED_DIAG": "0", "SOBFU_PROBE_TEST_ABORT": "1", "SOBFU_PROBE_TIMEOUT_S": "20"})
     assert d["transport"] == "rccl" and "sandboxed probe" in d["transport_fallback"], d
-    assert d["tiled_parity_vs_single_gpu"] == "bit-exact"
+    assert d["tiled_parity_vs_single_gpu"] == "bit-exact" and "sandboxed probe" in d["legs"]["direct"]["failed"] and d["legs"]["rccl"]["value"] > 0
+
+
+def test_gpus_8_harvests_everything():
+    """ONE `python bench.py --gpus 8` records everything the machine can tell: both transports timed on
+    BASELINE config 4's grid with `value` = the better bit-exact one, every grid of 8 tiles on both transports, the direct
+    transport's flag round trips / push-box rate / unhidden wait, one exchange and one all-reduce of the RCCL leg, a topology
+    snapshot, frames/s of the whole pipeline ON TILES.  Eight real processes sharing this box's GPU (RCCL leg over gloo)."""
+    d = run_bench("--gpus", "8", "--steps", "6", "--warmup", "2", "--dim", "64", "--repeats", "2", "--frame-iters", "8",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 8 and d["tiles"]["grid"] == [2, 2, 2] and d["tiled_parity_vs_single_gpu"] == "bit-exact"
+    legs = d["legs"]
+    assert set(legs) == {"direct", "rccl"} and d["transport"] in legs
+    for name, leg in legs.items():
+        assert leg["tiled_parity_vs_single_gpu"] == "bit-exact" and leg["value"] > 0 and len(leg["region_its"]) == 2, (name, leg)
+        assert leg["ms_a"] > 0 and leg["ms_b"] > 0
+    assert d["value"] == max(leg["value"] for leg in legs.values()) and abs(d["value"] - legs[d["transport"]]["value"]) < 1e-9
+    assert legs["direct"]["peer_wait_us_per_iteration"] >= 0 and legs["rccl"]["ms_exchange"] > 0
+    grids = d["tiled_autotune_us"]
+    assert set(grids) == {"direct", "rccl"} and all(set(g) == {"1x1x8", "1x2x4", "2x2x2"} and all(v and v > 0 for v in g.values()) for g in grids.values())
+    dd = d["tiled_diag"]["direct_diag"]
+    assert len(dd["flag_round_trip_us"]) == 28 and all(v > 0 for v in dd["flag_round_trip_us"].values())
+    assert dd["push_boxes_only_us"] > 0 and dd["push_boxes_only_local_stores_us"] > 0 and dd["push_rate_GBps_of_bytes_out"] > 0 and dd["status_ok"]
+    assert dd["messages"] == 6 and dd["bytes_out_per_iteration"] == 12 * (3 * 4 * 32 * 32 + 3 * 4 * 4 * 32)
+    rd = d["tiled_diag"]["rccl_diag"]
+    assert rd["exchange_4_cells_us"] > 0 and d["tiled_diag"]["iteration_us_compute_only"] > 0
+    topo = d["topology"]
+    assert topo["devices_visible"] >= 1 and "pairs" in topo
+    f = d["per_frame"]
+    assert f["frames_timed"] == 3 and f["iterations_per_frame"][-1] == 8 and f["frames_per_s"] > 0 and f["tiles"] == "2x2x2"
+    assert f["all_gathered_bytes_per_frame"] == 64 ** 3 * 24

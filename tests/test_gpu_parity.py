@@ -470,7 +470,9 @@ def test_tile_kernels_match_full_volume(ops, oracle, grid, compact):
     psi0 = warped_identity(oracle, dims, 43, 1.2)
     S = oracle.sobolev_filter(7, 0.1)
     w_reg, alpha = 0.6, 0.1
-    be = tiled.HipBackend(compact=compact)
+    import tiled_reference
+
+    be = tiled_reference.HipBackend(compact=compact)
     psi_f, pnp_f, nU_f = dev(psi0), ops.new_volume(dims), ops.new_field(dims)
     ops.apply(dev(pn), pnp_f, psi_f)
     ops.fused_potential_gradient(pnp_f, dev(pg), psi_f, nU_f, w_reg)

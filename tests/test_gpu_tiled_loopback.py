@@ -261,25 +261,15 @@ def test_direct_transport_deadline():
                                                ((70, 33, 23), (2, 1, 1), None), ((40, 24, 36), (1, 2, 1), None), ((40, 24, 36), (2, 2, 1), None),
                                                ((141, 19, 17), (2, 1, 2), None), ((36, 36, 36), (3, 3, 3), None),
                                                # the smallest tiles the layout allows (4 owned cells per split axis: a message is the whole tile)
-                                               ((8, 9, 10), (2, 2, 2), None), ((12, 8, 8), (3, 2, 1), None),
-                                               # the OVERLAPPED schedule of 3-D tiles: push boxes as their own launch, exchange + scatter on the
-                                               # communication stream beside pass A's owned block and pass B's interior, then pass B's rim slabs
-                                               ((40, 24, 36), (2, 2, 2), "overlap"), ((64, 64, 64), (2, 2, 2), "overlap"), ((33, 17, 16), (1, 2, 2), "overlap"),
-                                               ((141, 19, 17), (2, 1, 2), "overlap"), ((36, 36, 36), (3, 3, 3), "overlap"), ((8, 9, 10), (2, 2, 2), "overlap"),
-                                               ((70, 33, 23), (2, 1, 1), "overlap"), ((40, 24, 36), (1, 2, 1), "overlap")])
+                                               ((8, 9, 10), (2, 2, 2), None), ((12, 8, 8), (3, 2, 1), None)])
 def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
     import torch
 
     import oracle
     from sobfu_amd import ops
 
-    schedule = None
-    if split == "serial":
-        monkeypatch.setenv("SOBFU_TILED_SERIAL", "1")
-    elif split == "overlap":
-        monkeypatch.setenv("SOBFU_TILED_SERIAL", "0")
-    elif split is not None:
-        monkeypatch.setenv("SOBFU_TILED_SPLIT_A", split)
+    # how the z-slab iteration is issued (sobfu_hip_tiled_set_schedule): 3 serial, 1 overlapped with pass A split, 2 overlapped, pass A whole
+    schedule = {None: None, "serial": 3, "1": 1, "0": 2}[split]
     rng = np.random.default_rng(5)
     X, Y, Z = dims
     pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
