@@ -331,7 +331,7 @@ def direct_micro_diagnostics(solver, ranks, reps=400):
         dry.close()
         out["push_boxes_only_us"] = round(push_us, 2)             # rim cells evaluated + stored into the PEERS' halo cells + handshake
         out["push_boxes_only_local_stores_us"] = round(local_us, 2)  # the same launches storing locally (no peers, no handshake)
-        out["push_rate_GBps_of_bytes_out"] = round(12 * sum(cells) / (push_us * 1e-6) / 1e9, 1)
+        out["push_rate_GBps_of_bytes_out"] = round(12 * sum(cells) / (push_us * 1e-6) / 1e9, 3)
     ok, missing = solver.status()
     out["status_ok"] = bool(ok)
     return out
