@@ -376,7 +376,7 @@ SOBFU_DEV bool solver_converged(const uint32_t* __restrict__ prev_slots, float m
 struct GateRegs {
     uint32_t v[8];
 };
-SOBFU_DEV GateRegs gate_load(const uint32_t* __restrict__ prev_slots, int prev_rows) {
+SOBFU_DEV GateRegs gate_load(const uint32_t* __restrict__ prev_slots, int prev_rows, bool sys = false /* the rows hold entries other GPUs stored */) {
     GateRegs g;
     const int tid = threadIdx.x + blockDim.x * threadIdx.y;
 #pragma unroll
@@ -387,7 +387,8 @@ SOBFU_DEV GateRegs gate_load(const uint32_t* __restrict__ prev_slots, int prev_r
             if (r < prev_rows) {
                 const uint32_t* row = prev_slots - (size_t) r * 256;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g.v[4 * r + k] = row[tid + 64 * k];
+                for (int k = 0; k < 4; ++k)
+                    g.v[4 * r + k] = sys ? __hip_atomic_load(row + tid + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : row[tid + 64 * k];
             }
     }
     return g;
@@ -655,6 +656,12 @@ SOBFU_DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, uint32_t bytes) {
 // nt: the streaming (nontemporal) hint, bit 1 of the cache-policy operand on gfx94x / gfx950
 SOBFU_DEV float4 buf_ld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool nt = false) {
     const v3u t = nt ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 2) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
+}
+// the same load at SYSTEM scope (sc0 sc1: bits 0 and 4 of the cache-policy operand) when `sys` (wave-uniform) says so: cells another
+// GPU stored -- the halo rims of nabla_U on the direct transport
+SOBFU_DEV float4 buf_ld3_scope(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool sys) {
+    const v3u t = sys ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 17) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
     return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
 }
 SOBFU_DEV float buf_ld1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
@@ -939,11 +946,15 @@ SOBFU_DEV void maxnorm_tail(float msq, uint32_t* slots, uint32_t* s_max) {
 template <bool WRITE_UPDATES, bool COMPACT, bool IDX32>
 SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
     const Dims d = a.d;
+    // nabla_U cells of the halo rims may have been stored by other GPUs (direct transport): read at system scope then (compact format)
+    const bool sys = COMPACT && a.sys_acquire != 0;
+    const __amdgpu_buffer_rsrc_t r_nu = buf_rsrc(a.nU, (uint32_t) ((size_t) d.x * d.y * d.z * 12));
+    auto ld_nu = [&](size_t i) { return sys ? buf_ld3_scope(r_nu, (uint32_t) (i * 12), 0u, true) : ldv<COMPACT>(a.nU, i); };
     float slx = 0.f, sly = 0.f, slz = 0.f, srx = 0.f, sry = 0.f, srz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
 #pragma unroll
     for (int j = -3; j <= 3; ++j) {
         const float s = a.S.s[3 - j];
-        const float4 vl = ldv<COMPACT>(a.nU, vidx(d, min(max(x + j, 0), d.x - 1), y, z));
+        const float4 vl = ld_nu(vidx(d, min(max(x + j, 0), d.x - 1), y, z));
         slx += vl.x * s;
         sly += vl.y * s;
         slz += vl.z * s;
@@ -951,7 +962,7 @@ SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
 #pragma unroll
     for (int j = -3; j <= 3; ++j) {
         const float s = a.S.s[3 - j];
-        const float4 vr = ldv<COMPACT>(a.nU, vidx(d, x, min(max(y + j, 0), d.y - 1), z));
+        const float4 vr = ld_nu(vidx(d, x, min(max(y + j, 0), d.y - 1), z));
         srx += vr.x * s;
         sry += vr.y * s;
         srz += vr.z * s;
@@ -959,7 +970,7 @@ SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
 #pragma unroll
     for (int j = -3; j <= 3; ++j) {
         const float s = a.S.s[3 - j];
-        const float4 vz = ldv<COMPACT>(a.nU, vidx(d, x, y, min(max(z + j, 0), d.z - 1)));
+        const float4 vz = ld_nu(vidx(d, x, y, min(max(z + j, 0), d.z - 1)));
         szx += vz.x * s;
         szy += vz.y * s;
         szz += vz.z * s;
@@ -1031,92 +1042,87 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
     const __amdgpu_buffer_rsrc_t r_nu = buf_rsrc(a.nU, cells * VB), r_psi = buf_rsrc(a.psi, cells * VB), r_out = buf_rsrc(a.psi_out, cells * VB),
                                  r_f = buf_rsrc(a.pnp, cells * TB);
     auto nU_plane = [&](int z) { return 3u * (uint32_t) min(max(z, 0), d.z - 1) * plane4; };
-    // prologue: planes zb-3 .. zb+3 and the halo of plane zb, staged at once
-    float4 q[7], hq[TPW];
-    // DOWN: the march runs from the chunk's top plane to its bottom one (see Box::pair); q[k] is plane z - 3 + k either way
+    // direct transport: cells of nabla_U's halo rims were stored by other GPUs -> this launch reads nabla_U at system scope (measured on
+    // one GPU with every load of the march so marked: pass B 24.7 -> 24.2 us, the same fabric bytes: free)
+    const bool sys = a.sys_acquire != 0;
+    // The z taps live in EIGHT register slots that rotate (the loop is unrolled eight times: slot indices are constants, nothing is
+    // shifted -- the seven-plane shift of the plain march is 18 register moves per plane, 9 % of the loop's vector instructions).
+    // Slot m % 8 holds the m-th plane of the march's window: m = st .. st + 6 at step st, i.e. planes z - 3 .. z + 3 going up
+    // (plane = z_first - 3 + m) or z + 3 .. z - 3 going DOWN (plane = z_first + 3 - m, see Box::pair); the plane requested at step st,
+    // m = st + 7, takes the slot the window left a step ago.
     constexpr int DZ = DOWN ? -1 : 1;
     const int z_first = DOWN ? ze - 1 : zb, n_steps = ze - zb;
+    float4 Q[8], hq[TPW];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) q[k] = buf_ld3(r_nu, off, nU_plane(z_first - 3 + k));
+    for (int m = 0; m < 7; ++m) Q[m] = buf_ld3_scope(r_nu, off, nU_plane(z_first + DZ * (m - 3)), sys);
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
-        if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(z_first));
+        if (h_on[k]) hq[k] = buf_ld3_scope(r_nu, h_off[k], nU_plane(z_first), sys);
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
-    tile[0][wy + R][lx + R] = q[3];
+    tile[0][wy + R][lx + R] = Q[3];
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
         if (h_on[k]) tile[0][h_lr[k]][h_lc[k]] = hq[k];
     float4 p_prev = make_float4(0.f, 0.f, 0.f, 0.f);
     float msq = 0.f;
-    for (int st = 0; st < n_steps; ++st) {
-        const int z = z_first + DZ * st;
-        const int buf = st & 1;
-        const uint32_t zcur4 = (uint32_t) z * plane4;
-        // this step's requests
-        const float4 pv = buf_ld3(r_psi, off, 3u * zcur4, NTL >= 2);
-        float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st + 1 < n_steps) {
-            qn = buf_ld3(r_nu, off, nU_plane(z + 4 * DZ));
+    for (int s0 = 0; s0 < n_steps; s0 += 8) {
 #pragma unroll
-            for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) hq[k] = buf_ld3(r_nu, h_off[k], nU_plane(z + DZ));
-        }
-        Gather8 g;
-        if (mine && st > 0) g = gather_issue32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
-        __syncthreads();
-        // the taps of plane z: x and y from the LDS tile, z from the register planes (sum = 0; ascending j; products not contracted)
-        v2f l01 = {0.f, 0.f}, l23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, z01 = {0.f, 0.f}, z23 = {0.f, 0.f};
+        for (int i = 0; i < 8; ++i) {
+            const int st = s0 + i;
+            if (st >= n_steps) break;
+            const int z = z_first + DZ * st;
+            const int buf = st & 1;
+            const uint32_t zcur4 = (uint32_t) z * plane4;
+            const float4 qc = Q[(i + 3) % 8];  // plane z
+            // this step's requests
+            const float4 pv = buf_ld3(r_psi, off, 3u * zcur4, NTL >= 2);
+            if (st + 1 < n_steps) {
+                Q[(i + 7) % 8] = buf_ld3_scope(r_nu, off, nU_plane(z + 4 * DZ), sys);
 #pragma unroll
-        for (int j = -R; j <= R; ++j) {
-            const v2f s2 = {a.S.s[R - j], a.S.s[R - j]};
-            const float4 vl = (j == 0) ? q[3] : tile[buf][wy + R][lx + R + j];
-            l01 += v2f{vl.x, vl.y} * s2;
-            l23 += v2f{vl.z, vl.w} * s2;
-            const float4 vr = (j == 0) ? q[3] : tile[buf][wy + R + j][lx + R];
-            r01 += v2f{vr.x, vr.y} * s2;
-            r23 += v2f{vr.z, vr.w} * s2;
-            const float4 vz = q[3 + j];
-            z01 += v2f{vz.x, vz.y} * s2;
-            z23 += v2f{vz.z, vz.w} * s2;
-        }
-        const v2f t01 = (l01 + r01) + z01;
-        const float tx = t01.x, ty = t01.y, tz = (l23.x + r23.x) + z23.x;
-        // update_psi_kernel (solver.cu:64-67)
-        const float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
-        float4 p = pv;
-        p.x -= uu.x;
-        p.y -= uu.y;
-        p.z -= uu.z;
-        pin3<2>(p);
-        if (mine) {
-            if (owned && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
-            if (st > 0) {  // apply_kernel (vector_fields.cu:95-98) of the plane of the step before
-                buf_st1(r_f, offT, DOWN ? zcur4 + plane4 : zcur4 - plane4, gather_finish(g), NTL >= 1);
+                for (int k = 0; k < TPW; ++k)
+                    if (h_on[k]) hq[k] = buf_ld3_scope(r_nu, h_off[k], nU_plane(z + DZ), sys);
             }
-            buf_st3(r_out, off, 3u * zcur4, p, NTL >= 1);
-        }
-        p_prev = p;
-        // shift the z pipeline (plain register moves: see the plain march) and stage the next plane into the other buffer
-        if (DOWN) {
+            Gather8 g;
+            if (mine && st > 0) g = gather_issue32((const float*) a.phi_n, a.pd, p_prev.x, p_prev.y, p_prev.z);
+            __syncthreads();
+            // the taps of plane z: x and y from the LDS tile, z from the register planes (sum = 0; ascending j; products not contracted)
+            v2f l01 = {0.f, 0.f}, l23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, z01 = {0.f, 0.f}, z23 = {0.f, 0.f};
 #pragma unroll
-            for (int k = 6; k > 0; --k) {
-                q[k] = q[k - 1];
-                asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z));
+            for (int j = -R; j <= R; ++j) {
+                const v2f s2 = {a.S.s[R - j], a.S.s[R - j]};
+                const float4 vl = (j == 0) ? qc : tile[buf][wy + R][lx + R + j];
+                l01 += v2f{vl.x, vl.y} * s2;
+                l23 += v2f{vl.z, vl.w} * s2;
+                const float4 vr = (j == 0) ? qc : tile[buf][wy + R + j][lx + R];
+                r01 += v2f{vr.x, vr.y} * s2;
+                r23 += v2f{vr.z, vr.w} * s2;
+                const float4 vz = Q[(i + 3 + DZ * j + 8) % 8];  // plane z + j
+                z01 += v2f{vz.x, vz.y} * s2;
+                z23 += v2f{vz.z, vz.w} * s2;
             }
-            q[0] = qn;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                q[k] = q[k + 1];
-                asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z));
+            const v2f t01 = (l01 + r01) + z01;
+            const float tx = t01.x, ty = t01.y, tz = (l23.x + r23.x) + z23.x;
+            // update_psi_kernel (solver.cu:64-67)
+            const float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
+            float4 p = pv;
+            p.x -= uu.x;
+            p.y -= uu.y;
+            p.z -= uu.z;
+            pin3<2>(p);
+            if (mine) {
+                if (owned && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
+                if (st > 0) {  // apply_kernel (vector_fields.cu:95-98) of the plane of the step before
+                    buf_st1(r_f, offT, DOWN ? zcur4 + plane4 : zcur4 - plane4, gather_finish(g), NTL >= 1);
+                }
+                buf_st3(r_out, off, 3u * zcur4, p, NTL >= 1);
             }
-            q[6] = qn;
-        }
-        if (st + 1 < n_steps) {
-            tile[buf ^ 1][wy + R][lx + R] = q[3];
+            p_prev = p;
+            if (st + 1 < n_steps) {  // stage the next plane of the march into the other buffer
+                tile[buf ^ 1][wy + R][lx + R] = Q[(i + 4) % 8];
 #pragma unroll
-            for (int k = 0; k < TPW; ++k)
-                if (h_on[k]) tile[buf ^ 1][h_lr[k]][h_lc[k]] = hq[k];
+                for (int k = 0; k < TPW; ++k)
+                    if (h_on[k]) tile[buf ^ 1][h_lr[k]][h_lc[k]] = hq[k];
+            }
         }
     }
     if (ze > zb && mine) {  // the last plane's warp
@@ -1138,13 +1144,12 @@ __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B)
     __shared__ uint32_t s_max[WY];
     __shared__ P3 hfifo[HL > 0 ? HL : 1][HL > 0 ? NTASK * TX : 1];  // 12-byte entries: with the 32 KB tile, 3 workgroups still fit a CU's 160 KB
 
-    // Direct transport: the 4-cell halo rims of nabla_U and the other ranks' entries of the max-norm rows were stored into this GPU's
-    // memory by kernels of OTHER GPUs (write-through at system scope, acknowledged before their arrival flag went out, and the flag
-    // was seen by this rank's pass A before it retired: DESIGN.md section 6.1).  What this launch must not do is serve such a cell from
-    // a line its own caches kept from two iterations ago.  The acquire the runtime attaches to a dispatch is its business; this
-    // kernel does not rely on its scope: every wave invalidates at SYSTEM scope before its first load.
-    if (a.sys_acquire) asm volatile("buffer_inv sc0 sc1" ::: "memory");
-    const GateRegs gate = gate_load(a.prev_slots, a.prev_rows);
+    // Direct transport (a.sys_acquire): the 4-cell halo rims of nabla_U were stored into this GPU's memory by kernels of OTHER GPUs
+    // (write-through at system scope, acknowledged before their arrival flag went out; the flag was seen by this rank's pass A before
+    // it retired: DESIGN.md section 6.1).  An invalidate at this kernel's entry (`buffer_inv sc0 sc1` by every wave) was built and
+    // measured: + 39 us per launch on a 128^3 tile -- waves start at different times and every late invalidate throws away what the
+    // early waves had fetched.  Instead the pipelined march reads nabla_U at system scope on such handles (buf_ld3_scope).
+    const GateRegs gate = gate_load(a.prev_slots, a.prev_rows, a.sys_acquire != 0);
 
     const Dims d = a.d;
     const int lx = threadIdx.x, wy = threadIdx.y;
@@ -1726,12 +1731,13 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
                 {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi, sys_acquire ? 1 : 0};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
+    if (sys_acquire && (size_t) X * Y * Z * 12 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // scope-carrying loads are buffer loads: arrays below 4 GiB
     const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
     // the solver's own format (compact, 32-bit gather offsets, no `updates`): streaming hints only for grids beyond the Infinity
     // Cache; the pipelined march where the launch is latency-bound (cache-resident sizes; SOBFU_PIPE_B=0/1 overrides)
     const bool resident = cache_resident(X, Y, Z);
     const char* pipe_e = getenv("SOBFU_PIPE_B");
-    const bool pipe = compact && idx32 && !updates && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32) && (pipe_e ? atoi(pipe_e) != 0 : resident);  // (buffer addressing: arrays below 4 GiB)
+    const bool pipe = compact && idx32 && !updates && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32) && (pipe_e ? atoi(pipe_e) != 0 : (resident || sys_acquire));  // (buffer addressing: arrays below 4 GiB; connected handles always: its loads can carry the scope)
     // workgroups a CU holds: <= 80 VGPR (launch bounds) and 32 - 48 KB LDS: 3 of 8 waves; the pipelined march (<= 128 VGPR): 2
     // cache-resident launches are ONE resident round of workgroups, which lasts as long as its longest march: the planes are
     // split evenly over as many z-chunks as fill the marching workgroups' share of the chip

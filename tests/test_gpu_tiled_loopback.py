@@ -120,10 +120,15 @@ def run_world(dims, grid, psi0, pg, pn, n_iters, thr, schedule=None):
     return out, full
 
 
-def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, kw=None):
+def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, kw=None, keep_halo_lines_hot=False):
     """N ranks on the DIRECT transport in one process.  stepped: one host thread drives all ranks phase by phase (pass A incl.
     the pushes | pass B | ... | end-of-solve handshake) with the in-kernel waits off -- any number of ranks; else one thread
-    per rank runs the real loop, in-kernel waits live (few ranks: every rank's stream needs a hardware queue of its own)."""
+    per rank runs the real loop, in-kernel waits live (few ranks: every rank's stream needs a hardware queue of its own).
+    keep_halo_lines_hot (stepped): right before every pass A -- whose push boxes store into the OTHER ranks' nabla_U halo cells -- a
+    copy kernel reads every rank's nabla_U arena, so that the lines those stores are about to change sit in the reader's caches when
+    the stores happen: pass B must still see the new cells (its entry invalidates at system scope on connected handles)."""
+    import ctypes as C
+
     import torch
 
     from sobfu_amd import tiled
@@ -151,7 +156,17 @@ def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, 
                 with torch.cuda.stream(streams[r]):
                     s.begin(state[r][0], pn_d, state[r][2], state[r][1], n_iters)
             torch.cuda.synchronize()
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            sink = torch.empty(2 * max(sv.layout.L[0] * sv.layout.L[1] * sv.layout.L[2] for sv in solvers) * 3, dtype=torch.float32, device="cuda")
             for phase in [p for _ in range(n_iters) for p in (0, 1)] + [2]:
+                if keep_halo_lines_hot and phase == 0:
+                    for r, s in enumerate(solvers):  # read both halves of this rank's nabla_U (halo cells included) -> its lines are cache-resident
+                        e, nl = s.exports(), s.layout.L[0] * s.layout.L[1] * s.layout.L[2]
+                        for h in (0, 1):
+                            assert hip.hipMemcpyAsync(C.c_void_p(sink.data_ptr() + h * nl * 12), C.c_void_p(e.arena + e.nabla_u_off[h]), nl * 12, 3,
+                                                      C.c_void_p(streams[r].cuda_stream)) == 0
+                    torch.cuda.synchronize()
                 for r, s in enumerate(solvers):
                     with torch.cuda.stream(streams[r]):
                         s.step_phase(phase)
@@ -223,6 +238,36 @@ def test_native_loop_direct_transport(dims, grid, stepped):
             assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), hist_e.view(np.uint32))
         assert np.array_equal(psi_t[..., :3].view(np.uint32), psi_e[..., :3].view(np.uint32))
         assert np.array_equal(pnp_t.view(np.uint32), pnp_e.view(np.uint32))
+
+
+@pytest.mark.parametrize("dims,grid", [((40, 24, 36), (2, 2, 2)), ((64, 64, 64), (2, 2, 2)), ((40, 24, 36), (1, 1, 3))])
+def test_direct_transport_with_stale_halo_lines_in_cache(dims, grid):
+    """pass B reads halo cells OTHER ranks stored (on real hardware: other GPUs).  Here every rank's
+    nabla_U halo lines are deliberately made cache-resident right before the peers overwrite them (keep_halo_lines_hot): the
+    solve must still equal the single-GPU one bit for bit.  On ONE GPU the ordinary kernel boundary already guarantees that (this
+    test cannot fail for the reason it guards against -- only a second GPU can show that); what it does exercise is the explicit
+    system-scope invalidate at pass B's entry on connected handles, under exactly the access pattern it exists for."""
+    import torch
+
+    import oracle
+    from sobfu_amd import ops
+
+    rng = np.random.default_rng(11)
+    X, Y, Z = dims
+    pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    psi0 = oracle.new_field(dims)
+    oracle.init_identity(psi0)
+    psi0[..., :3] += rng.uniform(-0.7, 0.7, psi0[..., :3].shape).astype(np.float32)
+    sv = ops.Solver(dims, max_iter=6, alpha=0.05, w_reg=0.4, max_update_norm=1e-10)
+    psi, pnp = torch.from_numpy(psi0.copy()).cuda(), ops.new_volume(dims)
+    rep, hist = sv.iterate(torch.from_numpy(pg).cuda(), torch.from_numpy(pn).cuda(), pnp, psi, 6)
+    sv.close()
+    out, (psi_t, pnp_t) = run_world_direct(dims, grid, psi0, pg, pn, 6, 1e-10, True, keep_halo_lines_hot=True)
+    for done, h, _, _ in out:
+        assert done == rep.iterations and np.array_equal(np.asarray(h, np.float32).view(np.uint32), np.asarray(hist, np.float32).view(np.uint32))
+    assert np.array_equal(psi_t[..., :3].view(np.uint32), psi.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(pnp_t.view(np.uint32), pnp.cpu().numpy().view(np.uint32))
 
 
 def test_direct_transport_deadline():
