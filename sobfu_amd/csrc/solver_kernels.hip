@@ -13,6 +13,8 @@
 // Arithmetic is op-for-op the reference's (see sobfu_device.hpp): results are bit-identical to Part 1.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "sobfu_device.hpp"
@@ -799,14 +801,10 @@ struct TileSignal {
     const uint32_t* row;  // this rank's max-norm slot row of the PREVIOUS iteration (null: none) ...
     uint32_t row_index;   // ... which is row `row_index` of the global rows
 };
-// the same launch with its box list in DEVICE memory (a list is fixed for the life of a handle: uploaded once, read through the scalar
-// cache) instead of in the kernel-argument segment: a 1.5 KB argument block costs a launch 0.6 us (tools/calib/launch_cost.hip:
-// 2.9 -> 3.5 us back to back)
-struct TilePassAArgs {
-    PassACore c;
-    TileBoxList boxes;
-    TileSignal s;
-};
+// The box list of a launch lives in DEVICE memory (a list is fixed for the life of a handle: uploaded once -- launch_tile_pass_a keeps
+// every distinct list it has seen -- and read through the scalar cache), not in the kernel-argument segment: a 1.5 KB argument block
+// costs a launch 0.6 us (tools/calib/launch_cost.hip: 2.9 -> 3.5 us back to back), and handed on by reference it ended up copied to
+// 1.8 KB of scratch per lane (pass A 17 -> 129 us: found with SOBFU_TILED_DEBUG_SKIP=1)
 struct TilePassAArgsP {
     PassACore c;
     const TileBoxList* boxes;
@@ -870,11 +868,7 @@ SOBFU_DEV void tile_potential_gradient_body(const PassACore& core, const TileBox
 }
 
 template <int RPT, int WY, bool COMPACT, int NTL>
-__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePassAArgs a) {
-    tile_potential_gradient_body<RPT, WY, COMPACT, NTL>(a.c, a.boxes, a.s);
-}
-template <int RPT, int WY, bool COMPACT, int NTL>
-__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_planned_kernel(TilePassAArgsP a) {
+__global__ void __launch_bounds__(TX* WY) tile_potential_gradient_kernel(TilePassAArgsP a) {
     tile_potential_gradient_body<RPT, WY, COMPACT, NTL>(a.c, *a.boxes, a.s);
 }
 
@@ -943,14 +937,13 @@ SOBFU_DEV void maxnorm_tail(float msq, uint32_t* slots, uint32_t* s_max) {
 
 // DIRECT evaluation of one cell of pass B (thin boxes: the one-cell x / y shells of a tile): 19 nabla_U loads + psi + the
 // phi_n gather, op for op the marching path's arithmetic (sum = 0; taps ascending j; (Sx + Sy) + Sz)
-template <bool WRITE_UPDATES, bool COMPACT, bool IDX32>
-SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
+template <bool COMPACT, bool SYS>
+SOBFU_DEV void direct_taps(const PassBArgs& a, int x, int y, int z, float& slx, float& sly, float& slz, float& srx, float& sry, float& srz, float& szx,
+                           float& szy, float& szz) {
     const Dims d = a.d;
-    // nabla_U cells of the halo rims may have been stored by other GPUs (direct transport): read at system scope then (compact format)
-    const bool sys = COMPACT && a.sys_acquire != 0;
-    const __amdgpu_buffer_rsrc_t r_nu = buf_rsrc(a.nU, (uint32_t) ((size_t) d.x * d.y * d.z * 12));
-    auto ld_nu = [&](size_t i) { return sys ? buf_ld3_scope(r_nu, (uint32_t) (i * 12), 0u, true) : ldv<COMPACT>(a.nU, i); };
-    float slx = 0.f, sly = 0.f, slz = 0.f, srx = 0.f, sry = 0.f, srz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
+    const __amdgpu_buffer_rsrc_t r_nu = buf_rsrc(a.nU, SYS ? (uint32_t) ((size_t) d.x * d.y * d.z * 12) : 0u);
+    auto ld_nu = [&](size_t i) { return SYS ? buf_ld3_scope(r_nu, (uint32_t) (i * 12), 0u, true) : ldv<COMPACT>(a.nU, i); };
+    slx = sly = slz = srx = sry = srz = szx = szy = szz = 0.f;
 #pragma unroll
     for (int j = -3; j <= 3; ++j) {
         const float s = a.S.s[3 - j];
@@ -975,6 +968,14 @@ SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
         szy += vz.y * s;
         szz += vz.z * s;
     }
+}
+template <bool WRITE_UPDATES, bool COMPACT, bool IDX32>
+SOBFU_DEV float pass_b_direct_cell(const PassBArgs& a, int x, int y, int z) {
+    const Dims d = a.d;
+    float slx, sly, slz, srx, sry, srz, szx, szy, szz;
+    // nabla_U cells of the halo rims may have been stored by other GPUs (direct transport): the taps are read at system scope then
+    if (COMPACT && a.sys_acquire != 0) direct_taps<COMPACT, COMPACT>(a, x, y, z, slx, sly, slz, srx, sry, srz, szx, szy, szz);
+    else direct_taps<COMPACT, false>(a, x, y, z, slx, sly, slz, srx, sry, srz, szx, szy, szz);
     const float tx = (slx + srx) + szx, ty = (sly + sry) + szy, tz = (slz + srz) + szz;
     const size_t i = vidx(d, x, y, z);
     const float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
@@ -1653,63 +1654,87 @@ static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, in
             const int zc_box = zc > 0 ? zc : ((s.dst != nullptr && !s.box.direct) ? std::min(8, s.box.z1 - s.box.z0) : 0);
             total += finish_box(t.b, s.box, TY, std::max(256 * (cache_resident(X, Y, Z) ? 2 : 4) * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc_box,
                                 "SOBFU_ZC_A", false);
-            t.push = PushDst{s.dst, s.ox, s.oy, s.oz, s.px, s.py};
+            t.push.base = s.dst;  // (member by member: the list is looked up by its bytes, padding included -- the caller zeroed it)
+            t.push.ox = s.ox; t.push.oy = s.oy; t.push.oz = s.oz; t.push.px = s.px; t.push.py = s.py;
             ++L.n;
         }
         if (pass == 0) L.n_push_wgs = total;
     }
     for (int k = L.n; k <= kMaxTileBoxes; ++k) L.first[k] = total;
-    for (int k = L.n; k < kMaxTileBoxes; ++k) L.b[k] = TileBox{};
     return total;
 }
 
-int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
-                       int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact) {
-    TilePassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, nullptr, 0.f}, {}, {sync, seq, wait, row, row_index}};
-    const int total = fill_tile_boxes(a.boxes, boxes, n, X, Y, Z, zc);
-    if (total < 0) return SOBFU_E_BADARG;
-    if (total == 0) return 0;
-    const dim3 grid((unsigned) total), block(TX, SOBFU_WY);
+// device copies of the box lists seen so far (never freed: a list is 1.5 KB and a process sees a handful; a launch in flight may still
+// be reading its list)
+struct CachedBoxes {
+    TileBoxList host;
+    TileBoxList* dev;
+};
+static std::vector<CachedBoxes> g_box_cache;
+static std::mutex g_box_cache_mutex;
+static int device_boxes(const TileBoxList& L, TileBoxList** out) {
+    std::lock_guard<std::mutex> lock(g_box_cache_mutex);
+    for (const CachedBoxes& c : g_box_cache)
+        if (std::memcmp(&c.host, &L, sizeof L) == 0) {
+            *out = c.dev;
+            return 0;
+        }
+    TileBoxList* d = nullptr;
+    hipError_t e = hipMalloc((void**) &d, sizeof L);
+    if (e == hipSuccess) e = hipMemcpy(d, &L, sizeof L, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int) e;
+    g_box_cache.push_back(CachedBoxes{L, d});
+    *out = d;
+    return 0;
+}
+static int launch_tile_boxes(const TileBoxList* d_boxes, int groups, const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X,
+                             int Y, int Z, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream,
+                             bool compact) {
+    if (groups == 0) return 0;
+    TilePassAArgsP a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, nullptr, 0.f}, d_boxes, {sync, seq, wait, row, row_index}};
+    const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
     if (compact && cache_resident(X, Y, Z)) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, 0>), grid, block, 0, stream, a);
     else if (compact) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, SOBFU_NT>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, 0>), grid, block, 0, stream, a);
     return (int) hipGetLastError();
 }
 
-// A PLANNED launch of the same pass (compact format): the box list lives in device memory (built once per handle and half of the
-// nabla_U ping-pong), the kernel arguments shrink from 1.6 KB to ~100 bytes.
+int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const TileLaunchBox* boxes,
+                       int n, TileSync* sync, uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, int zc, hipStream_t stream, bool compact) {
+    TileBoxList L;
+    std::memset(&L, 0, sizeof L);  // (padding bytes too: the list is looked up by its bytes)
+    const int total = fill_tile_boxes(L, boxes, n, X, Y, Z, zc);
+    if (total < 0) return SOBFU_E_BADARG;
+    if (total == 0) return 0;
+    TileBoxList* d = nullptr;
+    SOBFU_TRY(device_boxes(L, &d));
+    return launch_tile_boxes(d, total, pnp, pg, psi, nU, w_reg, X, Y, Z, sync, seq, wait, row, row_index, stream, compact);
+}
+
+// A PLANNED launch of the same pass (compact format): the geometry is worked out once per handle and half of the nabla_U ping-pong
 struct TilePassAPlan {
     TileBoxList* d_boxes = nullptr;
     int groups = 0, X = 0, Y = 0, Z = 0;
 };
 int tile_pass_a_plan_create(TilePassAPlan** out, const TileLaunchBox* boxes, int n, int X, int Y, int Z) {
-    TileBoxList L{};
+    TileBoxList L;
+    std::memset(&L, 0, sizeof L);
     const int total = fill_tile_boxes(L, boxes, n, X, Y, Z, 0);
     if (total < 0) return SOBFU_E_BADARG;
     auto* p = new TilePassAPlan();
     p->groups = total; p->X = X; p->Y = Y; p->Z = Z;
-    hipError_t e = hipMalloc((void**) &p->d_boxes, sizeof(TileBoxList));
-    if (e == hipSuccess) e = hipMemcpy(p->d_boxes, &L, sizeof(TileBoxList), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        tile_pass_a_plan_destroy(p);
-        return (int) e;
+    const int rc = total > 0 ? device_boxes(L, &p->d_boxes) : 0;
+    if (rc != 0) {
+        delete p;
+        return rc;
     }
     *out = p;
     return 0;
 }
-void tile_pass_a_plan_destroy(TilePassAPlan* p) {
-    if (!p) return;
-    if (p->d_boxes) (void) hipFree(p->d_boxes);
-    delete p;
-}
+void tile_pass_a_plan_destroy(TilePassAPlan* p) { delete p; }
 int launch_tile_pass_a_plan(const TilePassAPlan* p, const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, TileSync* sync,
                             uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream) {
-    if (p->groups == 0) return 0;
-    TilePassAArgsP a{{pnp, pg, psi, nU, {p->X, p->Y, p->Z}, w_reg, nullptr, 0.f}, p->d_boxes, {sync, seq, wait, row, row_index}};
-    const dim3 grid((unsigned) p->groups), block(TX, SOBFU_WY);
-    if (cache_resident(p->X, p->Y, p->Z)) hipLaunchKernelGGL((tile_potential_gradient_planned_kernel<SOBFU_RPT, SOBFU_WY, true, 0>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((tile_potential_gradient_planned_kernel<SOBFU_RPT, SOBFU_WY, true, SOBFU_NT>), grid, block, 0, stream, a);
-    return (int) hipGetLastError();
+    return launch_tile_boxes(p->d_boxes, p->groups, pnp, pg, psi, nU, w_reg, p->X, p->Y, p->Z, sync, seq, wait, row, row_index, stream, true);
 }
 
 int launch_tile_pingpong(TileSync* sync, int q, int first, uint32_t seq0, int reps, hipStream_t stream) {
