@@ -13,12 +13,15 @@ struct LaunchBox {
     int x0, x1, y0, y1, z0, z1;
     bool direct;
 };
-// A box of a tile's pass A.  dst != null: a PUSH box (direct) -- the cells of one halo message, whose results go to
-// dst + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz))) only: the neighbour's halo cells (peer-mapped) or a packed send buffer.
+// A box of a tile's pass A.  dst != null: a PUSH box -- the cells of one halo message, whose results go to
+// dst + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz))): the neighbour's halo cells (peer-mapped) or a packed send buffer.
+// A MARCHING push box may be larger than its message and serve the owned block too (which then leaves those cells out): only rows
+// push_y0 <= y < push_y1 travel, and cells of planes local_z0 <= z < local_z1 are ALSO stored into this rank's own nabla_U.
 struct TileLaunchBox {
     LaunchBox box;
     float* dst;
     int ox, oy, oz, px, py;
+    int push_y0, push_y1, local_z0, local_z1;
 };
 // (X, Y, Z): extents of the field arrays; (pX, pY, pZ): extents of phi_n (the whole volume); own: the cells that enter the
 // max-norm (x0, x1, y0, y1, z0, z1).

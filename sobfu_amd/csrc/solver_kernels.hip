@@ -502,6 +502,7 @@ SOBFU_DEV float4 pass_a_direct_cell(const PassACore& a, int x, int y, int z) {
 struct PushDst {
     float* base;             // null: the box is stored locally
     int ox, oy, oz, px, py;  // cell (x, y, z) -> base + 3 * ((x + ox) + px * ((y + oy) + py * (z + oz)))
+    int y0, y1, lz0, lz1;    // marching push boxes: rows [y0, y1) travel; planes [lz0, lz1) are stored locally as well
 };
 SOBFU_DEV void st3_system(float* p, const float4& v);
 
@@ -628,9 +629,12 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
             pin3<1>(o);
             if (u < tg.u_hi && v < tg.v_hi) {
                 const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
-                if (PUSHABLE && pd->base != nullptr) {  // a marching PUSH box: the cell goes to its destination only
-                    const size_t j = (size_t) (u + pd->ox) + (size_t) pd->px * ((size_t) (v + pd->oy) + (size_t) pd->py * (size_t) (z + pd->oz));
-                    st3_system(pd->base + 3 * j, o);
+                if (PUSHABLE && pd->base != nullptr) {  // a marching PUSH box: the rows of the message go to their destination ...
+                    if (v >= pd->y0 && v < pd->y1) {
+                        const size_t j = (size_t) (u + pd->ox) + (size_t) pd->px * ((size_t) (v + pd->oy) + (size_t) pd->py * (size_t) (z + pd->oz));
+                        st3_system(pd->base + 3 * j, o);
+                    }
+                    if (z >= pd->lz0 && z < pd->lz1) stv<COMPACT>(a.nU, i, o);  // ... and where the box stands in for the owned block, home too
                 } else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
                 else stv<COMPACT>(a.nU, i, o);
             }
@@ -1620,7 +1624,7 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
     for (int i = 0; i < n; ++i) direct = direct || (boxes[i].direct && box_cells(boxes[i]) > 0);
     if (direct) {  // thin boxes: the tile kernel (no messages, no signalling)
         std::vector<TileLaunchBox> tb((size_t) n);
-        for (int i = 0; i < n; ++i) tb[(size_t) i] = TileLaunchBox{boxes[i], nullptr, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; ++i) tb[(size_t) i] = TileLaunchBox{boxes[i], nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         return launch_tile_pass_a(pnp, pg, psi, nU, w_reg, X, Y, Z, tb.data(), n, (TileSync*) nullptr, 0, 0, nullptr, 0, zc, stream, compact);
     }
     PassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, prev_slots, max_update_norm}, {}};
@@ -1656,6 +1660,7 @@ static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, in
                                 "SOBFU_ZC_A", false);
             t.push.base = s.dst;  // (member by member: the list is looked up by its bytes, padding included -- the caller zeroed it)
             t.push.ox = s.ox; t.push.oy = s.oy; t.push.oz = s.oz; t.push.px = s.px; t.push.py = s.py;
+            t.push.y0 = s.push_y0; t.push.y1 = s.push_y1; t.push.lz0 = s.local_z0; t.push.lz1 = s.local_z1;
             ++L.n;
         }
         if (pass == 0) L.n_push_wgs = total;

@@ -271,6 +271,7 @@ struct sobfu_hip_tiled {
     uint64_t timeout_ticks = 0;                    // deadline of the in-kernel waits (100 MHz ticks; SOBFU_TILED_DEADLINE_S at create)
     std::vector<sobfu_hip::TileLaunchBox> a_boxes[2];  // pass A's boxes per nabla_U half: one push box per message + the owned block
     sobfu_hip::TilePassAPlan* a_plan[2] = {nullptr, nullptr};  // ... and their launch plans (box lists in device memory)
+    sobfu_hip::TileLaunchBox a_own{};  // the owned block alone (launches without messages)
     int schedule = 0;  // 0 heuristic, 1 overlapped + pass A split, 2 overlapped + pass A whole, 3 serial (sobfu_hip_tiled_set_schedule)
     double last_enqueue_us = 0.0;  // host time per iteration the last iterate() spent issuing the loop (diagnostics)
     // optional timing of the serial schedule's three pieces with HIP events on the loop's stream (sobfu_hip_tiled_set_profiling)
@@ -300,6 +301,18 @@ double deadline_seconds() {
 // (re)builds pass A's box lists: one push box per message, then the owned block.  Destinations: the peers' halo cells when
 // connected (dst[half][i] != null), else the packed send buffer.
 void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, const TileLay* peers) {
+    // The y and z FACES are pushed by short marches whose cells the owned block would compute a second time.  Instead such a box
+    // stands in for the owned block on its cells (it stores them at home too) and the owned block shrinks: by the 4 rim planes
+    // along z, by a whole 8-row tile along y (the face box then marches 8 rows, of which the 4 rim rows travel).  Where face
+    // boxes meet, the z box is the one that stores at home.  The x face (4 cells of a 64-lane row: lane per cell) and the edge
+    // strips stay push-only: shrinking the owned block by 4 columns would not save it a single workgroup.  Measured (one box, A/B):
+    // 1 x 1 x 8 slabs of 256^3 43.1 -> 41.6 us per iteration; 2 x 2 x 2 and 1 x 2 x 4 tiles unchanged (43.4 / 44.7).
+    const int ny_nb = (t->lo[1] ? 1 : 0) + (t->hi[1] ? 1 : 0), nz_nb = (t->lo[2] ? 1 : 0) + (t->hi[2] ? 1 : 0);
+    const bool wide = (t->o1[0] - t->o0[0]) >= 64;  // rows wide enough for the faces to be MARCHED (thin rows: lane per cell, push-only)
+    const bool z_home = wide && nz_nb > 0 && (t->o1[2] - t->o0[2]) > kHalo * nz_nb;
+    const bool y_home = wide && ny_nb > 0 && (t->o1[1] - t->o0[1]) > 8 * ny_nb;
+    const int iz0 = t->o0[2] + ((z_home && t->lo[2]) ? kHalo : 0), iz1 = t->o1[2] - ((z_home && t->hi[2]) ? kHalo : 0);  // planes the z boxes leave
+    const int iy0 = t->o0[1] + ((y_home && t->lo[1]) ? 8 : 0), iy1 = t->o1[1] - ((y_home && t->hi[1]) ? 8 : 0);
     for (int h = 0; h < 2; ++h) {
         std::vector<sobfu_hip::TileLaunchBox>& v = t->a_boxes[h];
         v.clear();
@@ -310,6 +323,13 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
             // 26.6 -> 18.4 us); thin in x: direct
             const bool march = (m.sb[1] - m.sb[0]) >= 64;
             b.box = sobfu_hip::LaunchBox{m.sb[0], m.sb[1], m.sb[2], m.sb[3], m.sb[4], m.sb[5], !march};
+            b.push_y0 = m.sb[2]; b.push_y1 = m.sb[3];
+            const bool face_z = march && m.dir[0] == 0 && m.dir[1] == 0 && m.dir[2] != 0, face_y = march && m.dir[0] == 0 && m.dir[2] == 0 && m.dir[1] != 0;
+            if (face_z && z_home) { b.local_z0 = m.sb[4]; b.local_z1 = m.sb[5]; }
+            if (face_y && y_home) {
+                if (m.dir[1] > 0) b.box.y0 = t->o1[1] - 8; else b.box.y1 = t->o0[1] + 8;
+                b.local_z0 = iz0; b.local_z1 = iz1;
+            }
             float* const* dst = h ? dst1 : dst0;
             if (dst && dst[i]) {  // the matching message of the peer: direction -dir; its receive box is where these cells live there
                 const TileLay& pl = peers[i];
@@ -327,8 +347,11 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
             v.push_back(b);
         }
         sobfu_hip::TileLaunchBox own{};
-        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], false};
+        own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], iy0, iy1, iz0, iz1, false};
         v.push_back(own);
+        // the same launch without messages (a world of one; timing experiments): the whole owned block
+        t->a_own = sobfu_hip::TileLaunchBox{};
+        t->a_own.box = sobfu_hip::LaunchBox{t->o0[0], t->o1[0], t->o0[1], t->o1[1], t->o0[2], t->o1[2], false};
         sobfu_hip::tile_pass_a_plan_destroy(t->a_plan[h]);
         t->a_plan[h] = nullptr;
         if (sobfu_hip::tile_pass_a_plan_create(&t->a_plan[h], v.data(), (int) v.size(), t->L[0], t->L[1], t->L[2]) != 0) t->a_plan[h] = nullptr;
@@ -1037,7 +1060,7 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
                     SOBFU_TRY(sobfu_hip::launch_tile_pass_a_plan(t->a_plan[it & 1], f_in, t->c_g, psi_in, nu, p.w_reg, sync ? t->sync_d : nullptr,
                                                                  q.seq_base + (uint32_t) it, t->wait_enabled, row_prev, (uint32_t) (it - 1), st));
                 } else {
-                    SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, pushes ? bx.data() : &bx.back(),
+                    SOBFU_TRY(sobfu_hip::launch_tile_pass_a(f_in, t->c_g, psi_in, nu, p.w_reg, Lx, Ly, Lz, pushes ? bx.data() : &t->a_own,
                                                             pushes ? (int) bx.size() : 1, sync ? t->sync_d : nullptr, q.seq_base + (uint32_t) it,
                                                             t->wait_enabled, row_prev, (uint32_t) (it - 1), 0, st, true));
                 }
