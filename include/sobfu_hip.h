@@ -327,13 +327,11 @@ int sobfu_hip_tiled_end(sobfu_hip_tiled* t, sobfu_hip_solver_report* report, flo
  * runs beside iteration k+1 (the late gate only needs it by pass B of k+2) without ever queueing behind a halo exchange on the
  * main communicator; without it the reduction shares the exchange's communicator (comm stream, or in line when serial). */
 int sobfu_hip_tiled_add_reduce_comm(sobfu_hip_tiled* t, const char unique_id[128]);
-/* How an iteration is issued on the RCCL / callback transports (the results never depend on it; the direct transport has one way):
- * 0 = built-in heuristic (z-slabs: by thickness; 3-D tiles: serial), 1 = exchange overlapped with the interior compute -- z-slabs: pass
- * A split into boundary + interior launches; 3-D tiles: the push boxes as their own launch, send / recv + scatter on the
- * communication stream beside pass A's owned block and pass B's interior, then pass B's rim slabs --, 2 = overlapped, z-slabs: pass
- * A in one launch (3-D tiles: as 1), 3 = serial (pass A, exchange, pass B in line on one stream: no cross-stream events -- the
- * better choice when the exchange is fast).  Which one wins depends on the machine's exchange latency;
- * sobfu_amd.tiled.NativeTiledSolver.autotune times them. */
+/* How a Z-SLAB iteration is issued on the RCCL / callback transports (the results never depend on it; 3-D tiles and the direct
+ * transport have one way): 0 = built-in heuristic (by slab thickness), 1 = exchange overlapped with the interior compute, pass A
+ * split into boundary + interior launches, 2 = overlapped, pass A in one launch, 3 = serial (pass A, exchange, pass B in line on one
+ * stream: no cross-stream events -- the better choice when the exchange is fast).  Which one wins depends on the machine's
+ * exchange latency; sobfu_amd.tiled.NativeTiledSolver.autotune times them. */
 int sobfu_hip_tiled_set_schedule(sobfu_hip_tiled* t, int schedule);
 /* diagnostics: host microseconds per iteration the last sobfu_hip_tiled_iterate spent ISSUING its loop (launches, events,
  * RCCL calls) -- against the measured time per iteration it tells whether a thin slab is host-bound */

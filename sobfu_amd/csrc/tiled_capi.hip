@@ -8,7 +8,9 @@
 // convolution is exact there, so the values the next pass A reads are never exchanged.  phi_n is replicated.
 //
 // The exchange is PART OF PASS A's LAUNCH (solver_kernels.hip, tile_potential_gradient_kernel): the cells of every message
-// are evaluated by "push boxes" -- lane per cell, numbered first -- that store straight into the destination.  Transports:
+// are evaluated by "push boxes" -- numbered first; short marches for the y / z faces (which also store their cells at home: the
+// owned block leaves them out), lane per cell for the x face and the edge strips -- that store straight into the destination.
+// Transports:
 //   DIRECT    the destination is the neighbour's own nabla_U array, peer-mapped over xGMI (hipIpc; sobfu_hip_tiled_connect).
 //             No pack, no unpack, no communication launch: the last push workgroup raises this rank's arrival flag at its
 //             neighbours, the last workgroup of the launch waits for theirs (with a deadline), so the transfers overlap the
@@ -22,7 +24,7 @@
 //   CALLBACK  the same buffers handed to a user function (in-process loopback and gloo bring-up transports of the tests).
 // The one-cell x / y shells of pass B are DIRECT boxes of its launch (lane per cell), the z shells extra planes of the march.
 //
-// Schedules of the RCCL z-slab path: serial (pass A, exchange, pass B in line), or overlapped as in sobfu_amd/tiled.py:
+// Schedules of the RCCL z-slab path: serial (pass A, exchange, pass B in line), or overlapped as in tests/tiled_reference.py:
 //     A_bnd (planes next to an interior face)  ->  event  ->  [comm stream] group{send, recv} of 4 nabla_U planes / face
 //     A_int, B_int (planes whose +-3 taps are owned)            ... run while the exchange is in flight
 //     wait(comm)  ->  B_bnd (remaining planes out to owned +-1)
