@@ -270,6 +270,36 @@ def test_direct_transport_with_stale_halo_lines_in_cache(dims, grid):
     assert np.array_equal(pnp_t.view(np.uint32), pnp.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("dims,grid", [((70, 33, 23), (2, 1, 1)), ((40, 24, 36), (1, 1, 2)), ((64, 64, 64), (2, 2, 2))])
+def test_direct_transport_on_tiles_beyond_the_cache(dims, grid, monkeypatch):
+    """N = 2 and N = 4 cut 256^3 into tiles that do NOT fit the Infinity Cache: streaming hints on, and -- on connected handles -- still
+    the pipelined march of pass B (its loads carry the system scope for the cells other GPUs stored).  Forced here on small grids with
+    SOBFU_CACHE_CELLS=0: the instantiation <thin boxes, streaming hints, pipelined> of pass B and the streaming variant of the tile's
+    pass A, bit for bit against the single-GPU solve."""
+    import torch
+
+    import oracle
+    from sobfu_amd import ops
+
+    rng = np.random.default_rng(23)
+    X, Y, Z = dims
+    pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    psi0 = oracle.new_field(dims)
+    oracle.init_identity(psi0)
+    psi0[..., :3] += rng.uniform(-0.7, 0.7, psi0[..., :3].shape).astype(np.float32)
+    sv = ops.Solver(dims, max_iter=6, alpha=0.05, w_reg=0.4, max_update_norm=1e-10)
+    psi, pnp = torch.from_numpy(psi0.copy()).cuda(), ops.new_volume(dims)
+    rep, hist = sv.iterate(torch.from_numpy(pg).cuda(), torch.from_numpy(pn).cuda(), pnp, psi, 6)
+    sv.close()
+    monkeypatch.setenv("SOBFU_CACHE_CELLS", "0")
+    out, (psi_t, pnp_t) = run_world_direct(dims, grid, psi0, pg, pn, 6, 1e-10, True)
+    for done, h, _, _ in out:
+        assert done == rep.iterations and np.array_equal(np.asarray(h, np.float32).view(np.uint32), np.asarray(hist, np.float32).view(np.uint32))
+    assert np.array_equal(psi_t[..., :3].view(np.uint32), psi.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(pnp_t.view(np.uint32), pnp.cpu().numpy().view(np.uint32))
+
+
 def test_direct_transport_deadline():
     """A peer that never shows up: the wait in pass A's tail gives up at the deadline, records WHOM it missed, the handle reports
     SOBFU_E_TIMEOUT -- and the GPU is never hung."""
