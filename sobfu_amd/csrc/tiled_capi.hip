@@ -1019,7 +1019,8 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
                                                 {ax0 - 1, (xsh && t->lo[0]) ? ax0 : ax0 - 1, ay0, ay1, lo, hi, true},
                                                 {ax1, (xsh && t->hi[0]) ? ax1 + 1 : ax1, ay0, ay1, lo, hi, true}};
             return sobfu_hip::launch_pass_b_boxes(nu, const_cast<float*>(psi_in), t->c_n, f_out, nullptr, row, t->taps, p.alpha, Lx, Ly, Lz, X, Y,
-                                                  Z, own, bx, 6, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1, t->direct);
+                                                  Z, own, bx, 6, prev, p.max_update_norm, 0, st, true, psi_out, it > 3 ? 2 : 1,
+                                                  sync /* direct transport (and the handles that time its launches): peer-written cells are read at system scope */);
         };
         auto wait_gate = [&]() -> int {  // row it-2 must be global before the first pass-B launch of this iteration
             if (prev && red_issued[it & 1]) SOBFU_HIP_TRY(hipStreamWaitEvent(st, t->ev_red[it & 1], 0));
