@@ -332,6 +332,8 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
                 if (m.dir[1] > 0) b.box.y0 = t->o1[1] - 8; else b.box.y1 = t->o0[1] + 8;
                 b.local_z0 = iz0; b.local_z1 = iz1;
             }
+            if ((!march && (t->debug_skip & 128)) || (march && (t->debug_skip & 256))) continue;  // timing experiments: without the thin / the marched push boxes
+            if (march && (t->debug_skip & 512)) b.push_y1 = b.push_y0;  // timing experiments: the marched boxes keep their cells at home only
             float* const* dst = h ? dst1 : dst0;
             if (dst && dst[i]) {  // the matching message of the peer: direction -dir; its receive box is where these cells live there
                 const TileLay& pl = peers[i];
@@ -981,7 +983,8 @@ static int tiled_step_impl(sobfu_hip_tiled* t, int n_steps, hipStream_t st, int 
     const int own[6] = {ax0, ax1, ay0, ay1, lo, hi};
     const bool tiles = tile_path(t), sync = uses_sync(t);
     // timing experiments only (results are wrong): bit 0 no push boxes, bit 1 no thin shells, bit 2 no pass A, bit 3 no pass B,
-    // bit 4 no owned block in pass B, bit 5 no y shells, bit 6 no x shells
+    // bit 4 no owned block in pass B, bit 5 no y shells, bit 6 no x shells; in build_a_boxes: bit 7 no thin push boxes (x faces, edges,
+    // corners), bit 8 no marched push boxes (y / z faces), bit 9 the marched push boxes store at home only
     const bool b_direct = false;
     const int dbg = t->debug_skip;
     // pass A split into boundary + interior launches so that the exchange starts after 4 planes per face instead of after
