@@ -208,55 +208,44 @@ inline void printCudaDeviceInfo(int device) {
                 p.l2CacheSize / 1024, p.sharedMemPerBlock / 1024);
 }
 
-// ---- DeviceMemory: ref-counted hipMalloc blob (include/kfusion/cuda/device_memory.hpp:20-102) -------------------
+// ---- DeviceMemory: a shared device allocation (public surface of include/kfusion/cuda/device_memory.hpp:20-102) ---
+// Ownership is a std::shared_ptr whose deleter is hipFree: copies share the block, the last owner frees it; a block handed in by the
+// caller (pointer + size) is viewed, never owned.  create(n) keeps the block when the size already matches, create(0) is a no-op.
 class DeviceMemory {
 public:
-    DeviceMemory() : data_(nullptr), sizeBytes_(0), refcount_(nullptr) {}
-    explicit DeviceMemory(size_t n) : data_(nullptr), sizeBytes_(0), refcount_(nullptr) { create(n); }
-    DeviceMemory(void* p, size_t n) : data_(p), sizeBytes_(n), refcount_(nullptr) {}  // user buffer: no refcounting
-    DeviceMemory(const DeviceMemory& o) : data_(o.data_), sizeBytes_(o.sizeBytes_), refcount_(o.refcount_) { if (refcount_) ++*refcount_; }
-    DeviceMemory& operator=(const DeviceMemory& o) {
-        if (this != &o) {
-            if (o.refcount_) ++*o.refcount_;
-            release();
-            data_ = o.data_; sizeBytes_ = o.sizeBytes_; refcount_ = o.refcount_;
-        }
-        return *this;
-    }
-    ~DeviceMemory() { release(); }
+    DeviceMemory() = default;
+    explicit DeviceMemory(size_t n) { create(n); }
+    DeviceMemory(void* p, size_t n) : view_(p), bytes_(n) {}  // the caller's buffer
     void create(size_t n) {
-        if (n == sizeBytes_) return;
-        if (n > 0) {
-            if (data_) release();
-            sizeBytes_ = n;
-            sobfuSafeCall(hipMalloc(&data_, sizeBytes_));
-            refcount_ = new int(1);
-        }
+        if (n == bytes_ || n == 0) return;
+        void* p = nullptr;
+        sobfuSafeCall(hipMalloc(&p, n));
+        block_.reset(p, [](void* q) { (void) hipFree(q); });  // (a deleter must not throw)
+        view_  = p;
+        bytes_ = n;
     }
     void release() {
-        if (refcount_ && --*refcount_ == 0) {
-            delete refcount_;
-            sobfuSafeCall(hipFree(data_));
-        }
-        data_ = nullptr; sizeBytes_ = 0; refcount_ = nullptr;
+        block_.reset();
+        view_  = nullptr;
+        bytes_ = 0;
     }
     void copyTo(DeviceMemory& other) const {
         if (empty()) { other.release(); return; }
-        other.create(sizeBytes_);
-        sobfuSafeCall(hipMemcpy(other.data_, data_, sizeBytes_, hipMemcpyDeviceToDevice));
+        other.create(bytes_);
+        sobfuSafeCall(hipMemcpy(other.view_, view_, bytes_, hipMemcpyDeviceToDevice));
     }
-    void upload(const void* host, size_t n) { create(n); sobfuSafeCall(hipMemcpy(data_, host, n, hipMemcpyHostToDevice)); }
-    void download(void* host) const { sobfuSafeCall(hipMemcpy(host, data_, sizeBytes_, hipMemcpyDeviceToHost)); }
-    void swap(DeviceMemory& o) { std::swap(data_, o.data_); std::swap(sizeBytes_, o.sizeBytes_); std::swap(refcount_, o.refcount_); }
-    template <class T> T* ptr() { return (T*) data_; }
-    template <class T> const T* ptr() const { return (const T*) data_; }
-    bool empty() const { return !data_; }
-    size_t sizeBytes() const { return sizeBytes_; }
+    void upload(const void* host, size_t n) { create(n); sobfuSafeCall(hipMemcpy(view_, host, n, hipMemcpyHostToDevice)); }
+    void download(void* host) const { sobfuSafeCall(hipMemcpy(host, view_, bytes_, hipMemcpyDeviceToHost)); }
+    void swap(DeviceMemory& o) { block_.swap(o.block_); std::swap(view_, o.view_); std::swap(bytes_, o.bytes_); }
+    template <class T> T* ptr() { return (T*) view_; }
+    template <class T> const T* ptr() const { return (const T*) view_; }
+    bool empty() const { return view_ == nullptr; }
+    size_t sizeBytes() const { return bytes_; }
 
 private:
-    void* data_;
-    size_t sizeBytes_;
-    int* refcount_;
+    std::shared_ptr<void> block_;  // the owner (empty for a caller's buffer)
+    void* view_   = nullptr;
+    size_t bytes_ = 0;
 };
 typedef DeviceMemory CudaData;
 
