@@ -412,6 +412,153 @@ def bench_frames(args, ranks, torch):
             "iterations_per_frame": iters, "psi_moved_max_abs": moved}
 
 
+def _left(args):
+    return float("inf") if getattr(args, "deadline", None) is None else args.deadline - time.time()
+
+
+CORE_LINE = None    # rank 0: the early copy of a tiled run's line (value, legs, parity)
+CORE_READY_AT = None  # every rank: when the timed legs were done (on_core)
+LINE_LOCK = None      # whoever takes it prints THE line (the normal path or the watchdog): exactly one JSON line on stdout either way
+
+
+def _arm_watchdog(args, rank):
+    """--budget-s is a promise about when the line is on stdout.  Once the core of a tiled run's line exists (timed legs + bitwise
+    self-checks done: on_core), a run still busy 25 s past its deadline (a harvest collective that never returns, a sick node) prints
+    that core line (rank 0) and every rank leaves.  Before the core exists there is nothing valid to print: the run goes on."""
+    import threading
+
+    global LINE_LOCK
+    LINE_LOCK = threading.Lock()
+    if args.deadline is None:
+        return
+
+    def run():
+        while True:
+            if CORE_READY_AT is not None and time.time() > max(args.deadline + 25.0, CORE_READY_AT + 20.0):
+                if not LINE_LOCK.acquire(blocking=False):
+                    return  # the normal path is printing the full line
+                if rank == 0 and CORE_LINE is not None:
+                    import ctypes
+
+                    ctypes.CDLL(None).fflush(None)
+                    print(CORE_LINE, flush=True)
+                os._exit(0)
+            time.sleep(0.5)
+
+    threading.Thread(target=run, daemon=True).start()
+
+
+def make_line(args, P, res, world, force_tiled, full=True):
+    """the JSON line from a result dict.  full=False: the EARLY copy of a tiled run (no live PMC passes, no CPU baseline)"""
+    replicas = world > 1 and args.replicas
+    K = args.steps
+    secs = sorted(res["region_seconds"])
+    med = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
+    mult = world if replicas else 1
+    its = mult * K / med
+    N = res["N"]
+    ms_b, ms_a = res.get("ms_b"), res.get("ms_a")
+
+    def gbps(nbytes, ms):
+        return (nbytes / (ms * 1e-3) / 1e9) if ms else None
+
+    pmc = pmc_file = pmc_stale = None
+    for name in ("pmc_latest.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            import hashlib
+
+            with open(path) as f:
+                pj = json.load(f)
+            pmc, pmc_file = pj.get("pass_b_hbm_bytes_per_launch"), "profiles/" + name
+            with open(os.path.join(ROOT, "sobfu_amd", "csrc", "solver_kernels.hip"), "rb") as f:
+                pmc_stale = pj.get("kernel_source_sha256") != hashlib.sha256(f.read()).hexdigest()  # measured on other kernels?
+    NL = res.get("launch_cells") or N  # cells one launch produces on one GPU (the largest tile's owned cells when tiled)
+    ach_b = gbps(NL * B_PASS_B, ms_b)
+    phys_b = gbps(NL * C_PASS_B, ms_b)
+    out = {
+        "metric": f"solver iterations/sec on {args.dim}^3 voxel grid",
+        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": 1e3 * med / K, "higher_is_better": True,
+        "scaling": ("strong" if not replicas else "weak") if world > 1 else "single", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.dim}^3 TSDF, params_boxing.ini solver values (alpha 0.001, w_reg 0.6, S=7, "
+                               f"lambda 0.1, max_update_norm 1e-10), two analytic spheres 1.3 voxels apart; a step = one solver "
+                               f"iteration of an open solve",
+                   "grid": [args.dim] * 3, "parallelism": res["parallelism"]},
+        "repeats": len(secs), "timing": f"median of {len(secs)} regions of {K} iterations (barrier + synchronize around each, MAX over ranks)",
+        "region_its": [round(mult * K / s, 1) for s in res["region_seconds"]],
+        # whole-iteration view, per GPU: the 76 B/voxel the compact format must move per iteration against the HBM peak.
+        # (SURVEY 8(d) prices an iteration at 112 algorithmic B/voxel; at that price the same run is
+        # `iteration_algorithmic_GBps`, which can exceed the peak precisely because the format moves fewer bytes.)
+        "iteration_physical_GBps": N * C_ITER * its / world / 1e9,
+        "iteration_hbm_frac_physical": (N * C_ITER * its / world / 1e9) / HBM_PEAK_GBPS,
+        "iteration_algorithmic_GBps": N * B_ITER * its / world / 1e9,
+        "last_max_update_norm": res.get("last_norm"),
+        "solver_workspace_bytes": res.get("workspace"),
+    }
+    traffic, traffic_err = (None, "not measured (--no-traffic, N > 1 or another grid path)")
+    skipped = list(res.get("skipped") or [])
+    if world == 1 and not args.no_traffic and not force_tiled and ms_b and full:
+        if _left(args) > 40.0:
+            traffic, traffic_err = measure_traffic(args)
+        else:
+            traffic_err = "skipped: the run's --budget-s left no room for the two PMC passes"
+            skipped.append("roofline.traffic")
+    if ms_b:
+        out["roofline"] = {
+            "kernel": "fused_smooth_update_apply_kernel (pass B: sum of three 1-D Sobolev convolutions + psi update + phi_n o psi "
+                      "warp + max-norm)",
+            "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBPS,
+            # L2 <-> fabric bytes per launch of this kernel from rocprofv3's FETCH_SIZE / WRITE_SIZE counters, measured NOW by two
+            # short PMC passes over this script (measure_traffic); null when that was not possible
+            "traffic": traffic["b"]["bytes"] if traffic else None,
+            "traffic_GBps": gbps(traffic["b"]["bytes"], ms_b) if traffic else None,
+            "traffic_frac": (gbps(traffic["b"]["bytes"], ms_b) / HBM_PEAK_GBPS) if traffic else None,
+            "traffic_how": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 20 iterations each) of this script just now; "
+                            "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the factors calibrated on this part; " +
+                            f"{traffic['b']['launches']} launches averaged") if traffic else traffic_err,
+            "algorithmic_bytes_per_launch": NL * B_PASS_B, "avg_launch_ms": ms_b, "launches_timed": res.get("n_prof"),
+            "how": "HIP events on the solver's stream around every pass-A / pass-B launch of the profiled regions"
+                   + ("; per GPU: one launch produces the largest tile's owned cells (MAX over ranks of the averages)" if res.get("launch_cells") else ""),
+            # the solver iterates on a compact copy of the state (12-byte psi / nabla_U, tsdf-only TSDF streams): the bytes
+            # the kernel must physically move are below the survey's algorithmic figure
+            "physical_bytes_per_launch": NL * C_PASS_B, "physical_GBps": phys_b, "frac_physical": phys_b / HBM_PEAK_GBPS,
+            "traffic_from_profiles": {"file": pmc_file, "bytes_per_launch": pmc, "GBps": gbps(pmc, ms_b) if pmc else None,
+                                      "stale": pmc_stale,  # true: the kernel source has changed since the counters were collected
+                                      "note": "rocprofv3 PMC pass committed under profiles/, NOT measured in this run"},
+            "pass_a": {"avg_launch_ms": ms_a, "algorithmic_bytes_per_launch": NL * B_PASS_A, "physical_bytes_per_launch": NL * C_PASS_A,
+                       "traffic": traffic["a"]["bytes"] if traffic else None,
+                       "physical_GBps": gbps(NL * C_PASS_A, ms_a), "frac_physical": gbps(NL * C_PASS_A, ms_a) / HBM_PEAK_GBPS},
+            "event_sum_vs_step": (ms_a + ms_b + (res.get("ms_exchange") or 0.0)) / (1e3 * med / K),
+        }
+        if res.get("ms_exchange") is not None:  # N > 1, serial schedule: what an iteration is made of
+            out["tiled_iteration_ms"] = {"pass_a_incl_message_stores" + ("_and_peer_wait" if res.get("transport") == "direct" else ""): ms_a,
+                                         "exchange_transfer_and_scatter": res["ms_exchange"], "pass_b": ms_b}
+    if res.get("solve50_s"):
+        s50 = res["solve50_s"]
+        out["per_solve"] = {"iterations": 50, "ms": 1e3 * s50, "fixed_ms": 1e3 * s50 - 50 * 1e3 * med / K,
+                            "iterations_per_s_incl_fixed": 50 / s50,
+                            "note": "one whole sobfu_hip_solver_iterate call of 50 iterations (BASELINE config 3's frame): enter the "
+                                    "compact format + 50 iterations + max-norm rows to the host + leave, host-synchronised"}
+    for k in ("tiles", "legs", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame", "topology"):
+        if res.get(k):
+            out[k] = res[k]
+    if GPU_STATE is not None:
+        out["gpu_state"] = GPU_STATE.report()
+    if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise
+        out["tiled_parity_vs_single_gpu"] = "bit-exact" if res["tiled_parity"] else "MISMATCH"
+    if world == 1 and not args.no_cpu_baseline and full:
+        if _left(args) > 45.0:
+            out["cpu_baseline"] = cpu_baseline(P)
+        else:
+            skipped.append("cpu_baseline")
+    if args.budget_s > 0:
+        out["budget_s"] = args.budget_s
+    if skipped:
+        out["skipped"] = skipped
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -436,7 +583,17 @@ def main():
                          "params_umbrella.ini values at 512^3 (BASELINE config 5; use with --replicas for batched sequences)")
     ap.add_argument("--frame-dim", type=int, default=0, help="grid edge of the per-frame pipeline (default: --dim)")
     ap.add_argument("--frame-iters", type=int, default=50, help="solver iterations per frame (MAX_ITER; BASELINE config 3 states 50)")
+    ap.add_argument("--budget-s", type=float, default=-1.0,
+                    help="wall-clock budget of the WHOLE run in seconds, counted from the first process's start.  The timed legs always run; "
+                         "every harvest step behind them (diagnostics, other tile grids, frames on tiles, topology; at N = 1 the PMC traffic "
+                         "passes, the CPU baseline, the per-frame pipeline) runs only while the budget leaves room for it and is listed under "
+                         "`skipped` otherwise; a run still busy 25 s past its budget prints the core line it already holds and exits.  "
+                         "Default: 540 s at N > 1, none at N = 1; 0 = none")
     args = ap.parse_args()
+    os.environ.setdefault("SOBFU_BENCH_T0", repr(time.time()))  # (inherited by the ranks of a self-launched run: one clock for all)
+    if args.budget_s < 0:
+        args.budget_s = 540.0 if (args.gpus > 1 and not args.replicas) else 0.0
+    args.deadline = (float(os.environ["SOBFU_BENCH_T0"]) + args.budget_s) if args.budget_s > 0 else None
     if args.frames < 0:
         args.frames = 5 if (args.gpus == 1 or args.replicas) else 4  # tiles: frame 0 + three timed frames of the tiled pipeline
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -460,115 +617,37 @@ def main():
 
     P = boxing_params(args.dim)
     force_tiled = os.environ.get("SOBFU_FORCE_TILED") == "1"  # exercise the tile path on one GPU (debugging)
+    _arm_watchdog(args, rank)
     if (world > 1 and not args.replicas) or force_tiled:
         import bench_tiled
+
+        def on_core(core_res):  # called by every rank as soon as the timed legs and their bitwise self-checks are done
+            global CORE_LINE, CORE_READY_AT
+            CORE_READY_AT = time.time()
+            if rank == 0:
+                CORE_LINE = json.dumps(make_line(args, P, core_res, world, force_tiled, full=False))
+                print("[bench] core line (early copy; the full line is the last line on stdout): " + CORE_LINE, file=sys.stderr, flush=True)
+
+        args.on_core = on_core
 
         res = bench_tiled.bench_tiled(args, P, ranks, timed_regions)
     else:
         res = bench_single(args, P, ranks, torch)
         if args.frames >= 2 and not force_tiled:
-            res["per_frame"] = bench_frames(args, ranks, torch)
+            go = _left(args) > 30.0
+            if world > 1:  # replicas: rank 0's clock decides for everybody (bench_frames ends in a collective)
+                go = ranks.min([1.0 if (rank != 0 or go) else 0.0])[0] == 1.0
+            if go:
+                res["per_frame"] = bench_frames(args, ranks, torch)
+            else:
+                res["skipped"] = list(res.get("skipped") or []) + ["per_frame"]
 
-    out = None
-    if rank == 0:
-        replicas = world > 1 and args.replicas
-        K = args.steps
-        secs = sorted(res["region_seconds"])
-        med = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
-        mult = world if replicas else 1
-        its = mult * K / med
-        N = res["N"]
-        ms_b, ms_a = res.get("ms_b"), res.get("ms_a")
-
-        def gbps(nbytes, ms):
-            return (nbytes / (ms * 1e-3) / 1e9) if ms else None
-
-        pmc = pmc_file = pmc_stale = None
-        for name in ("pmc_latest.json",):
-            path = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(path):
-                import hashlib
-
-                with open(path) as f:
-                    pj = json.load(f)
-                pmc, pmc_file = pj.get("pass_b_hbm_bytes_per_launch"), "profiles/" + name
-                with open(os.path.join(ROOT, "sobfu_amd", "csrc", "solver_kernels.hip"), "rb") as f:
-                    pmc_stale = pj.get("kernel_source_sha256") != hashlib.sha256(f.read()).hexdigest()  # measured on other kernels?
-        NL = res.get("launch_cells") or N  # cells one launch produces on one GPU (the largest tile's owned cells when tiled)
-        ach_b = gbps(NL * B_PASS_B, ms_b)
-        phys_b = gbps(NL * C_PASS_B, ms_b)
-        out = {
-            "metric": f"solver iterations/sec on {args.dim}^3 voxel grid",
-            "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": 1e3 * med / K, "higher_is_better": True,
-            "scaling": ("strong" if not replicas else "weak") if world > 1 else "single", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.dim}^3 TSDF, params_boxing.ini solver values (alpha 0.001, w_reg 0.6, S=7, "
-                                   f"lambda 0.1, max_update_norm 1e-10), two analytic spheres 1.3 voxels apart; a step = one solver "
-                                   f"iteration of an open solve",
-                       "grid": [args.dim] * 3, "parallelism": res["parallelism"]},
-            "repeats": len(secs), "timing": f"median of {len(secs)} regions of {K} iterations (barrier + synchronize around each, MAX over ranks)",
-            "region_its": [round(mult * K / s, 1) for s in res["region_seconds"]],
-            # whole-iteration view, per GPU: the 76 B/voxel the compact format must move per iteration against the HBM peak.
-            # (SURVEY 8(d) prices an iteration at 112 algorithmic B/voxel; at that price the same run is
-            # `iteration_algorithmic_GBps`, which can exceed the peak precisely because the format moves fewer bytes.)
-            "iteration_physical_GBps": N * C_ITER * its / world / 1e9,
-            "iteration_hbm_frac_physical": (N * C_ITER * its / world / 1e9) / HBM_PEAK_GBPS,
-            "iteration_algorithmic_GBps": N * B_ITER * its / world / 1e9,
-            "last_max_update_norm": res.get("last_norm"),
-            "solver_workspace_bytes": res.get("workspace"),
-        }
-        traffic, traffic_err = (None, "not measured (--no-traffic, N > 1 or another grid path)")
-        if world == 1 and not args.no_traffic and not force_tiled and ms_b:
-            traffic, traffic_err = measure_traffic(args)
-        if ms_b:
-            out["roofline"] = {
-                "kernel": "fused_smooth_update_apply_kernel (pass B: sum of three 1-D Sobolev convolutions + psi update + phi_n o psi "
-                          "warp + max-norm)",
-                "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBPS,
-                # L2 <-> fabric bytes per launch of this kernel from rocprofv3's FETCH_SIZE / WRITE_SIZE counters, measured NOW by two
-                # short PMC passes over this script (measure_traffic); null when that was not possible
-                "traffic": traffic["b"]["bytes"] if traffic else None,
-                "traffic_GBps": gbps(traffic["b"]["bytes"], ms_b) if traffic else None,
-                "traffic_frac": (gbps(traffic["b"]["bytes"], ms_b) / HBM_PEAK_GBPS) if traffic else None,
-                "traffic_how": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 20 iterations each) of this script just now; "
-                                "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the factors calibrated on this part; " +
-                                f"{traffic['b']['launches']} launches averaged") if traffic else traffic_err,
-                "algorithmic_bytes_per_launch": NL * B_PASS_B, "avg_launch_ms": ms_b, "launches_timed": res.get("n_prof"),
-                "how": "HIP events on the solver's stream around every pass-A / pass-B launch of the profiled regions"
-                       + ("; per GPU: one launch produces the largest tile's owned cells (MAX over ranks of the averages)" if res.get("launch_cells") else ""),
-                # the solver iterates on a compact copy of the state (12-byte psi / nabla_U, tsdf-only TSDF streams): the bytes
-                # the kernel must physically move are below the survey's algorithmic figure
-                "physical_bytes_per_launch": NL * C_PASS_B, "physical_GBps": phys_b, "frac_physical": phys_b / HBM_PEAK_GBPS,
-                "traffic_from_profiles": {"file": pmc_file, "bytes_per_launch": pmc, "GBps": gbps(pmc, ms_b) if pmc else None,
-                                          "stale": pmc_stale,  # true: the kernel source has changed since the counters were collected
-                                          "note": "rocprofv3 PMC pass committed under profiles/, NOT measured in this run"},
-                "pass_a": {"avg_launch_ms": ms_a, "algorithmic_bytes_per_launch": NL * B_PASS_A, "physical_bytes_per_launch": NL * C_PASS_A,
-                           "traffic": traffic["a"]["bytes"] if traffic else None,
-                           "physical_GBps": gbps(NL * C_PASS_A, ms_a), "frac_physical": gbps(NL * C_PASS_A, ms_a) / HBM_PEAK_GBPS},
-                "event_sum_vs_step": (ms_a + ms_b + (res.get("ms_exchange") or 0.0)) / (1e3 * med / K),
-            }
-            if res.get("ms_exchange") is not None:  # N > 1, serial schedule: what an iteration is made of
-                out["tiled_iteration_ms"] = {"pass_a_incl_message_stores" + ("_and_peer_wait" if res.get("transport") == "direct" else ""): ms_a,
-                                             "exchange_transfer_and_scatter": res["ms_exchange"], "pass_b": ms_b}
-        if res.get("solve50_s"):
-            s50 = res["solve50_s"]
-            out["per_solve"] = {"iterations": 50, "ms": 1e3 * s50, "fixed_ms": 1e3 * s50 - 50 * 1e3 * med / K,
-                                "iterations_per_s_incl_fixed": 50 / s50,
-                                "note": "one whole sobfu_hip_solver_iterate call of 50 iterations (BASELINE config 3's frame): enter the "
-                                        "compact format + 50 iterations + max-norm rows to the host + leave, host-synchronised"}
-        for k in ("tiles", "legs", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame", "topology"):
-            if res.get(k):
-                out[k] = res[k]
-        if GPU_STATE is not None:
-            out["gpu_state"] = GPU_STATE.report()
-        if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise
-            out["tiled_parity_vs_single_gpu"] = "bit-exact" if res["tiled_parity"] else "MISMATCH"
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P)
+    out = make_line(args, P, res, world, force_tiled) if rank == 0 else None
     mismatch = res.get("tiled_parity") is False  # every rank holds the same verdict (MIN over ranks)
     if res.get("diag_hung_any"):
         # a diagnostics collective never returned on SOME rank (the verdict was agreed over a side channel that is not the
         # wedged communicator): nobody enters another collective -- every rank reports what was measured and leaves
+        LINE_LOCK.acquire()  # (never released: the watchdog must not print a second line)
         if rank == 0:
             import ctypes
 
@@ -582,6 +661,7 @@ def main():
 
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
+        LINE_LOCK.acquire()  # (never released: the watchdog must not print a second line)
         print(json.dumps(out), flush=True)
         # nothing may follow the line on stdout (RCCL writes banners from destructors / at exit): point fd 1 at /dev/null for the
         # rest of the process instead of killing it -- exit hooks (rocprofv3 writing its results) must still run

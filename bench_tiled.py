@@ -220,9 +220,11 @@ def direct_transport_sandbox(P, ranks, kw, grid, timeout=240):
     return None if all_ok else (why or "sandboxed probe failed on another rank")
 
 
-def direct_transport_usable(P, ranks, kw, grid):
-    """sandboxed probe in child processes, then the bitwise precheck in the ranks themselves (repeated once); None = usable"""
-    why = direct_transport_sandbox(P, ranks, kw, grid)  # first in child processes (a GPU fault there costs nothing) ...
+def direct_transport_usable(P, ranks, kw, grid, left=float("inf")):
+    """sandboxed probe in child processes, then the bitwise precheck in the ranks themselves (repeated once); None = usable.
+    left: seconds of the run's budget (the probe may take a third of it, at most 240 s)"""
+    probe_s = 240 if left == float("inf") else int(ranks.min([max(30.0, min(240.0, left / 3.0))])[0])
+    why = direct_transport_sandbox(P, ranks, kw, grid, timeout=probe_s)  # first in child processes (a GPU fault there costs nothing) ...
     if why is None:
         why = direct_transport_precheck(P, ranks, kw, grid)  # ... then in this one
         if why is not None:
@@ -490,6 +492,24 @@ def run_leg(args, P, ranks, timed_regions, grid, transport_name, kw):
     return leg
 
 
+def seconds_left(args):
+    """seconds until the run's --budget-s deadline (inf: no budget)"""
+    dl = getattr(args, "deadline", None)
+    return float("inf") if dl is None else dl - time.time()
+
+
+def agree(ranks, key, value):
+    """rank 0's decision, for every rank (over the rendezvous store: a skip decided on local clocks could leave some ranks in a
+    collective the others never enter)"""
+    if ranks.world == 1 or not dist.is_initialized():
+        return value
+    store = dist.distributed_c10d._get_default_store()
+    if ranks.rank == 0:
+        store.set(key, "1" if value else "0")
+        return value
+    return store.get(key) == b"1"
+
+
 def _last_enqueue_us(solver):
     lib = solver._lib.lib()
     lib.sobfu_hip_tiled_last_enqueue_us.restype = C.c_double
@@ -524,7 +544,7 @@ def bench_tiled(args, P, ranks, timed_regions):
     legs, usable = {}, {}
     direct_why = None
     if want in ("both", "direct") and world > 1:
-        direct_why = direct_transport_usable(P, ranks, kw, grid)
+        direct_why = direct_transport_usable(P, ranks, kw, grid, seconds_left(args))
         if direct_why is not None:
             print(f"[rank {rank}] direct transport not used: {direct_why}", file=sys.stderr, flush=True)
             legs["direct"] = {"failed": direct_why}
@@ -555,6 +575,46 @@ def bench_tiled(args, P, ranks, timed_regions):
         raise SystemExit(3 if mismatch else 2)
     best = max(good, key=lambda k: good[k]["value"])
     main = good[best]
+
+    def result(extras, hung, hung_any, grid_times, skipped):
+        own = main["owned"]
+        what = (f"{world} z-slabs of {own[2]} planes" if main["slab"] else f"{grid[0]}x{grid[1]}x{grid[2]} tiles of {own[0]}x{own[1]}x{own[2]} cells")
+        via = {"direct": "peer-mapped stores over xGMI issued by pass A's own launch (no pack / unpack, no RCCL in the loop; arrival flags "
+                         "and max-norm rows travel the same way)",
+               "rccl": "gloo (ranks share a GPU: bring-up transport)" if main["over_gloo"] else "RCCL send/recv (packed by pass A's launch, one scatter kernel)"}
+        pub = {}
+        for name, leg in legs.items():
+            if "failed" in leg:
+                pub[name] = {"failed": leg["failed"]}
+            else:
+                pub[name] = {k: v for k, v in leg.items() if not k.startswith("_") and k not in ("region_seconds", "owned", "slab")}
+                pub[name]["region_its"] = [round(args.steps / s, 1) for s in leg["region_seconds"]]
+                pub[name]["tiled_parity_vs_single_gpu"] = "bit-exact" if leg["parity"] else ("MISMATCH" if leg["parity"] is False else None)
+        layouts = [TileLayout(dims, grid, q) for q in range(world)]
+        return dict(diag_hung=hung, diag_hung_any=hung_any, transport=best, transport_fallback=direct_why, legs=pub,
+                    region_seconds=main["region_seconds"], N=X * Y * Z, ms_a=main["ms_a"], ms_b=main["ms_b"], ms_exchange=main["ms_exchange"],
+                    n_prof=main["n_prof"], last_norm=main["last_norm"], workspace=None, tiled_parity=main["parity"],
+                    launch_cells=max((l.g1[0] - l.g0[0]) * (l.g1[1] - l.g0[1]) * (l.g1[2] - l.g0[2]) for l in layouts),
+                    tiled_diag={k: v for k, v in extras.items() if k in ("direct_diag", "rccl_diag", "iteration_us_compute_only", "error")} or None,
+                    topology=extras.get("topology"), per_frame=extras.get("per_frame"),
+                    tiles={"grid": list(grid), "owned_cells_rank0": list(TileLayout(dims, grid, 0).g1[a] - TileLayout(dims, grid, 0).g0[a] for a in range(3)),
+                           "halo": HALO, "messages_per_exchange_rank0": len(TileLayout(dims, grid, 0).messages())},
+                    parallelism=f"{what} (+{HALO}-cell halos), one nabla_U halo exchange per iteration over {via[best]}, native C++ loop"
+                                + (f", schedule: {main['schedule']}" if main.get("schedule") else ""),
+                    tiled_autotune_us=grid_times or None, skipped=skipped or None)
+
+    # THE CORE OF THE LINE EXISTS NOW (value, both legs, parity): hand it to bench.py before any harvest step runs -- it keeps an early
+    # copy and, if the run is still busy when its budget ends, prints that copy instead of nothing
+    if getattr(args, "on_core", None) is not None:
+        args.on_core(result({}, False, False, dict(grid_times), ["everything after the timed legs (the run reached its --budget-s deadline)"]))
+    skipped = []
+
+    def want_step(name, estimate_s):
+        """does the budget leave room for a harvest step of about estimate_s seconds?  (rank 0 decides for everybody)"""
+        ok = agree(ranks, f"sobfu_step_{name}", seconds_left(args) > estimate_s + 15.0)
+        if not ok:
+            skipped.append(name)
+        return ok
     # everything below is outside the timed regions and runs in a worker thread with a deadline: whatever happens in there (an
     # exception on one rank would leave the others waiting in a collective), the benchmark line is still printed
     extras, hung = {}, False
@@ -566,33 +626,34 @@ def bench_tiled(args, P, ranks, timed_regions):
         def work():
             try:
                 torch.cuda.set_device(dev_index)
-                if rank == 0:
+                if want_step("topology", 35) and rank == 0:
                     box["topology"] = topology_snapshot(ranks)
-                if "direct" in good and world > 1:
+                if "direct" in good and world > 1 and want_step("direct_diag", 30):
                     box["direct_diag"] = direct_micro_diagnostics(good["direct"]["_solver"], ranks)
-                if "rccl" in good and world > 1:
+                if "rccl" in good and world > 1 and want_step("rccl_diag", 20):
                     box["rccl_diag"] = rccl_micro_diagnostics(good["rccl"]["_solver"], ranks)
                 # the compute side alone (same tile, no peers) next to the measured iteration
-                pg, pn_full = main["_state"]
-                dry = NativeTiledSolver(dims, dry=(world, rank), grid=grid, **kw)
-                pnp, psi = dry.new_local(2), dry.identity_psi()
-                box["iteration_us_compute_only"] = round(_timed(ranks, lambda: dry.iterate(pg, pn_full, pnp, psi, 60), 2) / 60, 2)
-                dry.close()
+                if want_step("iteration_us_compute_only", 10):
+                    pg, pn_full = main["_state"]
+                    dry = NativeTiledSolver(dims, dry=(world, rank), grid=grid, **kw)
+                    pnp, psi = dry.new_local(2), dry.identity_psi()
+                    box["iteration_us_compute_only"] = round(_timed(ranks, lambda: dry.iterate(pg, pn_full, pnp, psi, 60), 2) / 60, 2)
+                    dry.close()
                 for leg in good.values():  # the timed handles are done: their memory goes before the grid sweep
                     leg["_solver"].close()
+                frames = args.frames if args.frames >= 2 else 0
+                if frames and want_step("per_frame", 45):  # (before the grid sweep: frames/s on tiles is the scarcer number)
+                    box["per_frame"] = frames_on_tiles(args, ranks, grid, best, frames)
                 if world > 1:
                     for name in good:
-                        if name not in grid_times:
+                        if name not in grid_times and want_step(f"tiled_autotune_us.{name}", 60):
                             box.setdefault("grids", {})[name] = time_grids(P, ranks, kw, name)
-                frames = args.frames if args.frames >= 2 else 0
-                if frames:
-                    box["per_frame"] = frames_on_tiles(args, ranks, grid, best, frames)
             except Exception as e:  # noqa: BLE001
                 box["error"] = repr(e)
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("SOBFU_TILED_DIAG_TIMEOUT", "420")))
+        th.join(timeout=max(5.0, min(float(os.environ.get("SOBFU_TILED_DIAG_TIMEOUT", "420")), seconds_left(args) - 10.0)))
         hung = th.is_alive()
         extras = dict(box)
         if hung or "error" in box:
@@ -611,28 +672,6 @@ def bench_tiled(args, P, ranks, timed_regions):
             hung_any = True
     for name, t in (extras.get("grids") or {}).items():
         grid_times[name] = t
-    own = main["owned"]
-    what = (f"{world} z-slabs of {own[2]} planes" if main["slab"] else f"{grid[0]}x{grid[1]}x{grid[2]} tiles of {own[0]}x{own[1]}x{own[2]} cells")
-    via = {"direct": "peer-mapped stores over xGMI issued by pass A's own launch (no pack / unpack, no RCCL in the loop; arrival flags "
-                     "and max-norm rows travel the same way)",
-           "rccl": "gloo (ranks share a GPU: bring-up transport)" if main["over_gloo"] else "RCCL send/recv (packed by pass A's launch, one scatter kernel)"}
-    pub = {}
-    for name, leg in legs.items():
-        if "failed" in leg:
-            pub[name] = {"failed": leg["failed"]}
-        else:
-            pub[name] = {k: v for k, v in leg.items() if not k.startswith("_") and k not in ("region_seconds", "owned", "slab")}
-            pub[name]["region_its"] = [round(args.steps / s, 1) for s in leg["region_seconds"]]
-            pub[name]["tiled_parity_vs_single_gpu"] = "bit-exact" if leg["parity"] else ("MISMATCH" if leg["parity"] is False else None)
-    layouts = [TileLayout(dims, grid, q) for q in range(world)]
-    return dict(diag_hung=hung, diag_hung_any=hung_any, transport=best, transport_fallback=direct_why, legs=pub,
-                region_seconds=main["region_seconds"], N=X * Y * Z, ms_a=main["ms_a"], ms_b=main["ms_b"], ms_exchange=main["ms_exchange"],
-                n_prof=main["n_prof"], last_norm=main["last_norm"], workspace=None, tiled_parity=main["parity"],
-                launch_cells=max((l.g1[0] - l.g0[0]) * (l.g1[1] - l.g0[1]) * (l.g1[2] - l.g0[2]) for l in layouts),
-                tiled_diag={k: v for k, v in extras.items() if k in ("direct_diag", "rccl_diag", "iteration_us_compute_only", "error")} or None,
-                topology=extras.get("topology"), per_frame=extras.get("per_frame"),
-                tiles={"grid": list(grid), "owned_cells_rank0": list(TileLayout(dims, grid, 0).g1[a] - TileLayout(dims, grid, 0).g0[a] for a in range(3)),
-                       "halo": HALO, "messages_per_exchange_rank0": len(TileLayout(dims, grid, 0).messages())},
-                parallelism=f"{what} (+{HALO}-cell halos), one nabla_U halo exchange per iteration over {via[best]}, native C++ loop"
-                            + (f", schedule: {main['schedule']}" if main.get("schedule") else ""),
-                tiled_autotune_us=grid_times or None)
+    if hung:
+        skipped.append("harvest steps still running when the diagnostics deadline / the run's budget ended")
+    return result(extras, hung, hung_any, grid_times, skipped)

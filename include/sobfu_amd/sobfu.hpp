@@ -82,6 +82,43 @@ struct Ptr : std::shared_ptr<T> {
     Ptr(T* p) : std::shared_ptr<T>(p) {}
     Ptr(const std::shared_ptr<T>& p) : std::shared_ptr<T>(p) {}
 };
+// dense n-D host array, as far as the reference's tests use cv::Mat (test/deformation_field_test.cpp:96-105): the n-D constructor,
+// ptr<T>() as a download target, at<T>(i0, i1, i2) with the LAST index fastest
+#ifndef CV_32F
+#define CV_8U 0
+#define CV_16U 2
+#define CV_32S 4
+#define CV_32F 5
+#define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
+#define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
+#define CV_32FC3 CV_MAKETYPE(CV_32F, 3)
+#define CV_32FC4 CV_MAKETYPE(CV_32F, 4)
+#endif
+class Mat {
+public:
+    Mat() : dims(0), type_(0) {}
+    Mat(int ndims, const int* sizes, int type) : dims(ndims), type_(type), size_(sizes, sizes + ndims) {
+        size_t n = elemSize();
+        for (int i = 0; i < ndims; ++i) n *= (size_t) sizes[i];
+        data_ = std::make_shared<std::vector<unsigned char>>(n);
+    }
+    size_t elemSize() const {
+        static const size_t depth_bytes[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+        return depth_bytes[type_ & 7] * (size_t) ((type_ >> 3) + 1);
+    }
+    int type() const { return type_; }
+    template <class T> T* ptr() { return reinterpret_cast<T*>(data_->data()); }
+    template <class T> const T* ptr() const { return reinterpret_cast<const T*>(data_->data()); }
+    template <class T> T& at(int i0, int i1, int i2) { return ptr<T>()[((size_t) i0 * size_[1] + i1) * size_[2] + i2]; }
+    template <class T> const T& at(int i0, int i1, int i2) const { return ptr<T>()[((size_t) i0 * size_[1] + i1) * size_[2] + i2]; }
+    int dims;
+
+private:
+    int type_;
+    std::vector<int> size_;
+    std::shared_ptr<std::vector<unsigned char>> data_;
+};
 }  // namespace cv
 #endif
 

@@ -62,7 +62,9 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
                         float alpha, int X, int Y, int Z, int pX, int pY, int pZ, const int own[6], const LaunchBox* boxes, int n,
                         const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact,
                         float* psi_out = nullptr /* null: update psi in place */, int prev_rows = 1,
-                        bool sys_acquire = false /* the launch reads cells other GPUs stored: invalidate at system scope first */);
+                        bool sys_acquire = false /* the launch reads cells other GPUs stored: nabla_U and the max-norm rows are READ AT SYSTEM SCOPE
+                                                     (sc0 sc1 loads of the pipelined march / the thin shells / the gate; there is no invalidate -- + 39 us,
+                                                     measured); a launch that cannot take that march is refused with SOBFU_E_UNSUPPORTED */);
 // Pass A / pass B over planes [z_lo, z_hi) (z_hi <= 0: the whole grid) and, optionally, a second range [z_lo2, z_hi2)
 // in the same launch (both boundary regions of a multi-GPU slab).  zc <= 0: z-chunk chosen by the cost model.
 int launch_pass_a(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z,

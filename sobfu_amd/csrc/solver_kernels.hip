@@ -433,6 +433,9 @@ struct PassAArgs {
 #ifndef SOBFU_PIN
 #define SOBFU_PIN 2  // bit 0: pass A, bit 1: pass B
 #endif
+#ifndef SOBFU_NTA
+#define SOBFU_NTA 0  // experiment (big grids, compact format): REAL streaming hints in pass A through buffer instructions -- bit 0: the nabla_U store, bit 1: next-plane psi / F loads of rows no y-neighbour tile re-reads, bit 2: of all rows
+#endif
 #ifndef SOBFU_BG_AHEAD
 #define SOBFU_BG_AHEAD 1  // pass A requests phi_global one plane ahead (0: in the step that uses it)
 #endif
@@ -449,6 +452,37 @@ SOBFU_DEV void pin3(const float4& v) {
 template <int BIT>
 SOBFU_DEV void loads_landed() {
     if (SOBFU_PIN & BIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched (gfx9 encoding)
+}
+
+// --- buffer addressing (cache-resident launches) -------------------------------------------------------------------------------
+// A 128-bit buffer resource in SGPRs (base, bytes) + a 32-bit lane byte offset + a scalar byte offset (the plane): an address costs
+// no vector instruction and no 64-bit lane register pair.  Arrays below 4 GiB only (checked at launch).
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
+SOBFU_DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) bytes, 0x00020000);
+}
+// nt: the streaming (nontemporal) hint, bit 1 of the cache-policy operand on gfx94x / gfx950
+SOBFU_DEV float4 buf_ld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool nt = false) {
+    const v3u t = nt ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 2) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
+}
+// the same load at SYSTEM scope (sc0 sc1: bits 0 and 4 of the cache-policy operand) when `sys` (wave-uniform) says so: cells another
+// GPU stored -- the halo rims of nabla_U on the direct transport
+SOBFU_DEV float4 buf_ld3_scope(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool sys) {
+    const v3u t = sys ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 17) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
+}
+SOBFU_DEV float buf_ld1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int) voff, (int) soff, 0));
+}
+SOBFU_DEV void buf_st3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float4& v, bool nt = false) {
+    const v3u t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+    if (nt) __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) voff, (int) soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) voff, (int) soff, 0);
+}
+SOBFU_DEV void buf_st1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float v, bool nt = false) {
+    if (nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int) voff, (int) soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int) voff, (int) soff, 0);
 }
 
 // One cell of pass A from its centre c = psi, fc = (phi_n o psi).tsdf, bg = phi_global.tsdf and the six RAW neighbours of psi
@@ -590,7 +624,10 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
         const size_t zn = (size_t) min(z + 1, d.z - 1) * plane, zcur = (size_t) z * plane;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            if (NTL >= 5 && COMPACT && RPT == 1 && wy > 0 && wy < WY - 1) {  // rows no y-neighbour tile re-reads
+            if (NTL >= 1 && COMPACT && RPT == 1 && (((SOBFU_NTA & 2) && wy > 0 && wy < WY - 1) || (SOBFU_NTA & 4))) {
+                pn[r] = buf_ld3(buf_rsrc(a.psi, 0xffffffffu), (uint32_t) (zn + off[r]) * 12u, 0u, true);
+                fn[r] = __builtin_nontemporal_load((const float*) a.pnp + zn + off[r]);
+            } else if (NTL >= 5 && COMPACT && RPT == 1 && wy > 0 && wy < WY - 1) {  // rows no y-neighbour tile re-reads
                 pn[r] = ldv_nt<COMPACT>(a.psi, zn + off[r]);
                 fn[r] = __builtin_nontemporal_load((const float*) a.pnp + zn + off[r]);
             } else {
@@ -635,7 +672,8 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
                         st3_system(pd->base + 3 * j, o);
                     }
                     if (z >= pd->lz0 && z < pd->lz1) stv<COMPACT>(a.nU, i, o);  // ... and where the box stands in for the owned block, home too
-                } else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
+                } else if (NTL >= 1 && COMPACT && (SOBFU_NTA & 1)) buf_st3(buf_rsrc(a.nU, 0xffffffffu), (uint32_t) i * 12u, 0u, o, true);
+                else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
                 else stv<COMPACT>(a.nU, i, o);
             }
         }
@@ -651,37 +689,6 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
     }
 }
 
-
-// --- buffer addressing (cache-resident launches) -------------------------------------------------------------------------------
-// A 128-bit buffer resource in SGPRs (base, bytes) + a 32-bit lane byte offset + a scalar byte offset (the plane): an address costs
-// no vector instruction and no 64-bit lane register pair.  Arrays below 4 GiB only (checked at launch).
-typedef unsigned v3u __attribute__((ext_vector_type(3)));
-SOBFU_DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) bytes, 0x00020000);
-}
-// nt: the streaming (nontemporal) hint, bit 1 of the cache-policy operand on gfx94x / gfx950
-SOBFU_DEV float4 buf_ld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool nt = false) {
-    const v3u t = nt ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 2) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
-    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
-}
-// the same load at SYSTEM scope (sc0 sc1: bits 0 and 4 of the cache-policy operand) when `sys` (wave-uniform) says so: cells another
-// GPU stored -- the halo rims of nabla_U on the direct transport
-SOBFU_DEV float4 buf_ld3_scope(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bool sys) {
-    const v3u t = sys ? __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 17) : __builtin_amdgcn_raw_buffer_load_b96(r, (int) voff, (int) soff, 0);
-    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), 0.f);
-}
-SOBFU_DEV float buf_ld1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int) voff, (int) soff, 0));
-}
-SOBFU_DEV void buf_st3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float4& v, bool nt = false) {
-    const v3u t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
-    if (nt) __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) voff, (int) soff, 2);
-    else __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) voff, (int) soff, 0);
-}
-SOBFU_DEV void buf_st1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float v, bool nt = false) {
-    if (nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int) voff, (int) soff, 2);
-    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int) voff, (int) soff, 0);
-}
 
 template <int RPT, int WY, bool COMPACT, int NTL>
 __global__ void __launch_bounds__(TX* WY) fused_potential_gradient_kernel(PassAArgs a) {
@@ -915,6 +922,9 @@ struct PassBArgs {
 #define SOBFU_PK 1  // 1: packed-fp32 tap arithmetic (v_pk_mul_f32 / v_pk_add_f32) in pass B
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef SOBFU_NT_BUF
+#define SOBFU_NT_BUF 1  // 1: the plain march's 12-byte psi load / store go through buffer instructions whose cache-policy operand carries the streaming hint
+#endif
 #ifndef SOBFU_MINW_B
 #define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
 #endif
@@ -1138,8 +1148,13 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
 
 // DIRECT_OK: the launch may hold direct boxes (multi-GPU tiles)
 // NTL: streaming hints (see pass_a_march).  PIPE: the software-pipelined march (pass_b_march_pipe).
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0, int NTL = SOBFU_NT, bool PIPE = false>
+// NTBUF (plain march, compact format, arrays below 4 GiB -- the launcher checks): the streaming hint of the 12-byte psi load / store is
+// REAL.  hipcc drops the nontemporal flag of __builtin_nontemporal_load / _store on the 4-byte-aligned 12-byte vector type (found in the
+// ISA in round 5: `global_load_dwordx3 ... off` without `nt`, while the 4-byte phi_n o psi store carries it); the buffer instructions
+// take the hint as an operand.
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0, int NTL = SOBFU_NT, bool PIPE = false, bool NTBUF = false>
 __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
+    static_assert(!NTBUF || (COMPACT && !PIPE && NTL >= 1), "NTBUF: the plain march of the compact format with streaming hints");
     static_assert(!PIPE || (RPT == 1 && COMPACT && IDX32 && !WRITE_UPDATES && HL == 0), "the pipelined march exists for the compact solver format");
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;
     static_assert(HL == 0 || HL >= 2, "the halo-lead FIFO needs a lead of >= 2 planes (a lead of 1 is the register path, HL = 0)");
@@ -1295,7 +1310,10 @@ __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B)
         const size_t zcur = (size_t) z * plane;
         float4 pv[RPT], nq[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) pv[r] = ldvb<COMPACT>((const char*) a.psi + zcur * VB, off[r], NTL >= 2);
+        for (int r = 0; r < RPT; ++r) {
+            if constexpr (NTBUF && NTL >= 2) pv[r] = buf_ld3(buf_rsrc(a.psi, (uint32_t) (plane * (size_t) d.z) * VB), off[r], (uint32_t) zcur * VB, true);
+            else pv[r] = ldvb<COMPACT>((const char*) a.psi + zcur * VB, off[r], NTL >= 2);
+        }
         if (z + 1 < ze) {
             const char* nU4 = (const char*) a.nU + (size_t) min(z + 4, d.z - 1) * plane * VB;
 #pragma unroll
@@ -1380,7 +1398,8 @@ __global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B)
             if (mine[r]) {
                 if (owned[r] && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
                 // inside the box no clamp was active: off[r] is the cell itself
-                stvb<COMPACT>((char*) a.psi_out + zcur * VB, off[r], p, NTL >= 1);
+                if constexpr (NTBUF) buf_st3(buf_rsrc(a.psi_out, (uint32_t) (plane * (size_t) d.z) * VB), off[r], (uint32_t) zcur * VB, p, true);
+                else stvb<COMPACT>((char*) a.psi_out + zcur * VB, off[r], p, NTL >= 1);
                 if (WRITE_UPDATES) *(float4*) ((char*) a.updates + zcur * 16 + (size_t) (offT[r] / TB * 16u)) = uu;
                 // apply_kernel (vector_fields.cu:95-98)
                 if (COMPACT) {
@@ -1669,27 +1688,76 @@ static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, in
     return total;
 }
 
-// device copies of the box lists seen so far (never freed: a list is 1.5 KB and a process sees a handful; a launch in flight may still
-// be reading its list)
+// Device copies of the box lists seen so far.  An entry belongs to the HIP DEVICE it was allocated on (two handles on different GPUs
+// of one process may build byte-identical lists: each gets its own copy), is found by a hash of the list's bytes (then memcmp), and is
+// uploaded with hipMemcpyAsync ON THE LAUNCH STREAM from a pinned staging copy that lives as long as the entry: no blocking
+// null-stream copy inside a launch path, stream order makes the list visible to the launch that follows.  Entries are never freed
+// one by one (a launch in flight may still be reading its list); when a device's entries exceed kMaxCachedLists -- lists are keyed by
+// peer pointers, so a process that keeps creating handles keeps creating lists -- the device is drained and its entries are dropped.
 struct CachedBoxes {
-    TileBoxList host;
+    int device;
+    uint64_t hash;
+    TileBoxList* host;  // pinned
     TileBoxList* dev;
+    hipStream_t up_stream;  // the stream the upload was enqueued on ...
+    hipEvent_t uploaded;    // ... and its completion: a launch on ANOTHER stream that finds the entry waits for it (until it is known done)
+    bool ready;
 };
+constexpr size_t kMaxCachedLists = 256;
 static std::vector<CachedBoxes> g_box_cache;
 static std::mutex g_box_cache_mutex;
-static int device_boxes(const TileBoxList& L, TileBoxList** out) {
+static uint64_t bytes_hash(const void* p, size_t n) {  // FNV-1a
+    const unsigned char* b = (const unsigned char*) p;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+static int device_boxes(const TileBoxList& L, TileBoxList** out, hipStream_t stream) {
+    int dev = 0;
+    SOBFU_HIP_TRY(hipGetDevice(&dev));
+    const uint64_t h = bytes_hash(&L, sizeof L);
     std::lock_guard<std::mutex> lock(g_box_cache_mutex);
-    for (const CachedBoxes& c : g_box_cache)
-        if (std::memcmp(&c.host, &L, sizeof L) == 0) {
+    size_t on_dev = 0;
+    for (CachedBoxes& c : g_box_cache) {
+        if (c.device != dev) continue;
+        ++on_dev;
+        if (c.hash == h && std::memcmp(c.host, &L, sizeof L) == 0) {
+            if (!c.ready) {
+                if (hipEventQuery(c.uploaded) == hipSuccess) c.ready = true;
+                else if (stream != c.up_stream) SOBFU_HIP_TRY(hipStreamWaitEvent(stream, c.uploaded, 0));
+            }
             *out = c.dev;
             return 0;
         }
-    TileBoxList* d = nullptr;
-    hipError_t e = hipMalloc((void**) &d, sizeof L);
-    if (e == hipSuccess) e = hipMemcpy(d, &L, sizeof L, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return (int) e;
-    g_box_cache.push_back(CachedBoxes{L, d});
-    *out = d;
+    }
+    if (on_dev >= kMaxCachedLists) {  // rare: drain this device, then its lists are nobody's
+        SOBFU_HIP_TRY(hipDeviceSynchronize());
+        for (size_t k = 0; k < g_box_cache.size();) {
+            if (g_box_cache[k].device == dev) {
+                (void) hipFree(g_box_cache[k].dev);
+                (void) hipHostFree(g_box_cache[k].host);
+                (void) hipEventDestroy(g_box_cache[k].uploaded);
+                g_box_cache.erase(g_box_cache.begin() + (long) k);
+            } else ++k;
+        }
+    }
+    CachedBoxes c{dev, h, nullptr, nullptr, stream, nullptr, false};
+    hipError_t e = hipHostMalloc((void**) &c.host, sizeof L, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        std::memcpy(c.host, &L, sizeof L);
+        e = hipMalloc((void**) &c.dev, sizeof L);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.dev, c.host, sizeof L, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(c.uploaded, stream);
+    if (e != hipSuccess) {
+        if (c.uploaded) (void) hipEventDestroy(c.uploaded);
+        if (c.dev) (void) hipFree(c.dev);
+        if (c.host) (void) hipHostFree(c.host);
+        return (int) e;
+    }
+    g_box_cache.push_back(c);
+    *out = c.dev;
     return 0;
 }
 static int launch_tile_boxes(const TileBoxList* d_boxes, int groups, const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X,
@@ -1712,7 +1780,7 @@ int launch_tile_pass_a(const float* pnp, const float* pg, const float* psi, floa
     if (total < 0) return SOBFU_E_BADARG;
     if (total == 0) return 0;
     TileBoxList* d = nullptr;
-    SOBFU_TRY(device_boxes(L, &d));
+    SOBFU_TRY(device_boxes(L, &d, stream));
     return launch_tile_boxes(d, total, pnp, pg, psi, nU, w_reg, X, Y, Z, sync, seq, wait, row, row_index, stream, compact);
 }
 
@@ -1728,7 +1796,8 @@ int tile_pass_a_plan_create(TilePassAPlan** out, const TileLaunchBox* boxes, int
     if (total < 0) return SOBFU_E_BADARG;
     auto* p = new TilePassAPlan();
     p->groups = total; p->X = X; p->Y = Y; p->Z = Z;
-    const int rc = total > 0 ? device_boxes(L, &p->d_boxes) : 0;
+    int rc = total > 0 ? device_boxes(L, &p->d_boxes, nullptr) : 0;  // plan time (handle creation), not a launch path ...
+    if (rc == 0 && total > 0) rc = (int) hipStreamSynchronize(nullptr);  // ... so the list is simply there before any stream launches with it
     if (rc != 0) {
         delete p;
         return rc;
@@ -1767,7 +1836,10 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     // Cache; the pipelined march where the launch is latency-bound (cache-resident sizes; SOBFU_PIPE_B=0/1 overrides)
     const bool resident = cache_resident(X, Y, Z);
     const char* pipe_e = getenv("SOBFU_PIPE_B");
-    const bool pipe = compact && idx32 && !updates && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32) && (pipe_e ? atoi(pipe_e) != 0 : (resident || sys_acquire));  // (buffer addressing: arrays below 4 GiB; connected handles always: its loads can carry the scope)
+    // (buffer addressing: arrays below 4 GiB.  Connected handles ALWAYS take the pipelined march, whatever SOBFU_PIPE_B says: it is the
+    // march whose loads carry the system scope for the halo cells other GPUs stored)
+    const bool pipe = compact && idx32 && !updates && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32) && (sys_acquire || (pipe_e ? atoi(pipe_e) != 0 : resident));
+    if (sys_acquire && !pipe) return SOBFU_E_UNSUPPORTED;  // never fall back to a march that reads peer-written cells with ordinary loads
     // workgroups a CU holds: <= 80 VGPR (launch bounds) and 32 - 48 KB LDS: 3 of 8 waves; the pipelined march (<= 128 VGPR): 2
     // cache-resident launches are ONE resident round of workgroups, which lasts as long as its longest march: the planes are
     // split evenly over as many z-chunks as fill the marching workgroups' share of the chip
@@ -1777,7 +1849,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     int zc_max = 0;
     for (int i = 0; i < a.boxes.n; ++i) {
         direct = direct || a.boxes.b[i].kind != 0;
-        if (a.boxes.b[i].kind == 0) zc_max = std::max(zc_max, a.boxes.b[i].zc);
+        if (a.boxes.b[i].kind == 0) zc_max = std::max(zc_max, a.boxes.b[i].zc + (a.boxes.b[i].rem > 0 ? 1 : 0));  // the first `rem` chunks march one plane more
         if (a.boxes.b[i].kind == 0 && pipe && resident && SOBFU_PAIR_B) a.boxes.b[i].pair = 1;  // neighbouring z-chunks march towards / away from each other
     }
     const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
@@ -1785,6 +1857,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, DIR>), grid, block, 0, stream, a)
 #define SOBFU_LAUNCH_BX(DIR, HLV, NTV, PIP) \
     hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, 0, stream, a)
+    const bool ntbuf = SOBFU_NT_BUF && SOBFU_NT >= 1 && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32);  // buffer instructions: arrays below 4 GiB
     if (direct) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);
@@ -1803,7 +1876,8 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
             // long marches (big grids): halo requests run SOBFU_HLEAD planes ahead; short ones (small grids, multi-GPU tiles) skip
             // the extra prologue round trip
             const bool lead = SOBFU_HLEAD > 0 && zc_max >= SOBFU_HLEAD_MIN_ZC && !resident && !pipe;
-            if (lead) SOBFU_LAUNCH_BX(false, SOBFU_HLEAD, SOBFU_NT, false);
+            if (lead && ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, SOBFU_HLEAD, SOBFU_NT, false, SOBFU_NT_BUF != 0>), grid, block, 0, stream, a);
+            else if (lead) SOBFU_LAUNCH_BX(false, SOBFU_HLEAD, SOBFU_NT, false);
             else if (resident && pipe) SOBFU_LAUNCH_BX(false, 0, 0, true);
             else if (resident) SOBFU_LAUNCH_BX(false, 0, 0, false);
             else if (pipe) SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, true);

@@ -147,3 +147,23 @@ def test_gpus_8_harvests_everything():
     f = d["per_frame"]
     assert f["frames_timed"] == 3 and f["iterations_per_frame"][-1] == 8 and f["frames_per_s"] > 0 and f["tiles"] == "2x2x2"
     assert f["all_gathered_bytes_per_frame"] == 64 ** 3 * 24
+
+
+def test_budget_skips_the_harvest_and_keeps_one_valid_line():
+    """with a budget that is gone before the timed legs are done, every harvest step behind them is skipped
+    -- by name, agreed between the ranks -- and the line is still ONE valid JSON line with the core of the run (value, both legs, parity)"""
+    d = run_bench("--gpus", "2", "--steps", "10", "--warmup", "4", "--dim", "64", "--repeats", "3", "--no-cpu-baseline", "--budget-s", "1",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["budget_s"] == 1.0
+    assert d["tiled_parity_vs_single_gpu"] == "bit-exact"
+    assert set(d["legs"]) == {"direct", "rccl"} and all("value" in v or "failed" in v for v in d["legs"].values())
+    sk = d["skipped"]
+    # either the normal path skipped every step by name, or the watchdog printed the early copy (which says so in one entry)
+    assert any("per_frame" in x for x in sk) or any("budget" in x for x in sk), sk
+    assert "per_frame" not in d and not d.get("tiled_autotune_us")
+
+
+def test_single_gpu_budget_skips_named_steps():
+    d = run_bench("--gpus", "1", "--steps", "10", "--warmup", "4", "--dim", "64", "--repeats", "3", "--budget-s", "1")
+    assert d["value"] > 0 and d["roofline"]["traffic"] is None and "budget" in d["roofline"]["traffic_how"]
+    assert set(d["skipped"]) == {"roofline.traffic", "cpu_baseline", "per_frame"} and "cpu_baseline" not in d and "per_frame" not in d

@@ -9,6 +9,12 @@ config 2 -- 128^3, the reference's params/params_snoopy.ini values (params/confi
             bit for bit.  MAX_ITER is capped (the ini's 2048 iterations would take the oracle minutes; 1e-3 is only reached
             after > 600 iterations on this scene), so a second pass raises the threshold to make the break fire at a different
             iteration on every frame.
+config 3 -- 256^3, params_boxing.ini solver values, two analytic spheres: bench.py's OWN workload through the solver handle's default
+            configuration (compact format, halo-lead march, streaming hints, XCD tile map -- the code path the headline number is
+            measured on) against the oracle DIRECTLY, voxel by voxel at full size: psi, phi_n o psi, psi^-1, phi_global o psi^-1 and the
+            per-iteration max norms, bit for bit; a second start (psi = identity + a 1.2-voxel smooth-free hash displacement) makes
+            the gather, the inverse and the clamps do real work.  config 4's 2 x 2 x 2 tiles (direct transport) against the same
+            oracle result.
 config 5 -- 512^3, params/params_umbrella.ini values (params/config5_umbrella_512.ini): too large for the oracle, so the two
             independent HIP code paths are compared at full size (launcher kernels vs fused passes; compact vs API-format solve)
             plus size-independent properties; the batched-replicas bench leg is smoked in tests/test_gpu_bench_contract.py.
@@ -156,6 +162,101 @@ def _fused_vs_launchers(ops, oracle, dims, w_reg, alpha):
     assert torch.equal(psi_l.view(torch.int32), psi.view(torch.int32))
     assert torch.equal(out_l.view(torch.int32), out_f.view(torch.int32))
     assert m_l == m_f and m_f > 0
+
+
+
+# ---------------------------------------------------------------------------------------------------
+# config 3 (and config 4's tiles): the bench's own workload on the bench's own code path, DIRECTLY against the oracle at 256^3
+# (the OpenMP oracle runs ~20 iterations/s at this size: seconds, not minutes)
+# ---------------------------------------------------------------------------------------------------
+def _config3_inputs(oracle):
+    import bench
+
+    P = bench.boxing_params(256)
+    c0, c1, r = bench.sphere_pair(P)
+    pg, pn = oracle.new_volume(P["dims"]), oracle.new_volume(P["dims"])
+    oracle.init_sphere(pg, P["vs"], P["trunc"], P["eta"], c0, r)
+    oracle.init_sphere(pn, P["vs"], P["trunc"], P["eta"], c1, r)
+    return P, pg, pn
+
+
+_C3 = {}
+
+
+def _config3_oracle(oracle, n_iters):
+    """the oracle's solve of the bench workload from the identity (cached: config 3 and config 4's tiles are checked against it)"""
+    if n_iters not in _C3:
+        P, pg, pn = _config3_inputs(oracle)
+        psi = oracle.new_field(P["dims"])
+        oracle.init_identity(psi)
+        r = oracle.estimate_psi(pg, pn, psi, max_iter=n_iters, alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"],
+                                max_update_norm=P["max_update_norm"], compute_jacobian=False)
+        _C3[n_iters] = (P, pg, pn, psi, {k: r[k] for k in ("iters", "phi_n_psi", "psi_inv", "phi_global_psi_inv", "trace")})
+    return _C3[n_iters]
+
+
+@pytest.mark.parametrize("start", ["identity", "displaced"])
+def test_config3_256_bench_path_vs_oracle(ops, oracle, start):
+    from sobfu_amd.synthetic import hash_field
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 8 * 2 ** 30:
+        pytest.skip("needs ~4 GiB of HBM")
+    for k in ("SOBFU_COMPACT", "SOBFU_ZC_A", "SOBFU_ZC_B", "SOBFU_CACHE_CELLS", "SOBFU_PIPE_B"):
+        assert k not in os.environ, f"{k} is set: this test pins the DEFAULT configuration (the one bench.py measures)"
+    if start == "identity":
+        n_iters = 8
+        P, pg, pn, psi_o, r = _config3_oracle(oracle, n_iters)
+        psi0 = oracle.new_field(P["dims"])
+        oracle.init_identity(psi0)
+    else:
+        n_iters = 3
+        P, pg, pn = _config3_inputs(oracle)
+        psi0 = oracle.new_field(P["dims"])
+        oracle.init_identity(psi0)
+        psi0[..., :3] += hash_field((256, 256, 256, 3), 311, 1.2)  # up to 1.2 voxels, uncorrelated: samples leave the volume at the faces
+        psi_o = psi0.copy()
+        r = oracle.estimate_psi(pg, pn, psi_o, max_iter=n_iters, alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"],
+                                max_update_norm=P["max_update_norm"], compute_jacobian=False)
+    assert P["dims"] == (256, 256, 256)
+    assert r["iters"] == n_iters
+    sv = ops.Solver(P["dims"], max_iter=n_iters, alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
+    psi_d, psi_inv_d = dev(psi0), ops.new_field(P["dims"])
+    pnp_d, pgi_d = ops.new_volume(P["dims"]), ops.new_volume(P["dims"])
+    rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+    sv.close()
+    assert rep.iterations == n_iters and not rep.converged
+    assert same(hist, r["trace"][:, 2]) and float(hist.min()) > 0
+    got = host(psi_d)
+    assert same(got, psi_o)
+    assert float(np.sqrt(((got.astype(np.float64) - psi_o) ** 2).sum())) < 1e-5  # the north-star bar (it is exactly 0)
+    del got
+    assert same(host(pnp_d), r["phi_n_psi"])
+    assert same(host(psi_inv_d), r["psi_inv"])
+    assert same(host(pgi_d), r["phi_global_psi_inv"])
+    ident = oracle.new_field(P["dims"])
+    oracle.init_identity(ident)
+    assert float(np.abs(psi_o[..., :3] - ident[..., :3]).max()) > (1e-6 if start == "identity" else 1.0)  # the solve moved psi
+
+
+def test_config4_tiles_vs_oracle_256(ops, oracle):
+    """config 4 (the same workload on 2 x 2 x 2 tiles of 128^3, direct transport, eight ranks stepped in this process) against the
+    ORACLE's 256^3 solve -- not against the single-GPU HIP solve, which tests/test_gpu_tiled_loopback.py does"""
+    from test_gpu_tiled_loopback import run_world_direct
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs ~16 GiB of HBM")
+    n_iters = 8
+    P, pg, pn, psi_o, r = _config3_oracle(oracle, n_iters)
+    psi0 = oracle.new_field(P["dims"])
+    oracle.init_identity(psi0)
+    kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"])
+    out, (psi_t, pnp_t) = run_world_direct(P["dims"], (2, 2, 2), psi0, pg, pn, n_iters, P["max_update_norm"], True, 1, kw)
+    for done, hist, _, _ in out:
+        assert done == n_iters and same(np.asarray(hist, np.float32), r["trace"][:, 2])
+    assert same(psi_t[..., :3], psi_o[..., :3])
+    assert same(pnp_t, r["phi_n_psi"])
 
 
 def test_config5_umbrella_512(ops, oracle):

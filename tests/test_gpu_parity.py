@@ -401,7 +401,8 @@ def test_solver_rejects_bad_filter(ops):
 
 
 # ---------------------------------------------------------------------------------------------------
-# full-size (256^3, BASELINE config 3) properties the oracle is too slow to check voxel by voxel
+# full-size (256^3) launcher kernels vs fused passes in the API format, and size-independent properties (the oracle itself is put
+# against the bench's own code path at 256^3 in tests/test_gpu_configs.py::test_config3_256_bench_path_vs_oracle)
 # ---------------------------------------------------------------------------------------------------
 def test_full_size_256_fused_equals_launchers_and_properties(ops, oracle):
     dims = (256, 256, 256)

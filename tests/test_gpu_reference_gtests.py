@@ -109,3 +109,20 @@ def test_ref_DataTermTest(ops):
     assert np.all(host(pg)[..., 0] == 1.0)
     assert abs(ops.data_energy(pg, pn) - 0.5 * 64 ** 3) <= 0.1
     assert ops.reduce_config(64 ** 3) == (256, 512)
+
+
+def test_reference_own_test_binary():
+    """The reference's OWN test translation units (test/*.cpp, compiled unchanged against include/ by oracle/ref_callers.py in the build
+    container -- the binary travels, the reference does not) run on this GPU: its nine gtest cases pass on the HIP path."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "reference_gtests")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/reference_gtests was not built (needs /root/reference: __graft_entry__.build() in the build container)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    assert "9 tests ran, 0 failed" in r.stdout, tail
+    for name in ("DeformationFieldTest.ClearTest", "DeformationFieldTest.TsdfGradientTest", "ReductionsTest", "SolverTest"):
+        assert name in r.stdout, (name, tail)

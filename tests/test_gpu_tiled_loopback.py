@@ -126,7 +126,7 @@ def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, 
     per rank runs the real loop, in-kernel waits live (few ranks: every rank's stream needs a hardware queue of its own).
     keep_halo_lines_hot (stepped): right before every pass A -- whose push boxes store into the OTHER ranks' nabla_U halo cells -- a
     copy kernel reads every rank's nabla_U arena, so that the lines those stores are about to change sit in the reader's caches when
-    the stores happen: pass B must still see the new cells (its entry invalidates at system scope on connected handles)."""
+    the stores happen: pass B must still see the new cells (on connected handles it reads nabla_U and the max-norm rows at system scope)."""
     import ctypes as C
 
     import torch
@@ -202,6 +202,10 @@ def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, 
 @pytest.mark.parametrize("dims,grid,stepped", [((40, 24, 36), (2, 2, 2), True), ((64, 64, 64), (2, 2, 2), True), ((33, 17, 16), (1, 2, 2), True),
                                                 ((40, 24, 36), (1, 1, 3), True), ((70, 33, 23), (2, 1, 1), True), ((141, 19, 17), (2, 1, 2), True),
                                                 ((36, 36, 36), (3, 3, 3), True), ((8, 9, 10), (2, 2, 2), True),
+                                                # wide rows (owned x >= 64) meeting y neighbours: the marched y-face push box stores its 8 rows at
+                                                # home too and the owned block leaves them out (y_home), with and without the same along z
+                                                ((130, 40, 20), (1, 2, 1), True), ((130, 40, 20), (2, 2, 1), True), ((130, 40, 20), (1, 2, 2), True),
+                                                ((130, 60, 12), (1, 3, 1), True),
                                                 # in-kernel waits live: one thread per rank, the real loop
                                                 ((40, 24, 36), (1, 1, 2), False), ((70, 33, 23), (2, 1, 1), False), ((40, 24, 36), (1, 2, 1), False)])
 def test_native_loop_direct_transport(dims, grid, stepped):
@@ -246,7 +250,7 @@ def test_direct_transport_with_stale_halo_lines_in_cache(dims, grid):
     nabla_U halo lines are deliberately made cache-resident right before the peers overwrite them (keep_halo_lines_hot): the
     solve must still equal the single-GPU one bit for bit.  On ONE GPU the ordinary kernel boundary already guarantees that (this
     test cannot fail for the reason it guards against -- only a second GPU can show that); what it does exercise is the explicit
-    system-scope invalidate at pass B's entry on connected handles, under exactly the access pattern it exists for."""
+    system-scope loads of pass B on connected handles, under exactly the access pattern they exist for."""
     import torch
 
     import oracle
@@ -335,6 +339,9 @@ def test_direct_transport_deadline():
                                                ((40, 24, 36), (2, 2, 2), None), ((64, 64, 64), (2, 2, 2), None), ((33, 17, 16), (1, 2, 2), None),
                                                ((70, 33, 23), (2, 1, 1), None), ((40, 24, 36), (1, 2, 1), None), ((40, 24, 36), (2, 2, 1), None),
                                                ((141, 19, 17), (2, 1, 2), None), ((36, 36, 36), (3, 3, 3), None),
+                                               # wide rows meeting y neighbours on one side / on both sides, with and without a z split (y_home)
+                                               ((130, 40, 20), (1, 2, 1), None), ((130, 40, 20), (2, 2, 1), None), ((130, 40, 20), (1, 2, 2), None),
+                                               ((130, 60, 12), (1, 3, 1), None),
                                                # the smallest tiles the layout allows (4 owned cells per split axis: a message is the whole tile)
                                                ((8, 9, 10), (2, 2, 2), None), ((12, 8, 8), (3, 2, 1), None)])
 def test_native_loop_n_ranks_loopback(dims, world, split, monkeypatch):
