@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from sobfu_amd.tiled import HALO, SLOTS, NativeTiledSolver, TileLayout, parse_grid
+from sobfu_amd.tiled import HALO, SLOTS, DistHalo, NativeTiledSolver, TileLayout, parse_grid
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
@@ -382,7 +382,13 @@ def frames_on_tiles(args, ranks, grid, transport, max_frames):
         return full
 
     fP = dict(P, max_iter=args.frame_iters)
-    fu = TiledFusion(solver, fP, gather=(gather_cpu if ranks.share else None))
+    # the per-frame tail fetches bounded-reach windows of psi / phi_global (DistHalo; all-gather only when the displacement outgrows a
+    # tile); SOBFU_TILED_TAIL=gather forces the two all-gathers of round 4 (A/B)
+    force_gather = os.environ.get("SOBFU_TILED_TAIL", "halo") == "gather"
+    gather_fn = gather_cpu if ranks.share else solver.gather_owned
+    halo = None if (force_gather or ranks.world == 1) else DistHalo(L, via_host=ranks.share)
+    fu = TiledFusion(solver, fP, gather=gather_fn, halo=halo)
+    tails = []
     fu(depth[0])
     torch.cuda.synchronize()
     ranks.barrier()
@@ -395,17 +401,38 @@ def frames_on_tiles(args, ranks, grid, transport, max_frames):
         torch.cuda.synchronize()
         ms.append(1e3 * (time.perf_counter() - t0))
         iters.append(int(rep[0]) if rep is not None else 0)
+        if rep is not None and solver.tail_stats:
+            tails.append(dict(solver.tail_stats))
+    # self-check of the bounded-reach tail on the state the last frame left: the same tail on all-gathered sources, bit for bit on
+    # every rank's owned cells (MIN over ranks)
+    tail_ok = None
+    if halo is not None and tails:
+        from sobfu_amd.tiled import frame_tail
+
+        inv_a, pgi_a, inv_b, pgi_b = solver.new_local(4), solver.new_local(2), solver.new_local(4), solver.new_local(2)
+        frame_tail(solver, fu.phi_global, pgi_a, fu.psi, inv_a, gather=gather_fn, halo=halo)
+        mode_a = solver.tail_stats["mode"]
+        frame_tail(solver, fu.phi_global, pgi_b, fu.psi, inv_b, gather=gather_fn, halo=None)
+        same = torch.equal(L.owned(inv_a)[..., :3].contiguous().view(torch.int32), L.owned(inv_b)[..., :3].contiguous().view(torch.int32)) and \
+            torch.equal(L.owned(pgi_a).contiguous().view(torch.int32), L.owned(pgi_b).contiguous().view(torch.int32))
+        tail_ok = ranks.min([1.0 if (same and mode_a == "halo") else 0.0])[0] == 1.0
     solver.close()
     worst = ranks.max(ms)
     timed = [w for w, i in zip(worst, iters) if i > 0] or worst  # frames before START_FRAME only fuse
     med = sorted(timed)[len(timed) // 2]
-    gathered = P["dims"][0] * P["dims"][1] * P["dims"][2] * (16 + 8)  # psi (float4) and phi_global (float2), each all-gathered once per frame
+    all_gather_bytes = P["dims"][0] * P["dims"][1] * P["dims"][2] * (16 + 8)  # psi (float4) + phi_global (float2) all-gathered: what round 4 moved per frame
+    recv = int(ranks.max([float(np.median([t["bytes_received"] for t in tails])) if tails else 0.0])[0])
     return {"config": f"{ini} values, {P['dims'][0]}^3, {args.frame_iters} solver iterations per frame, synthetic 640x480 depth sequence",
             "pipeline": "bilateral + truncation + ray lengths -> integrate(depth) (own tile of phi_global, whole phi_n) -> tiled estimate_psi: iterations, "
-                        "all-gather psi, 48-sweep inverse, all-gather phi_global, canonical->live warp -> fuse   [reference src/sobfu/sob_fusion.cpp:71-145]",
+                        "one MAX reduction of |psi - id|, bounded-reach windows of psi and phi_global from the neighbours (all-gather only when the "
+                        "displacement outgrows a tile), 48-sweep inverse, canonical->live warp -> fuse   [reference src/sobfu/sob_fusion.cpp:71-145]",
             "transport": transport, "tiles": "x".join(map(str, grid)), "frames_timed": len(timed), "ms_per_frame": med,
             "ms_per_frame_all": [round(v, 3) for v in worst], "frames_per_s": 1e3 / med, "iterations_per_frame": iters,
-            "all_gathered_bytes_per_frame": gathered}
+            "tail": {"mode": sorted({t["mode"] for t in tails}) if tails else None, "halo_width_cells": sorted({t["halo_width"] for t in tails if t["halo_width"]}) or None,
+                     "max_displacement_voxels": max([t["reach"] for t in tails if t["reach"] is not None], default=None),
+                     "bytes_received_per_frame_per_rank": recv, "all_gather_would_move_bytes": all_gather_bytes,
+                     "parity_vs_all_gather_tail": None if tail_ok is None else ("bit-exact" if tail_ok else "MISMATCH")},
+            "all_gathered_bytes_per_frame": recv}
 
 
 def run_leg(args, P, ranks, timed_regions, grid, transport_name, kw):

@@ -176,6 +176,20 @@ int sobfu_hip_tile3_apply(const float* d_phi, int Xg, int Yg, int Zg, float* d_p
                           void* stream);
 int sobfu_hip_tile3_estimate_inverse(const float* d_psi, int Xg, int Yg, int Zg, float* d_psi_inv, int Lx, int Ly, int Lz, int xb, int yb,
                                      int zb, int n_sweeps, void* stream);
+/* The per-frame tail of a tile (reference src/sobfu/cuda/solver.cu:196-199; src/sobfu/cuda/vector_fields.cu:111-138) on a WINDOW of its
+ * sources instead of the all-gathered volume: psi^-1(x), and every point its fixed-point iteration visits, lies within
+ * r = max |psi - id| of x, so a tile needs psi / phi_global only on its owned cells widened by ceil(r) + 1 cells.
+ * win = (Wx, Wy, Wz, wbx, wby, wbz): extents of the window array and the global cell of its cell (0, 0, 0); box = (x0, x1, y0, y1, z0, z1):
+ * the LOCAL cells to produce (others are left untouched); clamps act on the global extents (Xg, Yg, Zg) as in the whole-volume kernels:
+ * same bits.  *d_violation (zeroed by the caller) becomes 1 when a sample fell outside the window -- the results are then invalid and the
+ * caller repeats the tail on all-gathered sources.  sobfu_hip_tile3_max_displacement folds max(|psi - id| components) over `box` into
+ * *d_max_bits (atomicMax on the float's bit pattern; zero it first; NaN / inf count as 3e38). */
+int sobfu_hip_tile3_estimate_inverse_window(const float* d_psi_win, const int win[6], int Xg, int Yg, int Zg, float* d_psi_inv, int Lx, int Ly, int Lz,
+                                            int xb, int yb, int zb, const int box[6], int n_sweeps, int* d_violation, void* stream);
+int sobfu_hip_tile3_apply_window(const float* d_phi_win, const int win[6], int Xg, int Yg, int Zg, float* d_phi_warped, const float* d_psi, int Lx,
+                                 int Ly, int Lz, const int box[6], int* d_violation, void* stream);
+int sobfu_hip_tile3_max_displacement(const float* d_psi, int Lx, int Ly, int Lz, int xb, int yb, int zb, const int box[6], uint32_t* d_max_bits,
+                                     void* stream);
 int sobfu_hip_tile3_integrate_depth(const float* d_dists, int dists_step_bytes, int rows, int cols, float* d_vol_local, int Lx, int Ly,
                                     int Lz, int xb, int yb, int zb, const float voxel_size[3], float trunc_dist, float eta,
                                     const float R[9], const float t[3], float fx, float fy, float cx, float cy, void* stream);

@@ -82,6 +82,94 @@ __global__ void __launch_bounds__(256) inverse_from_identity_and_warp_kernel(con
     phi_warped[i]   = interp_tsdf(phi, d, v.x, v.y, v.z);
 }
 
+// ---- the per-frame tail of a multi-GPU tile on a WINDOW of the sources instead of the whole volume --------------------------------
+// psi^-1(x) is the fixed point of p <- x - u(p) started at x (vector_fields.cu:111-138): every p it visits, and psi^-1(x) itself, lies
+// within r = max |psi - id| (component-wise, over the whole volume) of x, and the trilinear samplers read floor(p) and floor(p) + 1
+// (include/sobfu/cuda/utils.hpp:124-164, 50-86).  So a tile needs psi -- and, for the canonical -> live warp at psi^-1(x), phi_global --
+// only on its owned cells widened by ceil(r) + 1 cells, not the all-gathered volume (134 + 268 MB per frame at 256^3 that do not
+// shrink with N).  The window is an array (wd) whose cell (0, 0, 0) is global cell wb; the clamps act on the GLOBAL extents pd exactly
+// as in the whole-volume samplers, so the bits are the same.  A sample that would fall outside the window (a reach bound that did not
+// hold) is clamped into it AND recorded in *violation: the host then redoes the frame's tail on all-gathered sources.
+struct Window {
+    Dims pd, wd, wb;
+    int* violation;
+};
+SOBFU_DEV size_t win_idx(const Window& w, int x, int y, int z) {
+    const int lx = x - w.wb.x, ly = y - w.wb.y, lz = z - w.wb.z;
+    if ((unsigned) lx >= (unsigned) w.wd.x || (unsigned) ly >= (unsigned) w.wd.y || (unsigned) lz >= (unsigned) w.wd.z) {
+        if (w.violation != nullptr) *w.violation = 1;
+        return vidx(w.wd, min(max(lx, 0), w.wd.x - 1), min(max(ly, 0), w.wd.y - 1), min(max(lz, 0), w.wd.z - 1));
+    }
+    return vidx(w.wd, lx, ly, lz);
+}
+SOBFU_DEV float4 disp_at_win(const float4* __restrict__ psi, const Window& w, int x, int y, int z) {
+    return sub4(psi[win_idx(w, x, y, z)], f4((float) x, (float) y, (float) z));
+}
+// interpolate_field_inv (utils.hpp:124-164) on a window
+SOBFU_DEV float4 interp_disp_win(const float4* __restrict__ psi, const Window& w, float px, float py, float pz) {
+    const Tri a = tri_setup(px, w.pd.x), b = tri_setup(py, w.pd.y), c = tri_setup(pz, w.pd.z);
+    return lerp4(lerp4(lerp4(disp_at_win(psi, w, a.h, b.h, c.h), disp_at_win(psi, w, a.h, b.h, c.g), c.t),
+                       lerp4(disp_at_win(psi, w, a.h, b.g, c.h), disp_at_win(psi, w, a.h, b.g, c.g), c.t), b.t),
+                 lerp4(lerp4(disp_at_win(psi, w, a.g, b.h, c.h), disp_at_win(psi, w, a.g, b.h, c.g), c.t),
+                       lerp4(disp_at_win(psi, w, a.g, b.g, c.h), disp_at_win(psi, w, a.g, b.g, c.g), c.t), b.t),
+                 a.t);
+}
+// interpolate_tsdf (utils.hpp:50-86) on a window
+SOBFU_DEV float2 interp_tsdf_win(const float2* __restrict__ v, const Window& w, float px, float py, float pz) {
+    const Tri a = tri_setup(px, w.pd.x), b = tri_setup(py, w.pd.y), c = tri_setup(pz, w.pd.z);
+    const float2 ggg = v[win_idx(w, a.g, b.g, c.g)];
+    const float hhh = v[win_idx(w, a.h, b.h, c.h)].x, hhg = v[win_idx(w, a.h, b.h, c.g)].x, hgh = v[win_idx(w, a.h, b.g, c.h)].x,
+                hgg = v[win_idx(w, a.h, b.g, c.g)].x;
+    const float ghh = v[win_idx(w, a.g, b.h, c.h)].x, ghg = v[win_idx(w, a.g, b.h, c.g)].x, ggh = v[win_idx(w, a.g, b.g, c.h)].x;
+    const float t = lerp1(lerp1(lerp1(hhh, hhg, c.t), lerp1(hgh, hgg, c.t), b.t), lerp1(lerp1(ghh, ghg, c.t), lerp1(ggh, ggg.x, c.t), b.t), a.t);
+    return make_float2(t, ggg.y);
+}
+// the cells of `box` (local coordinates) of a tile: psi^-1 <- n_sweeps of the fixed point started at the identity, then, when phi != null,
+// phi o psi^-1 -- the lane still holds psi^-1(x) when it warps (the single-GPU tail kernel above, on windows)
+__global__ void __launch_bounds__(256) tile_inverse_window_kernel(const float4* __restrict__ psi_win, Window wpsi, float4* __restrict__ psi_inv, Dims d,
+                                                                  Dims base, int x0, int x1, int y0, int y1, int z0, int z1, int n_sweeps) {
+    const int x = x0 + blockIdx.x * kBX + threadIdx.x, y = y0 + blockIdx.y * kBY + threadIdx.y, z = z0 + blockIdx.z;
+    if (x >= x1 || y >= y1 || z >= z1) return;
+    const float4 id = f4((float) (x + base.x), (float) (y + base.y), (float) (z + base.z));
+    float4 v = id, w = id;
+    auto same = [](const float4& a, const float4& b) {
+        return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) && __float_as_uint(a.z) == __float_as_uint(b.z);
+    };
+    for (int it = 0; it < n_sweeps; ++it) {  // inverse_fixed_point() with the windowed sampler: the same early exits, the same bits
+        const float4 u  = interp_disp_win(psi_win, wpsi, v.x, v.y, v.z);
+        const float4 nv = sub4(id, mul4(u, 1.f));
+        const int left  = n_sweeps - (it + 1);
+        if (same(nv, v)) { v = nv; break; }
+        if (it > 0 && same(nv, w)) { v = (left & 1) ? v : nv; break; }
+        w = v;
+        v = nv;
+    }
+    psi_inv[vidx(d, x, y, z)] = v;
+}
+__global__ void __launch_bounds__(256) tile_apply_window_kernel(const float2* __restrict__ phi_win, Window wphi, float2* __restrict__ out,
+                                                                const float4* __restrict__ psi, Dims d, int x0, int x1, int y0, int y1, int z0, int z1) {
+    const int x = x0 + blockIdx.x * kBX + threadIdx.x, y = y0 + blockIdx.y * kBY + threadIdx.y, z = z0 + blockIdx.z;
+    if (x >= x1 || y >= y1 || z >= z1) return;
+    const size_t i = vidx(d, x, y, z);
+    const float4 p = psi[i];
+    out[i] = interp_tsdf_win(phi_win, wphi, p.x, p.y, p.z);
+}
+// max over the cells of `box` of max(|psi.x - x|, |psi.y - y|, |psi.z - z|) (global coordinates) -> atomicMax on the float's bit pattern
+__global__ void __launch_bounds__(256) tile_max_displacement_kernel(const float4* __restrict__ psi, Dims d, Dims base, int x0, int x1, int y0, int y1,
+                                                                    int z0, int z1, uint32_t* __restrict__ out) {
+    const int x = x0 + blockIdx.x * kBX + threadIdx.x, y = y0 + blockIdx.y * kBY + threadIdx.y, z = z0 + blockIdx.z;
+    float m = 0.f;
+    if (x < x1 && y < y1 && z < z1) {
+        const float4 p = psi[vidx(d, x, y, z)];
+        m = fmaxf(fmaxf(fabsf(p.x - (float) (x + base.x)), fabsf(p.y - (float) (y + base.y))), fabsf(p.z - (float) (z + base.z)));
+        if (!(m == m) || m > 3.0e38f) m = 3.0e38f;  // NaN / inf: "unbounded" (the caller falls back to the all-gather)
+    }
+    uint32_t b = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) b = max(b, (uint32_t) __shfl_xor((int) b, o, 64));
+    if (threadIdx.x == 0 && b != 0u) atomicMax(out, b);
+}
+
 // TsdfDifferentiator::operator() -- vector_fields.cu:157-208 (mirrored neighbour on boundary faces => exact 0)
 __global__ void __launch_bounds__(256) tsdf_gradient_kernel(const float2* __restrict__ vol, float4* __restrict__ grad, Dims d) {
     VOXEL_XYZ(d);
@@ -171,6 +259,47 @@ int sobfu_hip_tile3_estimate_inverse(const float* d_psi, int Xg, int Yg, int Zg,
     if (n_sweeps == 0) return 0;
     LAUNCH_VOXEL(inverse_fixed_point_kernel, Lx, Ly, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{Lx, Ly, Lz},
                  Dims{Xg, Yg, Zg}, Dims{xb, yb, zb}, n_sweeps);
+    return (int) hipGetLastError();
+}
+
+// ---- windowed per-frame tail of a tile (see Window above).  win = (Wx, Wy, Wz, wbx, wby, wbz): extents of the window array and the
+// global cell of its cell (0, 0, 0); box = (x0, x1, y0, y1, z0, z1): the LOCAL cells to produce (a tile's owned cells); d_violation: an
+// int the caller zeroed -- set to 1 when a sample fell outside the window (results are then not to be used).
+static bool win_ok(const int win[6], int Xg, int Yg, int Zg) {
+    return win[0] > 0 && win[1] > 0 && win[2] > 0 && win[3] >= 0 && win[4] >= 0 && win[5] >= 0 && win[3] + win[0] <= Xg && win[4] + win[1] <= Yg &&
+           win[5] + win[2] <= Zg;
+}
+static bool lbox_ok(const int b[6], int Lx, int Ly, int Lz) {
+    return b[0] >= 0 && b[0] < b[1] && b[1] <= Lx && b[2] >= 0 && b[2] < b[3] && b[3] <= Ly && b[4] >= 0 && b[4] < b[5] && b[5] <= Lz;
+}
+#define LAUNCH_BOX(kern, b, stream, ...) \
+    hipLaunchKernelGGL(kern, voxel_grid((b)[1] - (b)[0], (b)[3] - (b)[2], (b)[5] - (b)[4]), voxel_block(), 0, (hipStream_t) (stream), __VA_ARGS__)
+
+int sobfu_hip_tile3_estimate_inverse_window(const float* d_psi_win, const int win[6], int Xg, int Yg, int Zg, float* d_psi_inv, int Lx, int Ly, int Lz,
+                                            int xb, int yb, int zb, const int box[6], int n_sweeps, int* d_violation, void* stream) {
+    SOBFU_CHECK_ARGS(d_psi_win && win && d_psi_inv && box && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0 && xb >= 0 && yb >= 0 && zb >= 0 &&
+                     n_sweeps >= 0 && d_psi_win != d_psi_inv && win_ok(win, Xg, Yg, Zg) && lbox_ok(box, Lx, Ly, Lz));
+    const Window w{{Xg, Yg, Zg}, {win[0], win[1], win[2]}, {win[3], win[4], win[5]}, d_violation};
+    LAUNCH_BOX(tile_inverse_window_kernel, box, stream, (const float4*) d_psi_win, w, (float4*) d_psi_inv, Dims{Lx, Ly, Lz}, Dims{xb, yb, zb}, box[0],
+               box[1], box[2], box[3], box[4], box[5], n_sweeps);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile3_apply_window(const float* d_phi_win, const int win[6], int Xg, int Yg, int Zg, float* d_phi_warped, const float* d_psi, int Lx,
+                                 int Ly, int Lz, const int box[6], int* d_violation, void* stream) {
+    SOBFU_CHECK_ARGS(d_phi_win && win && d_phi_warped && d_psi && box && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0 &&
+                     d_phi_win != d_phi_warped && win_ok(win, Xg, Yg, Zg) && lbox_ok(box, Lx, Ly, Lz));
+    const Window w{{Xg, Yg, Zg}, {win[0], win[1], win[2]}, {win[3], win[4], win[5]}, d_violation};
+    LAUNCH_BOX(tile_apply_window_kernel, box, stream, (const float2*) d_phi_win, w, (float2*) d_phi_warped, (const float4*) d_psi, Dims{Lx, Ly, Lz},
+               box[0], box[1], box[2], box[3], box[4], box[5]);
+    return (int) hipGetLastError();
+}
+
+int sobfu_hip_tile3_max_displacement(const float* d_psi, int Lx, int Ly, int Lz, int xb, int yb, int zb, const int box[6], uint32_t* d_max_bits,
+                                     void* stream) {
+    SOBFU_CHECK_ARGS(d_psi && box && d_max_bits && Lx > 0 && Ly > 0 && Lz > 0 && xb >= 0 && yb >= 0 && zb >= 0 && lbox_ok(box, Lx, Ly, Lz));
+    LAUNCH_BOX(tile_max_displacement_kernel, box, stream, (const float4*) d_psi, Dims{Lx, Ly, Lz}, Dims{xb, yb, zb}, box[0], box[1], box[2], box[3],
+               box[4], box[5], d_max_bits);
     return (int) hipGetLastError();
 }
 

@@ -433,9 +433,6 @@ struct PassAArgs {
 #ifndef SOBFU_PIN
 #define SOBFU_PIN 2  // bit 0: pass A, bit 1: pass B
 #endif
-#ifndef SOBFU_NTA
-#define SOBFU_NTA 0  // experiment (big grids, compact format): REAL streaming hints in pass A through buffer instructions -- bit 0: the nabla_U store, bit 1: next-plane psi / F loads of rows no y-neighbour tile re-reads, bit 2: of all rows
-#endif
 #ifndef SOBFU_BG_AHEAD
 #define SOBFU_BG_AHEAD 1  // pass A requests phi_global one plane ahead (0: in the step that uses it)
 #endif
@@ -624,10 +621,7 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
         const size_t zn = (size_t) min(z + 1, d.z - 1) * plane, zcur = (size_t) z * plane;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            if (NTL >= 1 && COMPACT && RPT == 1 && (((SOBFU_NTA & 2) && wy > 0 && wy < WY - 1) || (SOBFU_NTA & 4))) {
-                pn[r] = buf_ld3(buf_rsrc(a.psi, 0xffffffffu), (uint32_t) (zn + off[r]) * 12u, 0u, true);
-                fn[r] = __builtin_nontemporal_load((const float*) a.pnp + zn + off[r]);
-            } else if (NTL >= 5 && COMPACT && RPT == 1 && wy > 0 && wy < WY - 1) {  // rows no y-neighbour tile re-reads
+            if (NTL >= 5 && COMPACT && RPT == 1 && wy > 0 && wy < WY - 1) {  // rows no y-neighbour tile re-reads
                 pn[r] = ldv_nt<COMPACT>(a.psi, zn + off[r]);
                 fn[r] = __builtin_nontemporal_load((const float*) a.pnp + zn + off[r]);
             } else {
@@ -672,8 +666,7 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
                         st3_system(pd->base + 3 * j, o);
                     }
                     if (z >= pd->lz0 && z < pd->lz1) stv<COMPACT>(a.nU, i, o);  // ... and where the box stands in for the owned block, home too
-                } else if (NTL >= 1 && COMPACT && (SOBFU_NTA & 1)) buf_st3(buf_rsrc(a.nU, 0xffffffffu), (uint32_t) i * 12u, 0u, o, true);
-                else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
+                } else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
                 else stv<COMPACT>(a.nU, i, o);
             }
         }

@@ -118,6 +118,17 @@ class TileLayout:
     def own_box(self):
         return (self.o0[0], self.o1[0], self.o0[1], self.o1[1], self.o0[2], self.o1[2])
 
+    def owned_box_global(self):
+        return (self.g0[0], self.g1[0], self.g0[1], self.g1[1], self.g0[2], self.g1[2])
+
+    def window_box(self, w):
+        """global box of the owned cells widened by w cells on every side, clipped to the volume"""
+        return tuple(v for a in range(3) for v in (max(self.g0[a] - w, 0), min(self.g1[a] + w, self.dims[a])))
+
+    def min_owned_extent(self):
+        """smallest owned extent of ANY tile along an axis that is split (a halo wider than that reaches past the neighbours)"""
+        return min([self.dims[a] // self.grid[a] for a in range(3) if self.grid[a] > 1] or [max(self.dims)])
+
     def pass_b_boxes(self):
         """[(box, thin)] pass B produces: the owned cells with their one-cell z shells (extra planes of the march) and the one-cell
         y / x shells as THIN boxes (evaluated lane per cell).  Cells on tile edges (two shells at once) are never read."""
@@ -201,19 +212,130 @@ def gather_owned(layout, local, group=None):
     return full
 
 
+def _box_and(a, b):
+    r = tuple(v for k in range(3) for v in (max(a[2 * k], b[2 * k]), min(a[2 * k + 1], b[2 * k + 1])))
+    return r if all(r[2 * k] < r[2 * k + 1] for k in range(3)) else None
+
+
+def window_plan(layout, w):
+    """Who sends what so that every rank holds its WINDOW (owned cells widened by w, clipped to the volume) of a field:
+    (window box, recvs, sends) in GLOBAL cell coordinates -- recvs = [(rank q, owned(q) & window(me))], sends = [(q, owned(me) &
+    window(q))], q != me.  Owned boxes are disjoint and a window is a box, so a pair of ranks exchanges at most one box each way; with
+    w below the tiles' extents these are the 26 face / edge / corner neighbours, but nothing here assumes that."""
+    me = layout
+    lays = [TileLayout(me.dims, me.grid, q, me.halo) for q in range(me.world)]
+    wb = me.window_box(w)
+    recvs = [(q, b) for q, l in enumerate(lays) if q != me.rank for b in [_box_and(l.owned_box_global(), wb)] if b]
+    sends = [(q, b) for q, l in enumerate(lays) if q != me.rank for b in [_box_and(me.owned_box_global(), l.window_box(w))] if b]
+    return wb, recvs, sends
+
+
+def _cut(t, box, origin):
+    """view of tensor t (z, y, x, ...) on global box `box`, t's cell (0, 0, 0) being global cell `origin`"""
+    return t[box[4] - origin[2]:box[5] - origin[2], box[2] - origin[1]:box[3] - origin[1], box[0] - origin[0]:box[1] - origin[0]]
+
+
+class DistHalo:
+    """What the per-frame tail needs from the other ranks, over torch.distributed: one MAX reduction of a float and the window of a
+    field (point-to-point: every rank receives exactly the cells of its window it does not own -- a few MB at 256^3 where the
+    all-gather moved the whole volume to everybody).  via_host: stage through host memory (ranks that share a GPU run on gloo)."""
+
+    def __init__(self, layout, group=None, via_host=None):
+        self.L, self.group = layout, group
+        self.via_host = (dist.get_backend(group) == "gloo") if via_host is None else via_host
+        self.bytes_received = 0
+
+    def _peer(self, q):
+        return q if self.group is None else dist.get_global_rank(self.group, q)
+
+    def allreduce_max(self, value):
+        if self.L.world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if self.via_host else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def window(self, local, w, nch):
+        """-> (window tensor with local's channel count, window box).  nch: leading channels that travel (psi: 3 of 4, w stays 0)"""
+        L = self.L
+        wb, recvs, sends = window_plan(L, w)
+        win = torch.zeros((wb[5] - wb[4], wb[3] - wb[2], wb[1] - wb[0]) + tuple(local.shape[3:]), dtype=local.dtype, device=local.device)
+        origin = (wb[0], wb[2], wb[4])
+        _cut(win, L.owned_box_global(), origin).copy_(L.owned(local))
+        dev = "cpu" if self.via_host else local.device
+        rbuf = [torch.empty((b[5] - b[4], b[3] - b[2], b[1] - b[0], nch), dtype=local.dtype, device=dev) for _, b in recvs]
+        sbuf = [_cut(local, b, L.base)[..., :nch].contiguous().to(dev) for _, b in sends]
+        if not self.via_host:
+            torch.cuda.current_stream().synchronize()  # the send buffers are final before the communication stream reads them
+        ops = [dist.P2POp(dist.irecv, t, self._peer(q), self.group) for (q, _), t in zip(recvs, rbuf)]
+        ops += [dist.P2POp(dist.isend, t, self._peer(q), self.group) for (q, _), t in zip(sends, sbuf)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for (q, b), t in zip(recvs, rbuf):
+            _cut(win, b, origin)[..., :nch].copy_(t.to(local.device))
+            self.bytes_received += t.numel() * t.element_size()
+        return win, wb
+
+
 def estimate_psi_tiled(solver, phi_global_local, phi_global_psi_inv_local, phi_n_full, phi_n_psi_local, psi_local, psi_inv_local,
-                       n_iters, inverse_iters=48, gather=None):
-    """One frame's Solver::estimate_psi (src/sobfu/cuda/solver.cu:85-205) on tiles: the tiled iteration loop, then the
-    two per-frame collectives of SURVEY 8(e) -- all-gather psi for the 48-sweep inverse (it gathers psi at arbitrary
-    psi^-1(x)), all-gather phi_global for the canonical -> live warp -- each followed by the tile kernel.  HIP backend only
-    (C ABI: sobfu_hip_tile3_init_identity / tile3_estimate_inverse / tile3_apply).  `gather` overrides solver.gather_owned
-    (tests).  Returns (iterations, per-iteration max norms)."""
+                       n_iters, inverse_iters=48, gather=None, halo=None):
+    """One frame's Solver::estimate_psi (src/sobfu/cuda/solver.cu:85-205) on tiles: the tiled iteration loop, then the per-frame
+    tail (solver.cu:196-199): psi^-1 by 48 fixed-point sweeps from the identity, and phi_global o psi^-1.
+
+    The tail gathers psi at psi^-1(x) and phi_global at psi^-1(x) -- points within r = max |psi - id| (over the whole volume) of x
+    (src/sobfu/cuda/vector_fields.cu:111-138, include/sobfu/cuda/utils.hpp:124-164).  So, after ONE global MAX reduction, every rank
+    fetches psi and phi_global on its owned cells widened by ceil(r) + 2 cells (`halo`: DistHalo over torch.distributed, or a test
+    double) and runs the windowed tile kernels (sobfu_hip_tile3_{estimate_inverse,apply}_window): a few MB per frame instead of the
+    two all-gathers of SURVEY 8(e) (psi 268 MB + phi_global 134 MB at 256^3, which do not shrink with N).  Same clamps on the global
+    extents, same arithmetic: bit-identical.  When the window would reach past the neighbours (r larger than the smallest tile), or a
+    sample is reported outside its window, the tail runs on all-gathered sources as before (`gather`).  Passing `gather` WITHOUT
+    `halo` forces that path (tests).  HIP backend only.  Returns (iterations, per-iteration max norms); solver.tail_stats says which
+    path ran and what it moved."""
+    done, norms = solver.iterate(phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters)
+    frame_tail(solver, phi_global_local, phi_global_psi_inv_local, psi_local, psi_inv_local, inverse_iters, gather, halo)
+    return done, norms
+
+
+def frame_tail(solver, phi_global_local, phi_global_psi_inv_local, psi_local, psi_inv_local, inverse_iters=48, gather=None, halo=None):
+    """the tail of estimate_psi_tiled on its own: psi^-1 and phi_global o psi^-1 on the owned cells (see there); fills solver.tail_stats"""
     from . import _lib
 
     L = solver.layout
     lib, st = _lib.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if halo is None and gather is None and L.world > 1:
+        halo = solver.halo_comm()
     gather = gather or solver.gather_owned
-    done, norms = solver.iterate(phi_global_local, phi_n_full, phi_n_psi_local, psi_local, n_iters)
+    I6 = C.c_int * 6
+    own = I6(*L.own_box())
+    stats = {"mode": "all-gather", "reach": None, "halo_width": None, "bytes_received": 0}
+    if halo is not None:
+        bits = torch.zeros(1, dtype=torch.int32, device=psi_local.device)
+        _lib.check(lib.sobfu_hip_tile3_max_displacement(C.c_void_p(psi_local.data_ptr()), *L.L, *L.base, own, C.c_void_p(bits.data_ptr()), st),
+                   "tile3_max_displacement")
+        r = halo.allreduce_max(float(np.array([bits.item()], np.int32).view(np.float32)[0]))
+        w = int(np.ceil(r)) + 2 if r < 1e30 else 1 << 30
+        stats["reach"] = r
+        if w <= L.min_owned_extent():
+            got0 = getattr(halo, "bytes_received", 0)
+            viol = torch.zeros(1, dtype=torch.int32, device=psi_local.device)
+            psi_win, wb = halo.window(psi_local, w, 3)
+            win6 = I6(wb[1] - wb[0], wb[3] - wb[2], wb[5] - wb[4], wb[0], wb[2], wb[4])
+            _lib.check(lib.sobfu_hip_tile3_init_identity(C.c_void_p(psi_inv_local.data_ptr()), *L.L, *L.base, st), "tile3_init_identity")
+            _lib.check(lib.sobfu_hip_tile3_estimate_inverse_window(C.c_void_p(psi_win.data_ptr()), win6, *L.dims, C.c_void_p(psi_inv_local.data_ptr()),
+                                                                   *L.L, *L.base, own, C.c_int(inverse_iters), C.c_void_p(viol.data_ptr()), st),
+                       "tile3_estimate_inverse_window")
+            pg_win, wb2 = halo.window(phi_global_local, w, 2)
+            assert wb2 == wb
+            _lib.check(lib.sobfu_hip_tile3_apply_window(C.c_void_p(pg_win.data_ptr()), win6, *L.dims, C.c_void_p(phi_global_psi_inv_local.data_ptr()),
+                                                        C.c_void_p(psi_inv_local.data_ptr()), *L.L, own, C.c_void_p(viol.data_ptr()), st),
+                       "tile3_apply_window")
+            bad = halo.allreduce_max(float(viol.item()))  # (synchronises: the windows die with this frame) -- every rank takes the same path
+            stats.update(mode="halo", halo_width=w, bytes_received=getattr(halo, "bytes_received", 0) - got0)
+            if bad == 0.0:
+                solver.tail_stats = stats
+                return
+            stats["mode"] = "all-gather (a sample left its window: the reach bound did not hold)"
     psi_full = gather(psi_local)                                                              # solver.cu:196-197
     _lib.check(lib.sobfu_hip_tile3_init_identity(C.c_void_p(psi_inv_local.data_ptr()), *L.L, *L.base, st), "tile3_init_identity")
     _lib.check(lib.sobfu_hip_tile3_estimate_inverse(C.c_void_p(psi_full.data_ptr()), *L.dims, C.c_void_p(psi_inv_local.data_ptr()), *L.L,
@@ -222,7 +344,10 @@ def estimate_psi_tiled(solver, phi_global_local, phi_global_psi_inv_local, phi_n
     _lib.check(lib.sobfu_hip_tile3_apply(C.c_void_p(pg_full.data_ptr()), *L.dims, C.c_void_p(phi_global_psi_inv_local.data_ptr()),
                                          C.c_void_p(psi_inv_local.data_ptr()), *L.L, st), "tile3_apply")
     torch.cuda.current_stream().synchronize()  # psi_full / pg_full die with this frame
-    return done, norms
+    X, Y, Z = L.dims
+    own_cells = (L.g1[0] - L.g0[0]) * (L.g1[1] - L.g0[1]) * (L.g1[2] - L.g0[2])
+    stats["bytes_received"] += (X * Y * Z - own_cells) * (16 + 8) if L.world > 1 else 0
+    solver.tail_stats = stats
 
 
 class TiledFusion:
@@ -234,10 +359,10 @@ class TiledFusion:
     params: dims, size (metres), trunc, eta (metres), max_weight, intr (fx, fy, cx, cy), R, t (volume -> camera), start_frame,
     bilateral (ksz, sigma_spatial, sigma_depth), trunc_depth, max_iter; `solver` is a TiledSolver / NativeTiledSolver."""
 
-    def __init__(self, solver, params, gather=None):
+    def __init__(self, solver, params, gather=None, halo=None):
         from . import ops
 
-        self.ops, self.solver, self.P, self.gather = ops, solver, params, gather
+        self.ops, self.solver, self.P, self.gather, self.halo = ops, solver, params, gather, halo
         self.L = solver.layout
         self.frame = 0
         X, Y, Z = self.L.dims
@@ -265,7 +390,7 @@ class TiledFusion:
             ops.integrate_fuse(self.phi_global, L.take(self.phi_n).contiguous(), P["max_weight"])
         else:
             result = s.estimate_psi(self.phi_global, self.phi_global_psi_inv, self.phi_n, self.phi_n_psi, self.psi, self.psi_inv,
-                                    P["max_iter"], gather=self.gather)               # :141
+                                    P["max_iter"], gather=self.gather, halo=self.halo)  # :141
             ops.integrate_fuse(self.phi_global, self.phi_n_psi, P["max_weight"])     # :142 (halo cells come out stale; never read)
         self.frame += 1
         return result
@@ -563,6 +688,14 @@ class NativeTiledSolver:
 
     def gather_owned(self, local):
         return gather_owned(self.layout, local, self.group)
+
+    tail_stats = None  # what the last frame's tail did (estimate_psi_tiled)
+
+    def halo_comm(self):
+        """the per-frame tail's communication over this handle's process group (kept: it counts the bytes it has received)"""
+        if getattr(self, "_halo", None) is None:
+            self._halo = DistHalo(self.layout, self.group)
+        return self._halo
 
     def estimate_psi(self, *args, **kw):
         return estimate_psi_tiled(self, *args, **kw)

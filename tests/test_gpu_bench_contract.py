@@ -146,7 +146,12 @@ def test_gpus_8_harvests_everything():
     assert topo["devices_visible"] >= 1 and "pairs" in topo
     f = d["per_frame"]
     assert f["frames_timed"] == 3 and f["iterations_per_frame"][-1] == 8 and f["frames_per_s"] > 0 and f["tiles"] == "2x2x2"
-    assert f["all_gathered_bytes_per_frame"] == 64 ** 3 * 24
+    # the per-frame tail moves bounded-reach windows, not two all-gathers, and says so; checked against the
+    # all-gather tail bit for bit inside the run
+    t = f["tail"]
+    assert t["mode"] == ["halo"] and t["parity_vs_all_gather_tail"] == "bit-exact" and t["all_gather_would_move_bytes"] == 64 ** 3 * 24
+    assert 0 < f["all_gathered_bytes_per_frame"] == t["bytes_received_per_frame_per_rank"] < 0.25 * 64 ** 3 * 24
+    assert t["halo_width_cells"] and max(t["halo_width_cells"]) <= 6 and 0 < t["max_displacement_voxels"] < 4
 
 
 def test_budget_skips_the_harvest_and_keeps_one_valid_line():

@@ -407,10 +407,60 @@ class LoopGather:
         return gather
 
 
+class LoopHalo:
+    """the per-frame tail's communication (sobfu_amd.tiled.DistHalo's interface) between the rank threads of one process: a MAX
+    reduction and the bounded-reach window of a field, assembled from the owners' parts by the same window_plan the real one uses"""
+
+    def __init__(self, solvers):
+        self.sv, n = solvers, len(solvers)
+        self.parts, self.vals, self.bar = [None] * n, [None] * n, threading.Barrier(n)
+
+    def make(self, rank, layout):
+        import torch
+
+        from sobfu_amd import tiled
+
+        outer = self
+
+        class Halo:
+            bytes_received = 0
+
+            def allreduce_max(self, v):
+                outer.vals[rank] = float(v)
+                outer.bar.wait(timeout=60)
+                m = max(outer.vals)
+                outer.bar.wait(timeout=60)
+                return m
+
+            def window(self, local, w, nch):
+                torch.cuda.current_stream().synchronize()
+                outer.parts[rank] = layout.owned(local).contiguous()
+                torch.cuda.current_stream().synchronize()
+                outer.bar.wait(timeout=60)
+                wb, recvs, _ = tiled.window_plan(layout, w)
+                win = torch.zeros((wb[5] - wb[4], wb[3] - wb[2], wb[1] - wb[0]) + tuple(local.shape[3:]), dtype=local.dtype, device=local.device)
+                origin = (wb[0], wb[2], wb[4])
+                tiled._cut(win, layout.owned_box_global(), origin).copy_(layout.owned(local))
+                for q, b in recvs:
+                    Lq = outer.sv[q].layout
+                    src = tiled._cut(outer.parts[q], b, Lq.g0)
+                    tiled._cut(win, b, origin)[..., :nch].copy_(src[..., :nch])
+                    self.bytes_received += src[..., :nch].numel() * 4
+                torch.cuda.current_stream().synchronize()
+                outer.bar.wait(timeout=60)
+                return win, wb
+
+        return Halo()
+
+
+@pytest.mark.parametrize("tail,amp", [("gather", 0.5), ("halo", 0.5), ("halo", 2.6), ("halo-overflow", 13.0)])
 @pytest.mark.parametrize("dims,world", [((40, 24, 36), 3), ((33, 17, 16), 4), ((40, 24, 36), (2, 2, 2)), ((33, 17, 16), (1, 2, 2))])
-def test_tiled_frame_estimate_psi_loopback(dims, world):
-    """A whole frame on tiles (iterations, all-gather psi -> 48-sweep inverse, all-gather phi_global -> canonical warp) =
-    the single-GPU Solver::estimate_psi, bit for bit, on every rank's owned planes."""
+def test_tiled_frame_estimate_psi_loopback(dims, world, tail, amp):
+    """A whole frame on tiles = the single-GPU Solver::estimate_psi, bit for bit, on every rank's owned cells -- with the tail
+    (48-sweep inverse, canonical warp) on all-gathered sources ("gather": the two collectives of SURVEY 8(e)), on bounded-reach WINDOWS
+    of psi / phi_global fetched from the neighbours ("halo": one MAX reduction of |psi - id| sizes them; amp 2.6 makes them 5 cells
+    wide and the samples really leave the tile), and with a displacement that outgrows the tiles ("halo-overflow": the windows would
+    reach past the neighbours, so the tail falls back to the all-gather)."""
     import torch
 
     import oracle
@@ -422,7 +472,7 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
     psi0 = oracle.new_field(dims)
     oracle.init_identity(psi0)
-    psi0[..., :3] += rng.uniform(-0.5, 0.5, psi0[..., :3].shape).astype(np.float32)
+    psi0[..., :3] += rng.uniform(-amp, amp, psi0[..., :3].shape).astype(np.float32)
     n_iters = 5
     ref = ops.Solver(dims, max_iter=n_iters, alpha=0.05, w_reg=0.4)
     psi_r, inv_r, pnp_r, pgi_r = torch.from_numpy(psi0.copy()).cuda(), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
@@ -432,11 +482,11 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     grid = as_grid(world)
     world = grid[0] * grid[1] * grid[2]
     solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(world, r), grid=grid) for r in range(world)]
-    lb, lg = Loopback(solvers), LoopGather(solvers)
+    lb, lg, lh = Loopback(solvers), LoopGather(solvers), LoopHalo(solvers)
     for s in solvers:
         s.set_transport(lb.exchange, lb.allreduce)
     pn_d = torch.from_numpy(pn).cuda()
-    out, errs = [None] * world, []
+    out, errs, modes = [None] * world, [], [None] * world
 
     def rank_main(r):
         try:
@@ -446,13 +496,17 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
                 pg_l = torch.from_numpy(np.ascontiguousarray(L.take(pg))).cuda()
                 psi_l = torch.from_numpy(np.ascontiguousarray(L.take(psi0))).cuda()
                 pnp_l, pgi_l, inv_l = s.new_local(2), s.new_local(2), s.new_local(4)
-                done, _ = s.estimate_psi(pg_l, pgi_l, pn_d, pnp_l, psi_l, inv_l, n_iters, gather=lg.make(r, L))
+                inv_l[...] = -5.0  # whatever the tail leaves outside the owned cells, it must produce the owned ones itself
+                done, _ = s.estimate_psi(pg_l, pgi_l, pn_d, pnp_l, psi_l, inv_l, n_iters, gather=lg.make(r, L),
+                                         halo=(None if tail == "gather" else lh.make(r, L)))
                 torch.cuda.current_stream().synchronize()
+            modes[r] = dict(s.tail_stats)
             out[r] = (done, L.owned(psi_l).cpu().numpy(), L.owned(pnp_l).cpu().numpy(), L.owned(inv_l).cpu().numpy(), L.owned(pgi_l).cpu().numpy())
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
             lb.bar.abort()
             lg.bar.abort()
+            lh.bar.abort()
 
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in th:
@@ -468,10 +522,19 @@ def test_tiled_frame_estimate_psi_loopback(dims, world):
     assert np.array_equal(cat(2).view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
     assert np.array_equal(cat(3)[..., :3].view(np.uint32), inv_r.cpu().numpy()[..., :3].view(np.uint32))
     assert np.array_equal(cat(4).view(np.uint32), pgi_r.cpu().numpy().view(np.uint32))
+    full = dims[0] * dims[1] * dims[2] * 24
+    fits = int(np.ceil(modes[0]["reach"] or 0)) + 2 <= tiled.TileLayout(dims, grid, 0).min_owned_extent()  # (33, 17, 16) on four 4-plane slabs: 5 > 4
+    if tail == "halo" and fits:
+        assert all(m["mode"] == "halo" and m["halo_width"] == int(np.ceil(m["reach"])) + 2 for m in modes), modes
+        assert all(0 < m["bytes_received"] < full for m in modes) and (amp < 1 or modes[0]["halo_width"] >= 5)
+    else:
+        assert all(m["mode"] == "all-gather" for m in modes), modes
+        assert tail == "gather" or all(m["reach"] > 8 for m in modes)
 
 
+@pytest.mark.parametrize("tail", ["gather", "halo"])
 @pytest.mark.parametrize("world", [2, 4, (2, 2, 2), (1, 2, 2)])
-def test_tiled_fusion_frames_loopback(world):
+def test_tiled_fusion_frames_loopback(world, tail):
     """BASELINE config 1 (64^3, translating sphere, three frames) through TiledFusion on N tiles = the same frames through the
     single-GPU launchers: phi_global after every frame and psi at the end, bit for bit."""
     import torch
@@ -510,7 +573,7 @@ def test_tiled_fusion_frames_loopback(world):
     grid = as_grid(world)
     world = grid[0] * grid[1] * grid[2]
     solvers = [tiled.NativeTiledSolver(dims, dry=(world, r), grid=grid, **kw) for r in range(world)]
-    lb, lg = Loopback(solvers), LoopGather(solvers)
+    lb, lg, lh = Loopback(solvers), LoopGather(solvers), LoopHalo(solvers)
     for s in solvers:
         s.set_transport(lb.exchange, lb.allreduce)
     out, errs = [None] * world, []
@@ -518,17 +581,19 @@ def test_tiled_fusion_frames_loopback(world):
     def rank_main(r):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                fu = tiled.TiledFusion(solvers[r], P, gather=lg.make(r, solvers[r].layout))
+                fu = tiled.TiledFusion(solvers[r], P, gather=lg.make(r, solvers[r].layout), halo=(lh.make(r, solvers[r].layout) if tail == "halo" else None))
                 L, pgs = solvers[r].layout, []
                 for f in frames:
                     fu(f)
                     torch.cuda.current_stream().synchronize()
                     pgs.append(L.owned(fu.phi_global).cpu().numpy().copy())
                 out[r] = (pgs, L.owned(fu.psi).cpu().numpy(), L.owned(fu.psi_inv).cpu().numpy())
+                assert solvers[r].tail_stats["mode"] == ("halo" if tail == "halo" else "all-gather"), solvers[r].tail_stats
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
             lb.bar.abort()
             lg.bar.abort()
+            lh.bar.abort()
 
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in th:

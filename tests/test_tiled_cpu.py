@@ -177,3 +177,34 @@ def test_layout_properties():
         assert own == list(range(64))
     with pytest.raises(ValueError):
         SlabLayout((16, 16, 8), 4, 0)
+
+
+@pytest.mark.parametrize("grid,dims,w", [("1x1x2", "20,12,24", 3), ("2x2x1", "20,12,24", 2), ("1x2x2", "20,12,24", 5), ("2x2x2", "16,18,20", 3),
+                                         ("1x1x4", "8,8,24", 6),  # w == the tiles' extent: a window reaches the next ring's owner ... not yet: exactly the neighbour
+                                         ("1x1x4", "8,8,24", 9)])  # ... and beyond it: cells two tiles away travel too (nothing assumes 26 neighbours)
+def test_bounded_reach_windows_over_gloo(grid, dims, w):
+    """the communication of the per-frame tail on tiles (sobfu_amd.tiled.DistHalo / window_plan): every rank ends up with its owned cells
+    widened by w, fetched point-to-point from their owners; the bytes received are exactly the cells it does not own"""
+    world = int(np.prod([int(v) for v in grid.split("x")]))
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_halo_worker.py"), str(r), str(world), port, grid, dims, str(w)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+
+
+def test_window_plan_is_symmetric_and_covers_the_window():
+    from sobfu_amd import tiled
+
+    for dims, grid, w in (((256, 256, 256), (2, 2, 2), 3), ((70, 33, 40), (2, 1, 3), 4), ((64, 64, 64), (1, 2, 4), 17)):
+        world = grid[0] * grid[1] * grid[2]
+        plans = [tiled.window_plan(tiled.TileLayout(dims, grid, r), w) for r in range(world)]
+        for r, (wb, recvs, sends) in enumerate(plans):
+            cells = sum((b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]) for _, b in recvs)
+            L = tiled.TileLayout(dims, grid, r)
+            own = (L.g1[0] - L.g0[0]) * (L.g1[1] - L.g0[1]) * (L.g1[2] - L.g0[2])
+            assert cells + own == (wb[1] - wb[0]) * (wb[3] - wb[2]) * (wb[5] - wb[4])  # disjoint owners tile the window exactly
+            for q, b in recvs:  # what r expects from q is what q sends to r
+                assert (r, b) in plans[q][2]
+        if dims == (256, 256, 256):  # BASELINE config 4: 7 neighbours, 1.8 MB of psi + 1.2 MB of phi_global instead of 268 + 134 MB
+            assert len(plans[0][1]) == 7 and sum((b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]) for _, b in plans[0][1]) == 131 ** 3 - 128 ** 3
