@@ -134,6 +134,12 @@ SOBFU_DEV void stv(void* base, size_t i, const float4& v) {
 // neighbouring workgroups re-read from the XCD's L2 (nabla_U halo rows, phi_n corners)
 #ifndef SOBFU_NT
 #define SOBFU_NT 3  // 1 = pass B stores of psi / phi_n o psi, 2 = + pass B load of psi, 3 = + pass A load of phi_global (4: + nabla_U store, 5: + pass A inner rows: A slower, B faster, no net gain)
+// NB (found in the ISA in round 5): hipcc keeps the hint of __builtin_nontemporal_load / _store on 4-byte accesses (`global_store_dword
+// ... nt`: phi_n o psi, phi_global, F) but DROPS it on the 4-byte-aligned 12-byte vector type -- the 12-byte variants below compile to
+// plain `global_load/store_dwordx3`.  Where the hint on a 12-byte access matters it goes through a buffer instruction, whose cache-policy
+// operand carries it (buf_ld3 / buf_st3: the pipelined march, and the plain march's psi load / store since round 5: template NTBUF,
+// + 3.4 % iterations/s at 256^3).  Levels 4 / 5 were therefore only ever measured on their 4-byte half; with real hints through buffer
+// instructions (round 5, profiles/r05_experiments/nta_ab_256.log) they are within the box's run-to-run noise: not kept.
 #endif
 template <bool C>
 SOBFU_DEV float4 ldv_nt(const void* base, size_t i) {

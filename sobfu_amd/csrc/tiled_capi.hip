@@ -224,6 +224,9 @@ TileLay make_layout(const int dims[3], const int P[3], int rank) {
                 m.peer = (c[0] + dx) + P[0] * ((c[1] + dy) + P[1] * (c[2] + dz));
                 t.msgs.push_back(m);
             }
+    // the z FACES go last: on the packed (RCCL / callback) transports of a 3-D tile they travel IN PLACE as whole padded planes of the
+    // array (see exchange_packed), so the messages that do use the packed buffers are a prefix of the list and of the buffers
+    std::stable_partition(t.msgs.begin(), t.msgs.end(), [](const MsgGeom& m) { return !(m.dir[0] == 0 && m.dir[1] == 0 && m.dir[2] != 0); });
     return t;
 }
 
@@ -259,6 +262,10 @@ struct sobfu_hip_tiled {
     std::vector<MsgGeom> geom;
     std::vector<int> sboxes, rboxes;  // 6 ints per message: the cells sent / the halo cells received
     float *sendbuf = nullptr, *recvbuf = nullptr;
+    // packed transports of a 3-D tile: the first n_packed messages travel through the buffers, the z faces behind them in place
+    // (zmsgs: offsets into the nabla_U array itself -- 4 whole padded planes out of the owned rim, 4 into the halo)
+    int n_packed = 0;
+    std::vector<sobfu_hip_tiled_msg> zmsgs;
     // direct transport (sobfu_hip_tiled_connect): push destinations in the peers, signalling state
     bool direct = false, dead = false, first_checked = false, dry_packed = false, force_comm = false;
     int debug_skip = 0;  // timing experiments only (results are wrong): see tiled_step_impl
@@ -311,7 +318,10 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
     // 1 x 1 x 8 slabs of 256^3 43.1 -> 41.6 us per iteration; 2 x 2 x 2 and 1 x 2 x 4 tiles unchanged (43.4 / 44.7).
     const int ny_nb = (t->lo[1] ? 1 : 0) + (t->hi[1] ? 1 : 0), nz_nb = (t->lo[2] ? 1 : 0) + (t->hi[2] ? 1 : 0);
     const bool wide = (t->o1[0] - t->o0[0]) >= 64;  // rows wide enough for the faces to be MARCHED (thin rows: lane per cell, push-only)
-    const bool z_home = wide && nz_nb > 0 && (t->o1[2] - t->o0[2]) > kHalo * nz_nb;
+    // packed (RCCL / callback) transports of a 3-D tile: the z faces leave IN PLACE, straight out of the owned block's rim planes -- no
+    // push box evaluates them and the owned block keeps those planes
+    const bool z_inplace = dst0 == nullptr && dst1 == nullptr && !t->slab && !t->zmsgs.empty();
+    const bool z_home = !z_inplace && wide && nz_nb > 0 && (t->o1[2] - t->o0[2]) > kHalo * nz_nb;
     const bool y_home = wide && ny_nb > 0 && (t->o1[1] - t->o0[1]) > 8 * ny_nb;
     const int iz0 = t->o0[2] + ((z_home && t->lo[2]) ? kHalo : 0), iz1 = t->o1[2] - ((z_home && t->hi[2]) ? kHalo : 0);  // planes the z boxes leave
     const int iy0 = t->o0[1] + ((y_home && t->lo[1]) ? 8 : 0), iy1 = t->o1[1] - ((y_home && t->hi[1]) ? 8 : 0);
@@ -332,6 +342,7 @@ void build_a_boxes(sobfu_hip_tiled* t, float* const* dst0, float* const* dst1, c
                 if (m.dir[1] > 0) b.box.y0 = t->o1[1] - 8; else b.box.y1 = t->o0[1] + 8;
                 b.local_z0 = iz0; b.local_z1 = iz1;
             }
+            if (z_inplace && m.dir[0] == 0 && m.dir[1] == 0 && m.dir[2] != 0) continue;
             if ((!march && (t->debug_skip & 128)) || (march && (t->debug_skip & 256))) continue;  // timing experiments: without the thin / the marched push boxes
             if (march && (t->debug_skip & 512)) b.push_y1 = b.push_y0;  // timing experiments: the marched boxes keep their cells at home only
             float* const* dst = h ? dst1 : dst0;
@@ -483,7 +494,15 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
             t->msgs.push_back(m);
             t->sboxes.insert(t->sboxes.end(), g.sb, g.sb + 6);
             t->rboxes.insert(t->rboxes.end(), g.rb, g.rb + 6);
+            const bool zface = g.dir[0] == 0 && g.dir[1] == 0 && g.dir[2] != 0;
+            if (zface && !t->slab) {  // the neighbour across a z face shares this tile's x / y layout: whole planes of the array match
+                const size_t plane_f = (size_t) t->L[0] * t->L[1] * 3;
+                t->zmsgs.push_back(sobfu_hip_tiled_msg{g.peer, plane_f * (size_t) g.sb[4], plane_f * (size_t) g.rb[4], plane_f * (size_t) kHalo});
+            } else if (!zface) {
+                t->n_packed += 1;  // (z faces are last in the list)
+            }
         }
+        if (t->slab) t->n_packed = (int) t->msgs.size();  // (slabs never take the packed path; keep the count meaningful)
         if (off > 0) {
             rc = (int) hipMalloc((void**) &t->sendbuf, off * sizeof(float));
             if (rc == 0) rc = (int) hipMalloc((void**) &t->recvbuf, off * sizeof(float));
@@ -814,14 +833,25 @@ int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs
     return n;  // number of messages of an exchange
 }
 
-// Delivers the messages of one exchange from d_send to d_recv (RCCL grouped send/recv, or the user transport).
-static int transfer(sobfu_hip_tiled* t, const float* d_send, float* d_recv, const sobfu_hip_tiled_msg* msgs, int n, hipStream_t stream) {
-    if (n == 0) return 0;
-    if (!t->comm) return t->xfn ? t->xfn(t->tctx, t->rank, d_send, d_recv, msgs, n, (void*) stream) : 0;  // user transport / dry handle
+// Delivers the messages of one exchange from d_send to d_recv (RCCL grouped send/recv, or the user transport) and, in the same RCCL
+// group, a second list with its own base pointers (the in-place z faces of a 3-D tile: both bases are the field array itself).
+static int transfer(sobfu_hip_tiled* t, const float* d_send, float* d_recv, const sobfu_hip_tiled_msg* msgs, int n, hipStream_t stream,
+                    const float* d_send2 = nullptr, float* d_recv2 = nullptr, const sobfu_hip_tiled_msg* msgs2 = nullptr, int n2 = 0) {
+    if (n + n2 == 0) return 0;
+    if (!t->comm) {  // user transport / dry handle: one call per list (a transport sees at most one message per peer in a call)
+        if (!t->xfn) return 0;
+        if (n > 0) SOBFU_TRY(t->xfn(t->tctx, t->rank, d_send, d_recv, msgs, n, (void*) stream));
+        if (n2 > 0) SOBFU_TRY(t->xfn(t->tctx, t->rank, d_send2, d_recv2, msgs2, n2, (void*) stream));
+        return 0;
+    }
     RCCL_TRY(g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
         RCCL_TRY(g_rccl.Send(d_send + msgs[i].send_off, msgs[i].count, ncclFloat32, msgs[i].peer, t->comm, stream));
         RCCL_TRY(g_rccl.Recv(d_recv + msgs[i].recv_off, msgs[i].count, ncclFloat32, msgs[i].peer, t->comm, stream));
+    }
+    for (int i = 0; i < n2; ++i) {
+        RCCL_TRY(g_rccl.Send(d_send2 + msgs2[i].send_off, msgs2[i].count, ncclFloat32, msgs2[i].peer, t->comm, stream));
+        RCCL_TRY(g_rccl.Recv(d_recv2 + msgs2[i].recv_off, msgs2[i].count, ncclFloat32, msgs2[i].peer, t->comm, stream));
     }
     RCCL_TRY(g_rccl.GroupEnd());
     return 0;
@@ -838,10 +868,15 @@ static int exchange_planes(sobfu_hip_tiled* t, float* field3, int planes, hipStr
 }
 
 // tile path, RCCL / callback transports: the send buffer (filled by pass A's push boxes) -> peers -> scatter into the halo cells
+// The z FACES do not go through the buffers: the neighbour across a z face has the same x / y layout, so 4 whole padded planes of the
+// array (Lx x Ly x 4 cells: + 6 % bytes on a 132^2 plane) leave straight out of the owned rim and land straight in the halo planes --
+// no push box packs them, the scatter kernel does not touch them.  What arrives in those planes' x / y halo columns is the sender's own
+// (stale) halo content: exactly the cells of the xz / yz EDGE STRIPS, which the scatter -- behind the transfer on the same stream --
+// overwrites with the diagonal neighbours' cells; the corner regions beyond are never read (every stencil is axis-aligned).
 static int exchange_packed(sobfu_hip_tiled* t, float* field3, hipStream_t stream) {
-    const int n = (int) t->msgs.size();
-    if (n == 0) return 0;
-    SOBFU_TRY(transfer(t, t->sendbuf, t->recvbuf, t->msgs.data(), n, stream));
+    const int n = t->n_packed, nz = (int) t->zmsgs.size();
+    if (n + nz == 0) return 0;
+    SOBFU_TRY(transfer(t, t->sendbuf, t->recvbuf, t->msgs.data(), n, stream, field3, field3, t->zmsgs.data(), nz));
     return sobfu_hip::launch_msg_copy(false, field3, t->recvbuf, t->L[0], t->L[1], t->L[2], t->rboxes.data(), n, stream);
 }
 
@@ -856,8 +891,8 @@ static int allreduce_max(sobfu_hip_tiled* t, uint32_t* buf, size_t n, hipStream_
 int sobfu_hip_tiled_exchange(sobfu_hip_tiled* t, float* d_field3, int planes, void* stream) {
     SOBFU_CHECK_ARGS(t && d_field3 && planes > 0 && planes <= kHalo && (t->slab || planes == kHalo));
     if (t->slab) return exchange_planes(t, d_field3, planes, (hipStream_t) stream);
-    const int n = (int) t->msgs.size();
-    if (n == 0) return 0;
+    const int n = t->n_packed;  // (the z faces travel in place: nothing to pack)
+    if (n + (int) t->zmsgs.size() == 0) return 0;
     SOBFU_TRY(sobfu_hip::launch_msg_copy(true, d_field3, t->sendbuf, t->L[0], t->L[1], t->L[2], t->sboxes.data(), n, (hipStream_t) stream));
     return exchange_packed(t, d_field3, (hipStream_t) stream);
 }

@@ -171,8 +171,9 @@ class TileLayout:
                 else:
                     sb += [self.o0[a], self.o1[a]]
                     rb += [self.o0[a], self.o1[a]]
-            out.append((n[0] + self.grid[0] * (n[1] + self.grid[1] * n[2]), tuple(sb), tuple(rb)))
-        return out
+            out.append((n[0] + self.grid[0] * (n[1] + self.grid[1] * n[2]), tuple(sb), tuple(rb), d[0] == 0 and d[1] == 0))
+        # the z faces go last (the library's order: on the packed transports of a 3-D tile they travel in place, as whole planes)
+        return [m[:3] for m in sorted(out, key=lambda m: m[3])]
 
 
 class SlabLayout(TileLayout):
