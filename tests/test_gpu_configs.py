@@ -15,9 +15,9 @@ config 3 -- 256^3, params_boxing.ini solver values, two analytic spheres: bench.
             per-iteration max norms, bit for bit; a second start (psi = identity + a 1.2-voxel smooth-free hash displacement) makes
             the gather, the inverse and the clamps do real work.  config 4's 2 x 2 x 2 tiles (direct transport) against the same
             oracle result.
-config 5 -- 512^3, params/params_umbrella.ini values (params/config5_umbrella_512.ini): too large for the oracle, so the two
-            independent HIP code paths are compared at full size (launcher kernels vs fused passes; compact vs API-format solve)
-            plus size-independent properties; the batched-replicas bench leg is smoked in tests/test_gpu_bench_contract.py.
+config 5 -- 512^3, params/params_umbrella.ini values (params/config5_umbrella_512.ini): a whole estimate_psi against the oracle at full
+            size when the host has the memory (test_config5_512_vs_oracle); the two independent HIP code paths compared at full
+            size (launcher kernels vs fused passes; compact vs API-format solve) plus size-independent properties; the batched-replicas bench leg is smoked in tests/test_gpu_bench_contract.py.
 """
 import os
 
@@ -257,6 +257,45 @@ def test_config4_tiles_vs_oracle_256(ops, oracle):
         assert done == n_iters and same(np.asarray(hist, np.float32), r["trace"][:, 2])
     assert same(psi_t[..., :3], psi_o[..., :3])
     assert same(pnp_t, r["phi_n_psi"])
+
+
+def test_config5_512_vs_oracle(ops, oracle):
+    """BASELINE config 5's grid and parameter set DIRECTLY against the oracle at full size (512^3, params_umbrella.ini values, two analytic
+    spheres): a whole estimate_psi -- 3 iterations + 48-sweep inverse + canonical warp -- psi, phi_n o psi, psi^-1, phi_global o psi^-1
+    and the max-norm history bit for bit on 134 M voxels.  The oracle needs ~25 GiB of host memory and half a minute at this size."""
+    import psutil
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs ~16 GiB of HBM")
+    if psutil.virtual_memory().available < 48 * 2 ** 30:
+        pytest.skip("needs ~25 GiB of host memory for the oracle's 512^3 arrays")
+    P = params.read_ini(os.path.join(ROOT, "params", "config5_umbrella_512.ini"))
+    dims, n_iters = P["dims"], 3
+    assert dims == (512, 512, 512)
+    c = 0.5
+    pg, pn = oracle.new_volume(dims), oracle.new_volume(dims)
+    oracle.init_sphere(pg, P["vs"], P["trunc"], P["eta"], (c, c, c), 0.25)
+    oracle.init_sphere(pn, P["vs"], P["trunc"], P["eta"], (c + 1.3 * float(P["vs"][0]), c, c - 0.7 * float(P["vs"][0])), 0.25)
+    psi_o = oracle.new_field(dims)
+    oracle.init_identity(psi_o)
+    r = oracle.estimate_psi(pg, pn, psi_o, max_iter=n_iters, alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"],
+                            max_update_norm=P["max_update_norm"], compute_jacobian=False)
+    r = {k: r[k] for k in ("iters", "phi_n_psi", "psi_inv", "phi_global_psi_inv", "trace")}
+    sv = ops.Solver(dims, max_iter=n_iters, alpha=P["alpha"], w_reg=P["w_reg"], s=P["s"], lam=P["lam"], max_update_norm=P["max_update_norm"])
+    psi_d, psi_inv_d = ops.new_field(dims), ops.new_field(dims)
+    ops.init_identity(psi_d)
+    pnp_d, pgi_d = ops.new_volume(dims), ops.new_volume(dims)
+    rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+    sv.close()
+    assert rep.iterations == n_iters == r["iters"] and same(hist, r["trace"][:, 2]) and float(hist.min()) > 0
+    assert same(host(psi_d), psi_o)
+    del psi_d
+    assert same(host(pnp_d), r["phi_n_psi"])
+    del pnp_d
+    assert same(host(psi_inv_d), r["psi_inv"])
+    del psi_inv_d
+    assert same(host(pgi_d), r["phi_global_psi_inv"])
 
 
 def test_config5_umbrella_512(ops, oracle):
