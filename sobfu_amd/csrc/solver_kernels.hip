@@ -1693,6 +1693,7 @@ static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, in
 // null-stream copy inside a launch path, stream order makes the list visible to the launch that follows.  Entries are never freed
 // one by one (a launch in flight may still be reading its list); when a device's entries exceed kMaxCachedLists -- lists are keyed by
 // peer pointers, so a process that keeps creating handles keeps creating lists -- the device is drained and its entries are dropped.
+// Nobody keeps a pointer into this cache beyond the launch it was looked up for (a TilePassAPlan owns its own copy).
 struct CachedBoxes {
     int device;
     uint64_t hash;
@@ -1703,7 +1704,7 @@ struct CachedBoxes {
     bool ready;
 };
 constexpr size_t kMaxCachedLists = 256;
-static std::vector<CachedBoxes> g_box_cache;
+static std::vector<CachedBoxes> g_box_cache, g_box_graveyard;
 static std::mutex g_box_cache_mutex;
 static uint64_t bytes_hash(const void* p, size_t n) {  // FNV-1a
     const unsigned char* b = (const unsigned char*) p;
@@ -1729,13 +1730,21 @@ static int device_boxes(const TileBoxList& L, TileBoxList** out, hipStream_t str
             return 0;
         }
     }
-    if (on_dev >= kMaxCachedLists) {  // rare: drain this device, then its lists are nobody's
+    if (on_dev >= kMaxCachedLists) {  // rare: this device's entries retire.  Two generations: what retired LAST time is freed now (after a
+        // device drain), what retires now is only taken out of the look-up -- a thread that has just looked an entry up and is about to
+        // launch with it (the lock is not held across the launch) still finds it alive
         SOBFU_HIP_TRY(hipDeviceSynchronize());
+        for (size_t k = 0; k < g_box_graveyard.size();) {
+            if (g_box_graveyard[k].device == dev) {
+                (void) hipFree(g_box_graveyard[k].dev);
+                (void) hipHostFree(g_box_graveyard[k].host);
+                (void) hipEventDestroy(g_box_graveyard[k].uploaded);
+                g_box_graveyard.erase(g_box_graveyard.begin() + (long) k);
+            } else ++k;
+        }
         for (size_t k = 0; k < g_box_cache.size();) {
             if (g_box_cache[k].device == dev) {
-                (void) hipFree(g_box_cache[k].dev);
-                (void) hipHostFree(g_box_cache[k].host);
-                (void) hipEventDestroy(g_box_cache[k].uploaded);
+                g_box_graveyard.push_back(g_box_cache[k]);
                 g_box_cache.erase(g_box_cache.begin() + (long) k);
             } else ++k;
         }
@@ -1795,16 +1804,26 @@ int tile_pass_a_plan_create(TilePassAPlan** out, const TileLaunchBox* boxes, int
     if (total < 0) return SOBFU_E_BADARG;
     auto* p = new TilePassAPlan();
     p->groups = total; p->X = X; p->Y = Y; p->Z = Z;
-    int rc = total > 0 ? device_boxes(L, &p->d_boxes, nullptr) : 0;  // plan time (handle creation), not a launch path ...
-    if (rc == 0 && total > 0) rc = (int) hipStreamSynchronize(nullptr);  // ... so the list is simply there before any stream launches with it
-    if (rc != 0) {
+    // a plan OWNS its device copy (the cache above may drop its entries; a plan lives as long as its handle): plan time is handle
+    // creation, not a launch path, so a blocking copy is fine -- the list is simply there before any stream launches with it
+    hipError_t e = hipSuccess;
+    if (total > 0) {
+        e = hipMalloc((void**) &p->d_boxes, sizeof L);
+        if (e == hipSuccess) e = hipMemcpy(p->d_boxes, &L, sizeof L, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        if (p->d_boxes) (void) hipFree(p->d_boxes);
         delete p;
-        return rc;
+        return (int) e;
     }
     *out = p;
     return 0;
 }
-void tile_pass_a_plan_destroy(TilePassAPlan* p) { delete p; }
+void tile_pass_a_plan_destroy(TilePassAPlan* p) {
+    if (p == nullptr) return;
+    if (p->d_boxes) (void) hipFree(p->d_boxes);  // (hipFree waits for the device: no launch is still reading the list)
+    delete p;
+}
 int launch_tile_pass_a_plan(const TilePassAPlan* p, const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, TileSync* sync,
                             uint32_t seq, int wait, const uint32_t* row, uint32_t row_index, hipStream_t stream) {
     return launch_tile_boxes(p->d_boxes, p->groups, pnp, pg, psi, nU, w_reg, p->X, p->Y, p->Z, sync, seq, wait, row, row_index, stream, true);

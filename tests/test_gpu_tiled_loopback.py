@@ -708,3 +708,39 @@ def test_config4_256_cubed_on_2x2x2_tiles_direct_transport():
         assert np.array_equal(np.asarray(hist, np.float32).view(np.uint32), np.asarray(hist_r, np.float32).view(np.uint32))
     assert np.array_equal(psi_t[..., :3].view(np.uint32), psi_r.cpu().numpy()[..., :3].view(np.uint32))
     assert np.array_equal(pnp_t.view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
+
+
+def test_box_list_cache_turnover_leaves_live_handles_alone():
+    """A process that keeps creating tile handles keeps creating box lists; the library's cache of their device copies is bounded
+    (256 per device) and retires its entries when full.  A handle that was created BEFORE the turnover -- its planned pass-A launches
+    own their lists -- must compute the same bits after it, and so must handles created during it (found in round 5: the bound first
+    freed lists that live plans still pointed to; the full GPU suite, > 256 handles in one process, caught it once in four runs)."""
+    import torch
+
+    from sobfu_amd import ops, tiled
+
+    dims = (40, 24, 36)
+    rng = np.random.default_rng(3)
+    X, Y, Z = dims
+    pg = torch.from_numpy(np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)).cuda()
+    pn = torch.from_numpy(np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)).cuda()
+
+    def run(sv):
+        L = sv.layout
+        pg_l, pnp_l, psi_l = L.take(pg).clone().contiguous(), sv.new_local(2), sv.identity_psi()
+        sv.iterate(pg_l, pn, pnp_l, psi_l, 3)
+        torch.cuda.synchronize()
+        return psi_l.clone(), pnp_l.clone()
+
+    old = tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(8, 7), grid=(2, 2, 2))  # planned launches (push boxes into its send buffer)
+    one = tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, dry=(1, 0), grid=(1, 1, 1))  # a world of one: the cached (un-planned) path
+    want_old, want_one = run(old), run(one)
+    for i in range(300):  # 300 distinct lists through the cache (a world of one looks its list up at every launch)
+        sv = tiled.NativeTiledSolver((8 + i % 150, 8 + i // 150, 8), alpha=0.05, w_reg=0.4, dry=(1, 0), grid=(1, 1, 1))
+        L = sv.layout
+        sv.iterate(sv.new_local(2), torch.zeros((8, 8 + i // 150, 8 + i % 150, 2), device="cuda"), sv.new_local(2), sv.identity_psi(), 1)
+        sv.close()
+    for sv, want in ((old, want_old), (one, want_one)):
+        got = run(sv)
+        assert torch.equal(got[0].view(torch.int32), want[0].view(torch.int32)) and torch.equal(got[1].view(torch.int32), want[1].view(torch.int32))
+        sv.close()
