@@ -1883,6 +1883,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
             if (resident && pipe) SOBFU_LAUNCH_BX(true, 0, 0, true);
             else if (resident) SOBFU_LAUNCH_BX(true, 0, 0, false);
             else if (pipe) SOBFU_LAUNCH_BX(true, 0, SOBFU_NT, true);
+            else if (ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, true, true, 0, SOBFU_NT, false, SOBFU_NT_BUF != 0>), grid, block, 0, stream, a);
             else SOBFU_LAUNCH_BX(true, 0, SOBFU_NT, false);
         }
         else if (compact) SOBFU_LAUNCH_B(false, true, true);
@@ -1899,6 +1900,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
             else if (resident && pipe) SOBFU_LAUNCH_BX(false, 0, 0, true);
             else if (resident) SOBFU_LAUNCH_BX(false, 0, 0, false);
             else if (pipe) SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, true);
+            else if (ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, 0, SOBFU_NT, false, SOBFU_NT_BUF != 0>), grid, block, 0, stream, a);
             else SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, false);
         }
         else if (compact) SOBFU_LAUNCH_B(false, true, false);

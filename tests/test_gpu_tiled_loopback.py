@@ -744,3 +744,33 @@ def test_box_list_cache_turnover_leaves_live_handles_alone():
         got = run(sv)
         assert torch.equal(got[0].view(torch.int32), want[0].view(torch.int32)) and torch.equal(got[1].view(torch.int32), want[1].view(torch.int32))
         sv.close()
+
+
+@pytest.mark.parametrize("dims,grid", [((40, 24, 36), (2, 2, 2)), ((70, 33, 23), (2, 1, 1)), ((40, 24, 36), (1, 1, 2))])
+def test_packed_transport_on_tiles_beyond_the_cache(dims, grid, monkeypatch):
+    """The RCCL / callback transports on tiles that do NOT fit the Infinity Cache (N = 2 and N = 4 of the 256^3 split): the plain march with
+    streaming hints -- since round 5 the instantiation whose psi load / store carry the hint for real (buffer instructions, NTBUF), with
+    thin boxes in the launch -- and the z faces in place.  Forced on small grids with SOBFU_CACHE_CELLS=0; bit for bit against the
+    single-GPU solve."""
+    import torch
+
+    import oracle
+    from sobfu_amd import ops
+
+    rng = np.random.default_rng(29)
+    X, Y, Z = dims
+    pg = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    pn = np.stack([rng.uniform(-1, 1, (Z, Y, X)), rng.integers(0, 3, (Z, Y, X))], -1).astype(np.float32)
+    psi0 = oracle.new_field(dims)
+    oracle.init_identity(psi0)
+    psi0[..., :3] += rng.uniform(-0.7, 0.7, psi0[..., :3].shape).astype(np.float32)
+    sv = ops.Solver(dims, max_iter=6, alpha=0.05, w_reg=0.4, max_update_norm=1e-10)
+    psi, pnp = torch.from_numpy(psi0.copy()).cuda(), ops.new_volume(dims)
+    rep, hist = sv.iterate(torch.from_numpy(pg).cuda(), torch.from_numpy(pn).cuda(), pnp, psi, 6)
+    sv.close()
+    monkeypatch.setenv("SOBFU_CACHE_CELLS", "0")
+    out, (psi_t, pnp_t) = run_world(dims, grid, psi0, pg, pn, 6, 1e-10)
+    for done, h, _, _ in out:
+        assert done == rep.iterations and np.array_equal(np.asarray(h, np.float32).view(np.uint32), np.asarray(hist, np.float32).view(np.uint32))
+    assert np.array_equal(psi_t[..., :3].view(np.uint32), psi.cpu().numpy()[..., :3].view(np.uint32))
+    assert np.array_equal(pnp_t.view(np.uint32), pnp.cpu().numpy().view(np.uint32))
