@@ -588,11 +588,11 @@ def main():
                          "every harvest step behind them (diagnostics, other tile grids, frames on tiles, topology; at N = 1 the PMC traffic "
                          "passes, the CPU baseline, the per-frame pipeline) runs only while the budget leaves room for it and is listed under "
                          "`skipped` otherwise; a run still busy 25 s past its budget prints the core line it already holds and exits.  "
-                         "Default: 540 s at N > 1, none at N = 1; 0 = none")
+                         "Default: 300 s at N > 1 (a healthy 8-GPU run takes about two minutes), none at N = 1; 0 = none")
     args = ap.parse_args()
     os.environ.setdefault("SOBFU_BENCH_T0", repr(time.time()))  # (inherited by the ranks of a self-launched run: one clock for all)
     if args.budget_s < 0:
-        args.budget_s = 540.0 if (args.gpus > 1 and not args.replicas) else 0.0
+        args.budget_s = 300.0 if (args.gpus > 1 and not args.replicas) else 0.0
     args.deadline = (float(os.environ["SOBFU_BENCH_T0"]) + args.budget_s) if args.budget_s > 0 else None
     if args.frames < 0:
         args.frames = 5 if (args.gpus == 1 or args.replicas) else 4  # tiles: frame 0 + three timed frames of the tiled pipeline
