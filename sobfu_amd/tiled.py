@@ -305,7 +305,7 @@ def frame_tail(solver, phi_global_local, phi_global_psi_inv_local, psi_local, ps
     L = solver.layout
     lib, st = _lib.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if halo is None and gather is None and L.world > 1:
-        halo = solver.halo_comm()
+        halo = solver.halo_comm() if hasattr(solver, "halo_comm") else DistHalo(L, getattr(solver, "group", None))
     gather = gather or solver.gather_owned
     I6 = C.c_int * 6
     own = I6(*L.own_box())
