@@ -898,6 +898,9 @@ inline bool read_params_ini(const std::string& path, Params& p, std::map<std::st
 // SobFusion (include/sobfu/sob_fusion.hpp, src/sobfu/sob_fusion.cpp:71-145) -- per-frame driver: bilateral filter ->
 // depth truncation -> dists; frame 0 builds phi_global and allocates everything; frame n builds phi_n, fuses it
 // directly while n < START_FRAME, otherwise estimates psi (warm-started) and fuses phi_n o psi.
+// A maintainer who keeps a SobFusion of their own (the reference's src/sobfu/sob_fusion.cpp with its PCL mesh getters) over the shells
+// below defines SOBFU_AMD_NO_SOBFUSION before including this header: the class then stays theirs.
+#ifndef SOBFU_AMD_NO_SOBFUSION
 class SobFusion {
 public:
     explicit SobFusion(const Params& p) : frame_counter_(0), params(p), camera_pose_(cv::Affine3f::Identity()) {
@@ -964,3 +967,4 @@ private:
     kfusion::cuda::Depth filtered_;
     kfusion::cuda::Dists dists_;
 };
+#endif  // SOBFU_AMD_NO_SOBFUSION

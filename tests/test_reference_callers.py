@@ -44,3 +44,15 @@ def test_sob_fusion_tu_is_replaced_not_wrapped():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "replaced" in text.lower() and "sob_fusion.cpp" in text
     assert "compile unchanged" in text.lower()
+
+
+def test_sobfusion_shell_can_be_switched_off(tmp_path):
+    """SOBFU_AMD_NO_SOBFUSION: a caller that brings its own SobFusion class (the reference's sob_fusion.cpp with PCL) over the lower shells"""
+    src = tmp_path / "own_sobfusion.cpp"
+    src.write_text("#define SOBFU_AMD_NO_SOBFUSION\n#include <sobfu/solver.hpp>\n#include <kfusion/cuda/tsdf_volume.hpp>\n"
+                   "class SobFusion { public: std::shared_ptr<sobfu::cuda::Solver> solver; cv::Ptr<kfusion::cuda::TsdfVolume> phi_global; };\n"
+                   "int main() { SobFusion f; return f.solver ? 1 : 0; }\n")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    r = subprocess.run(["g++", "-std=c++14", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{os.path.join(ROOT, 'include')}", "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
