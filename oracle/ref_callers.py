@@ -2,7 +2,10 @@
 from where they lie under /root/reference, against this repo's include/ (the header-only C++ shells over the C ABI) and links them with
 libsobfu_hip.so -> oracle/_ref/reference_gtests.
 
-TEST INFRASTRUCTURE ONLY.  No reference source is copied: the compiler reads the four files in place, only the binary lands in
+TEST INFRASTRUCTURE ONLY, and NOT a reference build in the sense of an oracle: no line of the reference's IMPLEMENTATION is compiled here
+(its .cu / .cpp sources of the path are exactly what this repo replaces) -- only its test drivers, against this repo's library.  The
+binary therefore pins nothing about the oracle; the oracle's pin status (oracle/sobfu_oracle.c header) is unchanged.
+No reference source is copied: the compiler reads the four files in place, only the binary lands in
 oracle/_ref/ (git-ignored, but it travels to the GPU box with the snapshot, where /root/reference does not exist).  The image has no
 GoogleTest; tests/cpp/gtest_stub/gtest/gtest.h supplies the five names those files use (TEST_F, ASSERT_NEAR, ::testing::Test,
 InitGoogleTest, RUN_ALL_TESTS).  What this is evidence for: the drop-in claim of INTEGRATION.md -- the reference's callers of the path
