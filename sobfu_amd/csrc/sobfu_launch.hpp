@@ -83,6 +83,8 @@ int launch_apply_tsdf_only(const float* phi1, float* out1, const float* psi3, in
                            int phi_Y = 0);
 // halo messages of a 3-D tile: n boxes (6 ints each: x0, x1, y0, y1, z0, z1) of a 12-byte field <-> consecutive buffer segments
 int launch_msg_copy(bool pack, float* field3, float* buf, int Lx, int Ly, int Lz, const int* boxes, int n, hipStream_t stream);
+// the same scatter by a precomputed table (device memory): cell c of buf -> cell d_table[c] of the field
+int launch_msg_scatter_table(float* field3, const float* buf, const uint32_t* d_table, unsigned n_cells, hipStream_t stream);
 // whole-volume enter / leave of the compact format in one pass each (solver handle)
 int launch_compact_enter(const float* psi4, const float* pg2, const float* pn2, float* c_psi, float* c_g, float* c_n, float* c_f, int X, int Y,
                          int Z, hipStream_t stream);

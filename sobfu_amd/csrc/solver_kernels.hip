@@ -1505,6 +1505,16 @@ __global__ void __launch_bounds__(256) msg_copy_kernel(float* __restrict__ field
     else stv<true>(field3, i, ldv<true>(buf, c));
 }
 
+// The scatter of an exchange's packed messages by a precomputed TABLE: cell c of the receive buffer goes to cell table[c] of the field.
+// The loop issues the same scatter every iteration, so the message scan, the three integer divisions per cell and the 500-byte argument
+// block of msg_copy_kernel are paid once, at handle creation: what is left is two independent loads and a store per cell.
+__global__ void __launch_bounds__(256) msg_scatter_table_kernel(float* __restrict__ field3, const float* __restrict__ buf, const uint32_t* __restrict__ table,
+                                                                unsigned n) {
+    const unsigned c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n) return;
+    stv<true>(field3, table[c], ldv<true>(buf, c));
+}
+
 }  // namespace
 
 // Tile configuration of the fused passes (see DESIGN.md "Kernel tuning").
@@ -1970,6 +1980,11 @@ int launch_msg_copy(bool pack, float* field3, float* buf, int Lx, int Ly, int Lz
     const dim3 grid((total + 255u) / 256u), block(256);
     if (pack) hipLaunchKernelGGL(msg_copy_kernel<true>, grid, block, 0, stream, field3, buf, Dims{Lx, Ly, Lz}, m);
     else hipLaunchKernelGGL(msg_copy_kernel<false>, grid, block, 0, stream, field3, buf, Dims{Lx, Ly, Lz}, m);
+    return (int) hipGetLastError();
+}
+int launch_msg_scatter_table(float* field3, const float* buf, const uint32_t* d_table, unsigned n_cells, hipStream_t stream) {
+    if (n_cells == 0) return 0;
+    hipLaunchKernelGGL(msg_scatter_table_kernel, dim3((n_cells + 255u) / 256u), dim3(256), 0, stream, field3, buf, d_table, n_cells);
     return (int) hipGetLastError();
 }
 #undef SOBFU_LIN

@@ -266,6 +266,8 @@ struct sobfu_hip_tiled {
     // (zmsgs: offsets into the nabla_U array itself -- 4 whole padded planes out of the owned rim, 4 into the halo)
     int n_packed = 0;
     std::vector<sobfu_hip_tiled_msg> zmsgs;
+    uint32_t* scatter_table = nullptr;  // device: destination cell of every cell of the packed receive buffer (the loop's scatter, precomputed)
+    unsigned scatter_cells = 0;
     // direct transport (sobfu_hip_tiled_connect): push destinations in the peers, signalling state
     bool direct = false, dead = false, first_checked = false, dry_packed = false, force_comm = false;
     int debug_skip = 0;  // timing experiments only (results are wrong): see tiled_step_impl
@@ -437,6 +439,7 @@ int sobfu_hip_tiled_destroy(sobfu_hip_tiled* t) {
     for (hipEvent_t e : t->prof_ev) (void) hipEventDestroy(e);
     if (t->sendbuf) (void) hipFree(t->sendbuf);
     if (t->recvbuf) (void) hipFree(t->recvbuf);
+    if (t->scatter_table) (void) hipFree(t->scatter_table);
     if (t->ev_bnd) (void) hipEventDestroy(t->ev_bnd);
     if (t->ev_xchg) (void) hipEventDestroy(t->ev_xchg);
     for (hipEvent_t e : {t->ev_red[0], t->ev_red[1], t->ev_row, t->ev_first})
@@ -506,6 +509,18 @@ int sobfu_hip_tiled_create3(sobfu_hip_tiled** out, int X, int Y, int Z, int Px, 
         if (off > 0) {
             rc = (int) hipMalloc((void**) &t->sendbuf, off * sizeof(float));
             if (rc == 0) rc = (int) hipMalloc((void**) &t->recvbuf, off * sizeof(float));
+        }
+        if (rc == 0 && !t->slab && t->n_packed > 0) {  // where every cell of the packed receive buffer goes (x fastest inside a message box)
+            std::vector<uint32_t> tab;
+            for (int i = 0; i < t->n_packed; ++i) {
+                const int* b = t->rboxes.data() + 6 * i;
+                for (int z = b[4]; z < b[5]; ++z)
+                    for (int y = b[2]; y < b[3]; ++y)
+                        for (int x = b[0]; x < b[1]; ++x) tab.push_back((uint32_t) ((size_t) x + (size_t) t->L[0] * ((size_t) y + (size_t) t->L[1] * (size_t) z)));
+            }
+            t->scatter_cells = (unsigned) tab.size();
+            rc = (int) hipMalloc((void**) &t->scatter_table, tab.size() * sizeof(uint32_t));
+            if (rc == 0) rc = (int) hipMemcpy(t->scatter_table, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
     }
     if (rc == 0) {
@@ -877,6 +892,7 @@ static int exchange_packed(sobfu_hip_tiled* t, float* field3, hipStream_t stream
     const int n = t->n_packed, nz = (int) t->zmsgs.size();
     if (n + nz == 0) return 0;
     SOBFU_TRY(transfer(t, t->sendbuf, t->recvbuf, t->msgs.data(), n, stream, field3, field3, t->zmsgs.data(), nz));
+    if (t->scatter_table) return sobfu_hip::launch_msg_scatter_table(field3, t->recvbuf, t->scatter_table, t->scatter_cells, stream);
     return sobfu_hip::launch_msg_copy(false, field3, t->recvbuf, t->L[0], t->L[1], t->L[2], t->rboxes.data(), n, stream);
 }
 
