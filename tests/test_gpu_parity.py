@@ -847,3 +847,61 @@ def test_session_begin_step_end(ops, oracle, dims, compact):
         sv.end()
     sv.close()
     sv2.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the windowed per-frame tail of a tile (sobfu_hip_tile3_*_window): same bits as the whole-volume kernels when the window is wide
+# enough, and a raised flag -- not a wild read -- when it is not
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims,grid,rank", [((40, 24, 36), (2, 2, 2), 5), ((33, 17, 16), (1, 2, 2), 0), ((70, 33, 23), (2, 1, 1), 1)])
+def test_window_tail_kernels_and_their_guard(ops, oracle, dims, grid, rank):
+    import ctypes as C
+
+    from sobfu_amd import _lib, tiled
+
+    lib = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    I6 = C.c_int * 6
+    amp = 2.6
+    psi = warped_identity(oracle, dims, 401, amp)
+    pg = rand_volume(dims, 402)
+    psi_d, pg_d = dev(psi), dev(pg)
+    L = tiled.TileLayout(dims, grid, rank)
+    own = I6(*L.own_box())
+    # reference: the whole-volume tile kernels
+    inv_ref, pgi_ref = torch.zeros(L.local_shape(4), device="cuda"), torch.zeros(L.local_shape(2), device="cuda")
+    _lib.check(lib.sobfu_hip_tile3_init_identity(C.c_void_p(inv_ref.data_ptr()), *L.L, *L.base, st), "id")
+    _lib.check(lib.sobfu_hip_tile3_estimate_inverse(C.c_void_p(psi_d.data_ptr()), *dims, C.c_void_p(inv_ref.data_ptr()), *L.L, *L.base, C.c_int(48), st), "inv")
+    _lib.check(lib.sobfu_hip_tile3_apply(C.c_void_p(pg_d.data_ptr()), *dims, C.c_void_p(pgi_ref.data_ptr()), C.c_void_p(inv_ref.data_ptr()), *L.L, st), "apply")
+    # the reach the tail measures for itself
+    bits = torch.zeros(1, dtype=torch.int32, device="cuda")
+    psi_l = L.take(psi_d).clone().contiguous()
+    _lib.check(lib.sobfu_hip_tile3_max_displacement(C.c_void_p(psi_l.data_ptr()), *L.L, *L.base, own, C.c_void_p(bits.data_ptr()), st), "maxdisp")
+    r = float(np.array([bits.item()], np.int32).view(np.float32)[0])
+    want_r = float(np.abs(L.owned_global(torch.from_numpy(psi))[..., :3].numpy()
+                          - np.stack(np.meshgrid(np.arange(L.g0[2], L.g1[2]), np.arange(L.g0[1], L.g1[1]), np.arange(L.g0[0], L.g1[0]), indexing="ij")[::-1], -1)).max())
+    assert r == want_r and amp * 0.9 < r <= amp
+
+    def run(w):
+        wb = L.window_box(w)
+        cut = lambda t: t[wb[4]:wb[5], wb[2]:wb[3], wb[0]:wb[1]].contiguous()  # noqa: E731
+        psi_w, pg_w = cut(psi_d), cut(pg_d)
+        win = I6(wb[1] - wb[0], wb[3] - wb[2], wb[5] - wb[4], wb[0], wb[2], wb[4])
+        inv, pgi = torch.full(L.local_shape(4), -7.0, device="cuda"), torch.full(L.local_shape(2), -7.0, device="cuda")
+        viol = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(lib.sobfu_hip_tile3_estimate_inverse_window(C.c_void_p(psi_w.data_ptr()), win, *dims, C.c_void_p(inv.data_ptr()), *L.L, *L.base, own,
+                                                               C.c_int(48), C.c_void_p(viol.data_ptr()), st), "inv_w")
+        _lib.check(lib.sobfu_hip_tile3_apply_window(C.c_void_p(pg_w.data_ptr()), win, *dims, C.c_void_p(pgi.data_ptr()), C.c_void_p(inv.data_ptr()), *L.L, own,
+                                                    C.c_void_p(viol.data_ptr()), st), "apply_w")
+        return inv, pgi, int(viol.item())
+
+    inv, pgi, viol = run(int(np.ceil(r)) + 2)
+    assert viol == 0
+    assert torch.equal(L.owned(inv)[..., :3].contiguous().view(torch.int32), L.owned(inv_ref)[..., :3].contiguous().view(torch.int32))
+    assert torch.equal(L.owned(pgi).contiguous().view(torch.int32), L.owned(pgi_ref).contiguous().view(torch.int32))
+    outside = torch.ones(L.local_shape(), dtype=torch.bool, device="cuda")
+    L.owned(outside)[...] = False
+    assert bool((inv[outside] == -7.0).all()) and bool((pgi[outside] == -7.0).all())  # cells outside the box are left alone
+    if min(L.lo3 + L.hi3) >= 0 and any(L.lo3) or any(L.hi3):
+        _, _, viol = run(1)  # a window narrower than the reach: samples leave it -> the flag, never a read outside the array
+        assert viol == 1
