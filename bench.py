@@ -654,6 +654,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
             print(json.dumps(out), flush=True)
         os._exit(3 if mismatch else 0)
+    if os.environ.get("SOBFU_BENCH_TEST_HANG") == "2" and rank == world - 1 and world > 1:  # test hook: a rank that never reaches the final barrier
+        time.sleep(3600)
     ranks.close()
     if rank == 0:  # after the process group is gone, and after flushing C stdio (RCCL's version banner sits in libc's stdout
         # buffer until exit when stdout is a pipe), so that the JSON is the LAST line on stdout

@@ -653,6 +653,8 @@ def bench_tiled(args, P, ranks, timed_regions):
         def work():
             try:
                 torch.cuda.set_device(dev_index)
+                if os.environ.get("SOBFU_BENCH_TEST_HANG") == "1":  # test hook: a harvest step that never returns (a sick node)
+                    time.sleep(3600)
                 if want_step("topology", 35) and rank == 0:
                     box["topology"] = topology_snapshot(ranks)
                 if "direct" in good and world > 1 and want_step("direct_diag", 30):

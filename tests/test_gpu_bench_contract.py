@@ -172,3 +172,25 @@ def test_single_gpu_budget_skips_named_steps():
     d = run_bench("--gpus", "1", "--steps", "10", "--warmup", "4", "--dim", "64", "--repeats", "3", "--budget-s", "1")
     assert d["value"] > 0 and d["roofline"]["traffic"] is None and "budget" in d["roofline"]["traffic_how"]
     assert set(d["skipped"]) == {"roofline.traffic", "cpu_baseline", "per_frame"} and "cpu_baseline" not in d and "per_frame" not in d
+
+
+@pytest.mark.parametrize("where", ["harvest", "final barrier"])
+def test_a_hang_behind_the_timed_legs_never_costs_the_line(where):
+    """the safety nets of the one real multi-GPU run (test hook SOBFU_BENCH_TEST_HANG).  "harvest": a harvest step that never returns --
+    the harvest thread's join is bounded by the budget, the run goes on without it and prints the FULL line, saying what is missing.
+    "final barrier": a rank that never reaches the barrier in front of the line (a sick node) -- nothing in the normal path can end
+    that; 25 s past the budget (30 s behind the core) every rank's watchdog ends the run, rank 0 having printed the core line it kept when
+    the timed legs finished.  Either way: exactly one valid JSON line, exit code 0."""
+    import time
+
+    t0 = time.time()
+    d = run_bench("--gpus", "2", "--steps", "10", "--warmup", "4", "--dim", "64", "--repeats", "3", "--no-cpu-baseline", "--budget-s", "20",
+                  env={"SOBFU_BENCH_SHARE_GPU": "1", "SOBFU_BENCH_TEST_HANG": "1" if where == "harvest" else "2"})
+    took = time.time() - t0
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["tiled_parity_vs_single_gpu"] == "bit-exact" and set(d["legs"]) == {"direct", "rccl"}
+    assert "per_frame" not in d
+    if where == "harvest":
+        assert any("still running" in x for x in d["skipped"]), d["skipped"]
+    else:
+        assert any("everything after the timed legs" in x for x in d["skipped"]), d["skipped"]  # the early copy, printed by the watchdog
+        assert 40 < took < 200, took  # budget 20 s + 25 s, or 30 s behind the core, + start-up
