@@ -1,0 +1,493 @@
+"""The oracle (CPU suite) and the HIP path (GPU suite, through the C ABI) against tests/golden/ref_*.npz: arrays computed by the
+reference's OWN source lines under the host emulation of tools/ref_emulation/ (recipe: tests/golden/make_reference_fixtures.py;
+regenerates byte-identically in the build container).  Everything is compared bit for bit, except where a device libm enters
+(powf in init_sphere, expf in the bilateral filter): tolerance stated at the assert.
+
+This is shim evidence -- stand-in headers, so by the task's rules it does not pin the oracle -- but it is
+what ties oracle/sobfu_oracle.c and the kernels to solver.cu / vector_fields.cu / reductor.cu / tsdf_volume.cu / imgproc.cu /
+sob_fusion.cpp / marching_cubes.cu executing, array for array.  The fixtures replaced the oracle-generated self-goldens that
+tests/test_golden.py used to hold."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import fixture_inputs as FI  # noqa: E402
+from sobfu_amd.synthetic import render_sphere_depth  # noqa: E402
+
+G = os.path.join(HERE, "golden")
+KERNEL_DIMS = [(17, 9, 5), (20, 12, 9), (40, 24, 20), (32, 32, 32)]
+SOLVER_NAMES = ["ref_solver_17x9x5", "ref_solver_20x12x9", "ref_solver_40x24x20", "ref_solver_32x32x32", "ref_solver_break_20x12x9"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+def load(name):
+    f = np.load(os.path.join(G, name + ".npz"))
+    d = {k: f[k] for k in f.files}
+    for k in ("log", "param_names"):
+        if k in d:
+            d[k] = bytes(d[k]).decode()
+    if "param_names" in d:
+        d["P"] = dict(zip(d["param_names"].split(","), d["params"]))
+    return d
+
+
+def check(f, key, value):
+    """full array when the fixture holds it, sha256 otherwise"""
+    value = value.cpu().numpy() if hasattr(value, "cpu") else np.asarray(value)
+    if key in f:
+        assert same(value, f[key]), key
+    else:
+        assert np.array_equal(FI.digest(value), f["sha256_" + key]), key
+
+
+def g6(x):
+    return "%.6g" % float(x)  # std::cout's default float formatting
+
+
+def expected_log(trace, dims, max_iter, w_reg, max_update_norm, verbosity):
+    """The lines sobfu::device::estimate_psi prints (solver.cu:115-117,132-142,173-190), from per-iteration (e_data, e_reg, max, idx)."""
+    X, Y, _ = dims
+    out = []
+    w = np.float32(w_reg)
+    for it, (ed, er, mx, idx) in enumerate(trace, 1):
+        if it == 1 or it % 50 == 0:
+            out.append("iter. no. %d" % it)
+        report = verbosity == 2 or (verbosity == 1 and (it == 1 or it % 50 == 0 or it == max_iter))
+        if report:
+            e = np.float32(np.float32(ed) + np.float32(w * np.float32(er)))
+            out.append("data energy + w_reg * reg energy = %s + %s * %s = %s" % (g6(ed), g6(w), g6(er), g6(e)))
+            ix = int(np.float32(idx) / np.float32(X * Y))
+            iy = int(np.float32(np.float32(idx) - np.float32(ix * X * Y)) / np.float32(X))
+            iz = int(np.float32(idx) - np.float32(X * (iy + Y * ix)))
+            out.append("max. update norm %s at voxel (%d, %d, %d)" % (g6(mx), iz, iy, ix))
+        if np.float32(mx) <= np.float32(max_update_norm):
+            out.append("SOLVER CONVERGED AFTER %d ITERATIONS" % it)
+            break
+        if it == max_iter:
+            out.append("SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING")
+    return "\n".join(out) + "\n"
+
+
+def kernel_fixture(dims):
+    f = load("ref_kernels_%dx%dx%d" % dims)
+    seed, amp, w_reg, alpha, max_weight = f["params"]
+    ins = FI.kernel_inputs(dims, int(seed), amp)
+    for k, v in ins.items():  # the generator must still produce what the emulation consumed
+        check(f, "in_" + k, v)
+    return f, ins, float(w_reg), float(alpha), float(max_weight)
+
+
+def triangle_set(v, n):
+    """the reference appends occupied voxels by atomicAdd, so only the SET of (vertices, normal) triangles is defined"""
+    a = np.concatenate([np.asarray(v).reshape(-1, 3, 4), np.asarray(n).reshape(-1, 3, 4)], axis=2).reshape(-1, 24)
+    return bits(a[np.lexsort(bits(a).T[::-1])])
+
+
+def test_fixture_inventory():
+    names = sorted(n[:-4] for n in os.listdir(G) if n.startswith("ref_") and n.endswith(".npz"))
+    assert names == sorted(["ref_kernels_%dx%dx%d" % d for d in KERNEL_DIMS] + SOLVER_NAMES +
+                           ["ref_solver_test_64", "ref_tsdf_30x24x18", "ref_depth_32x32x32", "ref_frames_32x32x32", "ref_frames_gated_32x32x32",
+                            "ref_config1_64", "ref_mc_14x11x9"])
+    assert sum(os.path.getsize(os.path.join(G, n + ".npz")) for n in names) < 4 << 20  # small fixtures
+
+
+# ------------------------------------------------------------------------------------------------- oracle (CPU)
+@pytest.mark.parametrize("dims", KERNEL_DIMS)
+def test_oracle_launchers(oracle, dims):
+    O = oracle
+    f, ins, w_reg, alpha, max_weight = kernel_fixture(dims)
+    X, Y, Z = dims
+    g, L, nU, nUS, upd, inv = (O.new_field(dims) for _ in range(6))
+    O.tsdf_gradient(ins["phi_n_psi"], g)
+    O.laplacian(ins["psi"], L)
+    check(f, "grad", g), check(f, "laplacian", L)
+    J1 = None
+    for mode in (0, 1):
+        J1 = np.zeros((Z, Y, X, 4, 4), np.float32)
+        O.jacobian(ins["psi"], J1, mode)
+        check(f, "jacobian%d" % mode, J1)
+    O.potential_gradient(ins["phi_n_psi"], ins["phi_global"], g, L, nU, w_reg)
+    check(f, "nabla_U", nU)
+    for fn, key in ((O.convolution_rows, "conv_rows"), (O.convolution_columns, "conv_cols"), (O.convolution_depth, "conv_depth")):
+        fn(nUS, nU, ins["taps"])
+        check(f, key, nUS)
+    psi = ins["psi"].copy()
+    O.update_psi(psi, nUS, upd, alpha)
+    check(f, "psi_new", psi), check(f, "updates", upd)
+    warped = O.new_volume(dims)
+    O.apply(ins["phi_n_psi"], warped, psi)
+    check(f, "warped", warped)
+    O.init_identity(inv)
+    O.estimate_inverse(psi, inv, 48)
+    check(f, "psi_inv", inv)
+    fused = ins["fuse_in"].copy()
+    O.integrate_fuse(fused, warped, max_weight)
+    check(f, "fused", fused)
+    m = O.max_update_norm(upd)
+    mine = np.array([O.data_energy(ins["phi_global"], ins["phi_n_psi"]), O.reg_energy_sobolev(J1), m[0], m[1], *O.reduce_config(X * Y * Z)], np.float32)
+    assert same(mine, f["scalars"]), (mine, f["scalars"])
+
+
+@pytest.mark.parametrize("name", SOLVER_NAMES)
+def test_oracle_estimate_psi(oracle, name):
+    f = load(name)
+    mi, alpha, w_reg, s, lam, mun, verb = f["params"]
+    dims = f["in_psi0"].shape[2::-1]
+    psi = f["in_psi0"].copy()
+    r = oracle.estimate_psi(f["in_phi_global"], f["in_phi_n"], psi, max_iter=int(mi), alpha=alpha, w_reg=w_reg, s=int(s), lam=lam, max_update_norm=mun,
+                            verbosity=2)
+    for k, v in (("psi", psi), ("phi_n_psi", r["phi_n_psi"]), ("psi_inv", r["psi_inv"]), ("phi_global_psi_inv", r["phi_global_psi_inv"])):
+        assert same(v, f[k]), (name, k)
+    assert expected_log(r["trace"], dims, int(mi), w_reg, mun, int(verb)) == f["log"]  # every line the reference printed
+    if "psi_after" in f:  # the state after each iteration k = the reference stopped at max_iter = k
+        for k in range(1, int(mi) + 1):
+            p = f["in_psi0"].copy()
+            oracle.estimate_psi(f["in_phi_global"], f["in_phi_n"], p, max_iter=k, alpha=alpha, w_reg=w_reg, s=int(s), lam=lam, max_update_norm=mun)
+            assert same(p, f["psi_after"][k - 1]), k
+    if name == "ref_solver_break_20x12x9":
+        assert r["iters"] < int(mi) and f["log"].endswith("SOLVER CONVERGED AFTER %d ITERATIONS\n" % r["iters"])
+
+
+def test_oracle_solver_test_setup_64(oracle):
+    """the reference's own test/solver_test.cpp:109-132 set-up (two initSphere volumes, identity start), 10 iterations at verbosity 2"""
+    f = load("ref_solver_test_64")
+    P = f["P"]
+    dims = (64, 64, 64)
+    vs = (np.full(3, P["size_x"], np.float32) / np.float32(64)).astype(np.float32)
+    trunc, eta = np.float32(P["trunc_vox"]) * vs[0], np.float32(P["eta_vox"]) * vs[0]
+    pg, pn = oracle.new_volume(dims), oracle.new_volume(dims)
+    oracle.init_sphere(pg, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    oracle.init_sphere(pn, vs, trunc, eta, (P["sphere2_cx"], P["sphere2_cy"], P["sphere2_cz"]), P["sphere_r"])
+    check(f, "phi_global", pg), check(f, "phi_n", pn)
+    psi = FI.identity(dims)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=3, alpha=P["alpha"], w_reg=P["w_reg"])
+    check(f, "psi_after3", psi)
+    psi = FI.identity(dims)
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=10, alpha=P["alpha"], w_reg=P["w_reg"], verbosity=2)
+    for k, v in (("psi", psi), ("phi_n_psi", r["phi_n_psi"]), ("psi_inv", r["psi_inv"]), ("phi_global_psi_inv", r["phi_global_psi_inv"])):
+        check(f, k, v)
+    assert expected_log(r["trace"], dims, 10, P["w_reg"], -1.0, 2) == f["log"]
+    assert same(psi[32, 32, 30], f["probe_psi_30_32_32"][1])
+
+
+def _tsdf_params(P, dims):
+    size = np.array([P["size_x"], P["size_y"], P["size_z"]], np.float32)
+    vs = (size / np.array(dims, np.float32)).astype(np.float32)  # Params::voxel_sizes
+    return size, vs, np.float32(P["trunc_vox"]) * vs[0], np.float32(P["eta_vox"]) * vs[0]
+
+
+def test_oracle_tsdf_builders(oracle):
+    f = load("ref_tsdf_30x24x18")
+    P, dims = f["P"], (30, 24, 18)
+    _, vs, trunc, eta = _tsdf_params(P, dims)
+    v = oracle.new_volume(dims)
+    oracle.init_sphere(v, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    assert same(v, f["sphere"])
+    for fn, key, arg in ((oracle.init_box, "box", (P["box_x"], P["box_y"], P["box_z"])), (oracle.init_ellipsoid, "ellipsoid", (P["ell_x"], P["ell_y"], P["ell_z"])),
+                         (oracle.init_plane, "plane", P["plane_z"]), (oracle.init_torus, "torus", (P["torus_R"], P["torus_r"]))):
+        v = oracle.new_volume(dims)
+        fn(v, vs, trunc, arg)
+        assert same(v, f[key]), key
+
+
+def _pose(P, size):
+    return np.eye(3, dtype=np.float32), np.array([-size[0] / np.float32(2), -size[1] / np.float32(2), np.float32(P["t_z"])], np.float32)  # demo.cpp:73-74
+
+
+def test_oracle_depth_steps(oracle):
+    f = load("ref_depth_32x32x32")
+    P, dims = f["P"], (32, 32, 32)
+    size, vs, trunc, eta = _tsdf_params(P, dims)
+    intr = (P["fx"], P["fy"], P["cx"], P["cy"])
+    d = oracle.bilateral(f["in_depth"], int(P["bilateral_ksz"]), P["bilateral_ss"], P["bilateral_sd"])
+    assert np.array_equal(d, f["bilateral"])
+    oracle.truncate_depth(d, P["trunc_depth"])
+    assert np.array_equal(d, f["truncated"]) and (f["truncated"] != f["bilateral"]).sum() >= 20
+    dist = oracle.compute_dists(d, intr)
+    assert same(dist, f["dists"])
+    v = oracle.new_volume(dims)
+    R, t = _pose(P, size)
+    oracle.integrate_depth(dist, v, vs, trunc, eta, R, t, intr)
+    assert same(v, f["volume"]) and (f["volume"][..., 1] > 0).sum() > 1000
+
+
+class OracleFusion:
+    """SobFusion::operator() (sob_fusion.cpp:71-145) over the oracle's functions -- the CPU twin of sobfu_amd.fusion.SobFusion"""
+
+    def __init__(self, O, P):
+        self.O, self.P, self.frame = O, P, 0
+        self.dims = (int(P["X"]), int(P["Y"]), int(P["Z"]))
+        self.size, self.vs, self.trunc, self.eta = _tsdf_params(P, self.dims)
+        self.R, self.t = _pose(P, self.size)
+        self.intr = (P["fx"], P["fy"], P["cx"], P["cy"])
+        self.log = ""
+
+    def __call__(self, depth):
+        O, P = self.O, self.P
+        self.log += "--- FRAME NO. %d ---\n" % self.frame
+        d = O.bilateral(depth, int(P["bilateral_ksz"]), P["bilateral_ss"], P["bilateral_sd"])
+        O.truncate_depth(d, P["trunc_depth"])
+        dist = O.compute_dists(d, self.intr)
+        v = O.new_volume(self.dims)
+        O.integrate_depth(dist, v, self.vs, self.trunc, self.eta, self.R, self.t, self.intr)
+        if self.frame == 0:
+            self.phi_global, self.psi = v, FI.identity(self.dims)
+        else:
+            self.phi_n = v
+            if self.frame < int(P["start_frame"]):
+                O.integrate_fuse(self.phi_global, v, P["max_weight"])
+            else:
+                r = O.estimate_psi(self.phi_global, v, self.psi, max_iter=int(P["max_iter"]), alpha=P["alpha"], w_reg=P["w_reg"], s=int(P["s"]), lam=P["lambda"],
+                                   max_update_norm=P["max_update_norm"], verbosity=2)
+                self.log += expected_log(r["trace"], self.dims, int(P["max_iter"]), P["w_reg"], P["max_update_norm"], int(P["verbosity"]))
+                self.phi_n_psi, self.psi_inv, self.phi_global_psi_inv = r["phi_n_psi"], r["psi_inv"], r["phi_global_psi_inv"]
+                O.integrate_fuse(self.phi_global, self.phi_n_psi, P["max_weight"])
+        self.frame += 1
+
+
+def _frame_inputs(f, n):
+    P = f["P"]
+    intr = (P["fx"], P["fy"], P["cx"], P["cy"])
+    out = []
+    for i in range(n):
+        d = f["in_depth_%d" % i] if "in_depth_%d" % i in f else render_sphere_depth((0.005 * i, 0.0, 0.75), 0.1, intr, rows=int(P["rows"]), cols=int(P["cols"]))
+        check(f, "in_depth_%d" % i, d)
+        out.append(d)
+    return out
+
+
+def _check_frames(f, fusion_factory, host=np.asarray):
+    P = f["P"]
+    n = int(P["frames"])
+    fu = fusion_factory(P)
+    for i, depth in enumerate(_frame_inputs(f, n)):
+        fu(depth)
+        check(f, "phi_global_f%d" % i, host(fu.phi_global))
+        if i > 0:
+            check(f, "phi_n_f%d" % i, host(fu.phi_n))
+        if i >= max(1, int(P["start_frame"])):
+            for k in ("psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv"):
+                check(f, "%s_f%d" % (k, i), host(getattr(fu, k)))
+    return fu
+
+
+@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64"])
+def test_oracle_frame_pipeline(oracle, name):
+    """every volume and field of every frame of SobFusion::operator(), and every line it printed; ref_config1_64 is BASELINE config 1"""
+    f = load(name)
+    fu = _check_frames(f, lambda P: OracleFusion(oracle, P))
+    assert fu.log == f["log"]
+
+
+def test_oracle_marching_cubes(oracle):
+    f = load("ref_mc_14x11x9")
+    P = f["P"]
+    vol = FI.mc_volume((14, 11, 9))
+    assert same(vol, f["in_volume"])
+    size = np.array([P["size_x"], P["size_y"], P["size_z"]], np.float32)
+    R, t = _pose(P, size)
+    v, n = oracle.marching_cubes(vol, tuple(size), R, t)
+    assert f["log"] == "no. of active voxels: %d\n" % oracle.mc_occupied_voxels(vol, 4096)[1]
+    assert len(v) == len(f["vertices"]) == 1164 and np.array_equal(triangle_set(v, n), triangle_set(f["vertices"], f["normals"]))
+
+
+# ------------------------------------------------------------------------------------------------- HIP (GPU box, through the C ABI)
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", KERNEL_DIMS)
+def test_hip_launchers(dims):
+    from sobfu_amd import ops
+
+    f, ins, w_reg, alpha, max_weight = kernel_fixture(dims)
+    g, L, nU, nUS, upd, inv = (ops.new_field(dims) for _ in range(6))
+    vol, pg, psi0 = _dev(ins["phi_n_psi"]), _dev(ins["phi_global"]), _dev(ins["psi"])
+    ops.tsdf_gradient(vol, g)
+    ops.laplacian(psi0, L)
+    check(f, "grad", g), check(f, "laplacian", L)
+    J = ops.new_jacobian(dims)
+    for mode in (0, 1):
+        ops.jacobian(psi0, J, mode)
+        check(f, "jacobian%d" % mode, J)
+    ops.potential_gradient(vol, pg, g, L, nU, w_reg)
+    check(f, "nabla_U", nU)
+    for fn, key in ((ops.convolution_rows, "conv_rows"), (ops.convolution_columns, "conv_cols"), (ops.convolution_depth, "conv_depth")):
+        fn(nUS, nU, ins["taps"])
+        check(f, key, nUS)
+    psi = psi0.clone()
+    ops.update_psi(psi, nUS, upd, alpha)
+    check(f, "psi_new", psi), check(f, "updates", upd)
+    warped = ops.new_volume(dims)
+    ops.apply(vol, warped, psi)
+    check(f, "warped", warped)
+    ops.init_identity(inv)
+    ops.estimate_inverse(psi, inv, 48)
+    check(f, "psi_inv", inv)
+    fused = _dev(ins["fuse_in"])
+    ops.integrate_fuse(fused, warped, max_weight)
+    check(f, "fused", fused)
+    m = ops.max_update_norm(upd)
+    mine = np.array([ops.data_energy(pg, vol), ops.reg_energy_sobolev(J), m[0], m[1]], np.float32)
+    assert same(mine, f["scalars"][:4]), (mine, f["scalars"])
+    # the fused passes of the iteration loop against the same reference arrays
+    nU2, pnp = ops.new_field(dims), ops.new_volume(dims)
+    ops.fused_potential_gradient(vol, pg, psi0, nU2, w_reg)
+    check(f, "nabla_U", nU2)
+    psi = psi0.clone()
+    mx = ops.fused_smooth_update_apply(nU2, psi, vol, pnp, ins["taps"], alpha)
+    check(f, "psi_new", psi), check(f, "warped", pnp)
+    assert np.float32(mx) == f["scalars"][2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SOLVER_NAMES)
+def test_hip_estimate_psi(name):
+    from sobfu_amd import ops
+
+    f = load(name)
+    mi, alpha, w_reg, s, lam, mun, verb = f["params"]
+    dims = f["in_psi0"].shape[2::-1]
+    for verbosity, compact in ((int(verb), True), (0, True), (0, False), (2, True)):
+        sv = ops.Solver(dims, max_iter=int(mi), alpha=alpha, w_reg=w_reg, s=int(s), lam=lam, max_update_norm=mun, verbosity=verbosity)
+        sv.set_compact(compact)
+        psi, psi_inv, pnp, pgi = _dev(f["in_psi0"]), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+        sv.estimate_psi(_dev(f["in_phi_global"]), pgi, _dev(f["in_phi_n"]), pnp, psi, psi_inv)
+        for k, v in (("psi", psi), ("phi_n_psi", pnp), ("psi_inv", psi_inv), ("phi_global_psi_inv", pgi)):
+            check(f, k, v)
+        if verbosity == int(verb):
+            assert "\n".join(sv.log_lines) + "\n" == f["log"], (name, verbosity)
+        sv.close()
+    if "psi_after" in f:
+        for k in range(1, int(mi) + 1):
+            sv = ops.Solver(dims, max_iter=k, alpha=alpha, w_reg=w_reg, s=int(s), lam=lam, max_update_norm=mun)
+            psi = _dev(f["in_psi0"])
+            sv.estimate_psi(_dev(f["in_phi_global"]), ops.new_volume(dims), _dev(f["in_phi_n"]), ops.new_volume(dims), psi, ops.new_field(dims))
+            assert same(psi.cpu().numpy(), f["psi_after"][k - 1]), k
+            sv.close()
+
+
+@pytest.mark.gpu
+def test_hip_solver_test_setup_64():
+    from sobfu_amd import ops
+
+    f = load("ref_solver_test_64")
+    P, dims = f["P"], (64, 64, 64)
+    _, vs, trunc, eta = _tsdf_params(P, dims)
+    # init_sphere goes through the device's powf: <= 4e-6 from the reference's (stated in tests/test_gpu_parity.py); the solve below
+    # therefore starts from the reference's volumes, rebuilt on the CPU by the oracle and checked against the fixture
+    import oracle as O
+
+    pg, pn = O.new_volume(dims), O.new_volume(dims)
+    O.init_sphere(pg, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    O.init_sphere(pn, vs, trunc, eta, (P["sphere2_cx"], P["sphere2_cy"], P["sphere2_cz"]), P["sphere_r"])
+    check(f, "phi_global", pg), check(f, "phi_n", pn)
+    g = ops.new_volume(dims)
+    ops.init_sphere(g, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    assert np.abs(g.cpu().numpy() - pg).max() <= 4e-6
+    sv = ops.Solver(dims, max_iter=10, alpha=P["alpha"], w_reg=P["w_reg"], verbosity=2)
+    psi, psi_inv, pnp, pgi = _dev(FI.identity(dims)), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+    sv.estimate_psi(_dev(pg), pgi, _dev(pn), pnp, psi, psi_inv)
+    for k, v in (("psi", psi), ("phi_n_psi", pnp), ("psi_inv", psi_inv), ("phi_global_psi_inv", pgi)):
+        check(f, k, v)
+    assert "\n".join(sv.log_lines) + "\n" == f["log"]
+    sv.close()
+
+
+@pytest.mark.gpu
+def test_hip_tsdf_builders():
+    from sobfu_amd import ops
+
+    f = load("ref_tsdf_30x24x18")
+    P, dims = f["P"], (30, 24, 18)
+    _, vs, trunc, eta = _tsdf_params(P, dims)
+    v = ops.new_volume(dims)
+    ops.init_sphere(v, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    h = v.cpu().numpy()
+    assert np.abs(h[..., 0] - f["sphere"][..., 0]).max() <= 4e-6 and np.array_equal(h[..., 1], f["sphere"][..., 1])  # device powf
+    for fn, key, arg in ((ops.init_box, "box", (P["box_x"], P["box_y"], P["box_z"])), (ops.init_ellipsoid, "ellipsoid", (P["ell_x"], P["ell_y"], P["ell_z"])),
+                         (ops.init_plane, "plane", P["plane_z"]), (ops.init_torus, "torus", (P["torus_R"], P["torus_r"]))):
+        v = ops.new_volume(dims)
+        fn(v, vs, trunc, arg)
+        assert same(v.cpu().numpy(), f[key]), key
+
+
+@pytest.mark.gpu
+def test_hip_depth_steps():
+    from sobfu_amd import ops
+
+    f = load("ref_depth_32x32x32")
+    P, dims = f["P"], (32, 32, 32)
+    size, vs, trunc, eta = _tsdf_params(P, dims)
+    intr = (P["fx"], P["fy"], P["cx"], P["cy"])
+    d = ops.bilateral_filter(_dev(f["in_depth"].view(np.int16)), int(P["bilateral_ksz"]), P["bilateral_ss"], P["bilateral_sd"])
+    h = d.cpu().numpy().view(np.uint16)
+    diff = np.abs(h.astype(np.int32) - f["bilateral"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # device expf vs the reference's __expf stand-in: <= 1 mm on < 0.1 % of the pixels
+    d = _dev(f["bilateral"].view(np.int16))
+    ops.truncate_depth(d, P["trunc_depth"])
+    assert np.array_equal(d.cpu().numpy().view(np.uint16), f["truncated"])
+    dist = ops.compute_dists(d, intr)
+    assert same(dist.cpu().numpy(), f["dists"])
+    v = ops.new_volume(dims)
+    R, t = _pose(P, size)
+    ops.integrate_depth(dist, v, vs, trunc, eta, R, t, intr)
+    assert same(v.cpu().numpy(), f["volume"])
+
+
+class HipFusion:
+    """sobfu_amd.fusion.SobFusion with the depth pre-step's filter output taken from the reference where the device expf would differ"""
+
+    def __init__(self, P):
+        from sobfu_amd import fusion
+
+        dims = (int(P["X"]), int(P["Y"]), int(P["Z"]))
+        size, vs, trunc, eta = _tsdf_params(P, dims)
+        R, t = _pose(P, size)
+        self.inner = fusion.SobFusion(dict(dims=dims, vs=vs, trunc=trunc, eta=eta, max_weight=P["max_weight"], intr=(P["fx"], P["fy"], P["cx"], P["cy"]), R=R, t=t,
+                                           bilateral=(int(P["bilateral_ksz"]), P["bilateral_ss"], P["bilateral_sd"]), trunc_depth=P["trunc_depth"],
+                                           start_frame=int(P["start_frame"]), max_iter=int(P["max_iter"]), max_update_norm=P["max_update_norm"], s=int(P["s"]),
+                                           lam=P["lambda"], alpha=P["alpha"], w_reg=P["w_reg"]))
+
+    def __call__(self, depth):
+        self.inner(_dev(depth.view(np.int16)))
+
+    def __getattr__(self, k):
+        return getattr(self.inner, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64"])
+def test_hip_frame_pipeline(name):
+    """the product's frame driver against every array of the reference's SobFusion::operator().  The bilateral filter uses the
+    device's expf; on these inputs its output is identical to the reference's (asserted through phi_global of frame 0 being
+    bit-equal), so everything downstream is compared bit for bit."""
+    f = load(name)
+    fu = _check_frames(f, HipFusion, host=lambda t: t.cpu().numpy())
+    fu.close()
+
+
+@pytest.mark.gpu
+def test_hip_marching_cubes():
+    from sobfu_amd import ops
+
+    f = load("ref_mc_14x11x9")
+    P = f["P"]
+    size = np.array([P["size_x"], P["size_y"], P["size_z"]], np.float32)
+    R, t = _pose(P, size)
+    v, n = ops.marching_cubes(_dev(f["in_volume"]), tuple(size), R, t, max_voxels=4096)
+    assert np.array_equal(triangle_set(v.cpu().numpy(), n.cpu().numpy()), triangle_set(f["vertices"], f["normals"]))
