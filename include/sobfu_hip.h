@@ -226,8 +226,8 @@ typedef struct {
     int iterations;        /* iterations executed (iter at break, or max_iter) */
     int converged;         /* 1 if the max-update-norm test fired */
     float last_max_update_norm;
-    float last_max_update_index; /* float-encoded linear voxel index; NaN in the fast (quiet) path */
-    float last_e_data, last_e_reg; /* last energies evaluated (verbosity > 0), else NaN */
+    float last_max_update_index; /* float-encoded linear voxel index of the last iteration, when that iteration reported (verbosity 2; 1, 50 k, max_iter at verbosity 1: solver.cu:173); else NaN */
+    float last_e_data, last_e_reg; /* energies of the last reporting iteration (verbosity > 0), else NaN */
 } sobfu_hip_solver_report;
 
 /* Allocates the per-solver device workspace (the reference's SpatialGradients + Reductor, minus the fields

@@ -98,6 +98,40 @@ def build_mutant(k: int, out_dir: str) -> str:
     return out
 
 
+def build_nvcc(out_dir: str) -> str:
+    """This restatement evaluated the way the reference AS BUILT by nvcc may evaluate it (-DSO_NVCC_MODE=1: flush-to-zero, approximate
+    divide / sqrt / powf / __expf, fmad contraction -- see the top of sobfu_oracle.c), built into out_dir.  x86-64-v3 only: the FTZ
+    emulation needs hardware fma.  Loaded by tests/test_nvcc_distance.py and tools/nvcc_distance.py, nothing else."""
+    if not _cpu_has_v3():
+        raise RuntimeError("SO_NVCC_MODE needs avx2+fma (flush-to-zero of fmaf goes through the hardware instruction)")
+    out = os.path.join(out_dir, "liboracle_nvcc.so")
+    subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-march=x86-64-v3",
+                           "-DSO_NVCC_MODE=1", "-o", out, os.path.join(_HERE, "sobfu_oracle.c"), "-lm"])
+    return out
+
+
+class nvcc_mode:
+    """`with nvcc_mode(path, seed):` -- oracle calls inside run on the SO_NVCC_MODE build with FTZ|DAZ switched on in every OpenMP
+    thread; on exit the IEEE library and the threads' IEEE behaviour are restored."""
+
+    def __init__(self, path, seed=1):
+        self.path, self.seed = path, seed
+
+    def __enter__(self):
+        global _lib
+        self.old = _lib if _lib is not None else lib()
+        _lib = _load(self.path)
+        _lib.so_nvcc_set_seed(C.c_uint(self.seed))
+        _lib.so_nvcc_ftz(C.c_int(1))
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.so_nvcc_ftz(C.c_int(0))
+        _lib = self.old
+        return False
+
+
 class use_library:
     """context manager: every function of this module calls the given build of the oracle instead of the regular one"""
 

@@ -53,6 +53,79 @@
 #define SO_MUTANT 0
 #endif
 
+/* -DSO_NVCC_MODE=1: the same restatement evaluated the way the reference AS BUILT may evaluate it.  The reference compiles with
+ * nvcc --ftz=true --prec-div=false --prec-sqrt=false and the default --fmad=true (CMakeLists.txt:40-46); this file and the HIP
+ * kernels evaluate IEEE.  The mode exists to put a NUMBER on that distance (tests/test_nvcc_distance.py):
+ *   - flush-to-zero of binary32 subnormal operands and results: the caller switches the CPU's MXCSR FTZ|DAZ bits on in every
+ *     OpenMP thread around the calls (so_nvcc_ftz, below) -- the same semantics as PTX's .ftz, for every operation of the file;
+ *   - every device-side `/` and __fdividef (div.approx.ftz.f32, <= 2 ulp): the correctly rounded quotient moved by k ulp,
+ *     k in {-2..2} drawn from a hash of the operands and a seed; exact when the divisor is a power of two (x / 2.f);
+ *   - device-side sqrtf (sqrt.approx.ftz.f32, ~1 ulp): k in {-1..1};  powf (<= 4 ulp, CUDA C Programming Guide, table of
+ *     single-precision function errors): k in {-4..4};  __expf (2 + floor(|1.16 x|) ulp): k in that range;
+ *   - plain `a * b + c` in device code contracted into one fma where the product is not an __fmul_rn intrinsic
+ *     (tsdf_volume.cu:70-71,189-196,256-257; imgproc.cu:28-34,238-240; reductor.cu:26-31).  Nothing in the per-iteration
+ *     recurrence is affected: it is written in rn intrinsics and explicit fma throughout.
+ * The draws are a deterministic function of (operands, seed): a randomised within-spec perturbation, not an adversarial bound.
+ * Host-side arithmetic of the reference (1.f / f.x in compute_dists' wrapper, 0.5f / sigma^2 in bilateralFilter's) stays IEEE.
+ * 0 (the default) is the oracle everything else uses; only tests/test_nvcc_distance.py builds and loads the other. */
+#ifndef SO_NVCC_MODE
+#define SO_NVCC_MODE 0
+#endif
+#if SO_NVCC_MODE
+#include <xmmintrin.h>
+static uint32_t so_nvcc_seed = 1u, so_nvcc_mask = 31u;
+void so_nvcc_set_seed(unsigned s) { so_nvcc_seed = s; }
+/* which approximations are on (for attribution): 1 divide, 2 sqrtf, 4 powf, 8 __expf, 16 fmad contraction; default all */
+void so_nvcc_set_mask(unsigned m) { so_nvcc_mask = m; }
+/* FTZ|DAZ on (1) / off (0) in the calling thread and every thread of the OpenMP pool; returns the caller's previous state */
+int so_nvcc_ftz(int on) {
+    int was = (_mm_getcsr() & 0x8040u) == 0x8040u;
+#pragma omp parallel
+    { _mm_setcsr(on ? (_mm_getcsr() | 0x8040u) : (_mm_getcsr() & ~0x8040u)); }
+    _mm_setcsr(on ? (_mm_getcsr() | 0x8040u) : (_mm_getcsr() & ~0x8040u));
+    return was;
+}
+static inline uint32_t nv_bits(float v) { uint32_t u; memcpy(&u, &v, 4); return u; }
+static inline uint32_t nv_hash(uint32_t a, uint32_t b) {
+    uint32_t h = (a ^ so_nvcc_seed) * 0x9E3779B1u;
+    h ^= h >> 15; h = (h ^ b) * 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+    return h;
+}
+static inline float nv_step(float v, int k) { /* k ulp away from (k > 0) / toward (k < 0) zero */
+    uint32_t u = nv_bits(v), mag = u & 0x7FFFFFFFu;
+    if (mag == 0 || mag >= 0x7F800000u || k == 0) return v;
+    int64_t m = (int64_t) mag + k;
+    if (m < 0) m = 0;
+    if (m > 0x7F7FFFFF) m = 0x7F7FFFFF;
+    u = (u & 0x80000000u) | (uint32_t) m;
+    memcpy(&v, &u, 4);
+    return v;
+}
+static inline int nv_draw(float a, float b, int range) { return (int) (nv_hash(nv_bits(a), nv_bits(b)) % (uint32_t) (2 * range + 1)) - range; }
+static inline float so_div(float a, float b) {
+    float q = a / b;
+    if (!(so_nvcc_mask & 1u) || (nv_bits(b) & 0x007FFFFFu) == 0) return q; /* power of two: exact */
+    return nv_step(q, nv_draw(a, b, 2));
+}
+static inline float so_sqrt(float a) { return (so_nvcc_mask & 2u) ? nv_step(sqrtf(a), nv_draw(a, 0.5f, 1)) : sqrtf(a); }
+static inline float so_pow(float a, float b) { return (so_nvcc_mask & 4u) ? nv_step(powf(a, b), nv_draw(a, b, 4)) : powf(a, b); }
+static inline float so_exp_fast(float x) {
+    return (so_nvcc_mask & 8u) ? nv_step(expf(x), nv_draw(x, 2.f, 2 + (int) floorf(fabsf(1.16f * x)))) : expf(x);
+}
+static inline float so_mad(float a, float b, float c) {
+    if (so_nvcc_mask & 16u) return fmaf(a, b, c);
+    volatile float p = a * b; /* keep the product rounded */
+    return p + c;
+}
+#define SO_MAD(a, b, c) so_mad((a), (b), (c))
+#else
+#define so_div(a, b) ((a) / (b))
+#define so_sqrt(a) sqrtf(a)
+#define so_pow(a, b) powf((a), (b))
+#define so_exp_fast(x) expf(x)
+#define SO_MAD(a, b, c) ((a) * (b) + (c))
+#endif
+
 typedef struct { float x, y; } f2;
 typedef struct { float x, y, z, w; } f4;
 typedef struct { f4 r[4]; } m4;
@@ -66,7 +139,7 @@ static inline f4 mk4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; 
 static inline f4 add4(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, 0.f); }          /* :245 */
 static inline f4 sub4(f4 a, f4 b) { return mk4(a.x + (-b.x), a.y + (-b.y), a.z + (-b.z), 0.f); } /* :249 */
 static inline f4 mul4(f4 v, float m) { return mk4(v.x * m, v.y * m, v.z * m, 0.f); }              /* :267 */
-static inline f4 div4(f4 v, float d) { return mk4(v.x / d, v.y / d, v.z / d, 0.f); }              /* :273 */
+static inline f4 div4(f4 v, float d) { return mk4(so_div(v.x, d), so_div(v.y, d), so_div(v.z, d), 0.f); } /* :273 (__fdividef) */
 static inline float norm_sq4(f4 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }                  /* :283 */
 
 /* __fsqrt_rd: sqrt rounded toward -inf (utils.hpp:279-281 `norm`) */
@@ -155,7 +228,7 @@ static inline f2 pack_tsdf(float sdf, float trunc, float weight) { /* tsdf_volum
     r.y = weight;
     if (sdf >= trunc) r.x = 1.f;
     else if (sdf <= -trunc) r.x = -1.f;
-    else r.x = sdf / trunc;
+    else r.x = so_div(sdf, trunc); /* __fdividef */
     return r;
 }
 
@@ -170,12 +243,12 @@ void so_integrate_depth(const float *dists, int step_bytes, int rows, int cols, 
 #pragma omp parallel for collapse(2) schedule(static)
     for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x) {
-            float vcx = x * vsx + vsx / 2.f, vcy = y * vsy + vsy / 2.f, vcz = vsz / 2.f; /* :70-71 */
+            float vcx = SO_MAD(x, vsx, vsx / 2.f), vcy = SO_MAD(y, vsy, vsy / 2.f), vcz = vsz / 2.f; /* :70-71 */
             float camx = dot3(R + 0, vcx, vcy, vcz) + t[0];                              /* :72 */
             float camy = dot3(R + 3, vcx, vcy, vcz) + t[1];
             float camz = dot3(R + 6, vcx, vcy, vcz) + t[2];
             for (int i = 0; i < Z; ++i, camx += 0.f, camy += 0.f, camz += vsz) {        /* :76 */
-                float coox = fmaf(fx, camx / camz, cx), cooy = fmaf(fy, camy / camz, cy); /* device.hpp:38-39 */
+                float coox = fmaf(fx, so_div(camx, camz), cx), cooy = fmaf(fy, so_div(camy, camz), cy); /* device.hpp:38-39 */
                 if (coox < 0 || cooy < 0 || coox >= (float) cols || cooy >= (float) rows) continue; /* :79 */
                 if (!(camz > 0)) continue; /* :84 second clause, hoisted before the fetch (both `continue`) */
                 if (!(coox == coox) || !(cooy == cooy)) continue; /* NaN coo only arises with camz<=0 */
@@ -198,7 +271,7 @@ void so_integrate_fuse(f2 *phi_global, const f2 *phi_n_psi, int X, int Y, int Z,
         if (t.y == 0.f || (t.y == 1.f && (t.x == 0.f || t.x == -1.f))) continue; /* :118 */
         f2 p = phi_global[i];
         f2 o;
-        o.x = fmaf(p.y, p.x, t.x) / (p.y + 1.f);  /* :124 */
+        o.x = so_div(fmaf(p.y, p.x, t.x), p.y + 1.f);  /* :124 (__fdividef) */
         o.y = fminf(p.y + 1.f, (float) max_weight); /* :125 */
         phi_global[i] = o;
     }
@@ -210,9 +283,9 @@ void so_init_sphere(f2 *vol, int X, int Y, int Z, float vsx, float vsy, float vs
 #pragma omp parallel for collapse(2) schedule(static)
     for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x) {
-            float vx = x * vsx + vsx / 2.f, vy = y * vsy + vsy / 2.f, vz = vsz / 2.f; /* :256-257 */
+            float vx = SO_MAD(x, vsx, vsx / 2.f), vy = SO_MAD(y, vsy, vsy / 2.f), vz = vsz / 2.f; /* :256-257 */
             for (int i = 0; i < Z; vz += vsz, ++i) {
-                float d   = sqrtf(powf(vx - cx, 2) + powf(vy - cy, 2) + powf(vz - cz, 2)); /* :262 */
+                float d   = so_sqrt(so_pow(vx - cx, 2) + so_pow(vy - cy, 2) + so_pow(vz - cz, 2)); /* :262 */
                 float sdf = d - radius;
                 float w   = (sdf > -eta) ? 1.f : 0.f;
                 vol[IDX(x, y, i)] = pack_tsdf(sdf, trunc, w);
@@ -222,7 +295,7 @@ void so_init_sphere(f2 *vol, int X, int Y, int Z, float vsx, float vsy, float vs
 
 static inline float norm3_fma(float x, float y, float z) { /* temp_utils.hpp:86: sqrt(dot(v,v)) */
     float a[3] = {x, y, z};
-    return sqrtf(dot3(a, x, y, z));
+    return so_sqrt(dot3(a, x, y, z));
 }
 
 /* init_box_kernel -- tsdf_volume.cu:181-213 */
@@ -232,7 +305,7 @@ void so_init_box(f2 *vol, int X, int Y, int Z, float vsx, float vsy, float vsz, 
 #pragma omp parallel for collapse(2) schedule(static)
     for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x) {
-            float vx = (x * vsx + vsx / 2.f) - ccx, vy = (y * vsy + vsy / 2.f) - ccy, vz = (vsz / 2.f) - ccz;
+            float vx = SO_MAD(x, vsx, vsx / 2.f) - ccx, vy = SO_MAD(y, vsy, vsy / 2.f) - ccy, vz = (vsz / 2.f) - ccz;
             for (int i = 0; i < Z; vz += vsz, ++i) {
                 float dx = fabsf(vx) - bx, dy = fabsf(vy) - by, dz = fabsf(vz) - bz; /* :199 */
                 float sdf = fminf(fmaxf(dx, fmaxf(dy, dz)), 0.f) +
@@ -249,11 +322,11 @@ void so_init_ellipsoid(f2 *vol, int X, int Y, int Z, float vsx, float vsy, float
 #pragma omp parallel for collapse(2) schedule(static)
     for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x) {
-            float vx = (x * vsx + vsx / 2.f) - ccx, vy = (y * vsy + vsy / 2.f) - ccy, vz = (vsz / 2.f) - ccz;
+            float vx = SO_MAD(x, vsx, vsx / 2.f) - ccx, vy = SO_MAD(y, vsy, vsy / 2.f) - ccy, vz = (vsz / 2.f) - ccz;
             for (int i = 0; i < Z; vz += vsz, ++i) {
-                float k0  = norm3_fma(vx / rx, vy / ry, vz / rz);                          /* :233 */
-                float k1  = norm3_fma(vx / (rx * rx), vy / (ry * ry), vz / (rz * rz));    /* :234 */
-                float sdf = k0 * (k0 - 1.f) / k1;                                          /* :236 */
+                float k0  = norm3_fma(so_div(vx, rx), so_div(vy, ry), so_div(vz, rz));     /* :233 */
+                float k1  = norm3_fma(so_div(vx, rx * rx), so_div(vy, ry * ry), so_div(vz, rz * rz)); /* :234 */
+                float sdf = so_div(k0 * (k0 - 1.f), k1);                                   /* :236 */
                 vol[IDX(x, y, i)] = pack_tsdf(sdf, trunc, 1.f);
             }
         }
@@ -276,7 +349,7 @@ void so_init_torus(f2 *vol, int X, int Y, int Z, float vsx, float vsy, float vsz
 #pragma omp parallel for collapse(2) schedule(static)
     for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x) {
-            float vx = (x * vsx + vsx / 2.f) - ccx, vy = (y * vsy + vsy / 2.f) - ccy, vz = (vsz / 2.f) - ccz;
+            float vx = SO_MAD(x, vsx, vsx / 2.f) - ccx, vy = SO_MAD(y, vsy, vsy / 2.f) - ccy, vz = (vsz / 2.f) - ccz;
             for (int i = 0; i < Z; vz += vsz, ++i) {
                 float qx  = sqrtf(vx * vx + vz * vz) - t0; /* :321 */
                 float sdf = sqrtf(qx * qx + vy * vy) - t1; /* :323 */
@@ -307,11 +380,11 @@ void so_bilateral(const uint16_t *src, int src_step, uint16_t *dst, int dst_step
                     int depth    = SRC(cy, cx);
                     float space2 = (float) ((x - cx) * (x - cx) + (y - cy) * (y - cy));                     /* :28 */
                     float color2 = (float) (int32_t) ((uint32_t)(value - depth) * (uint32_t)(value - depth)); /* :29 */
-                    float weight = expf(-(space2 * sss + color2 * sds));                                    /* :31 */
-                    sum1 += depth * weight;
+                    float weight = so_exp_fast(-SO_MAD(space2, sss, color2 * sds));                         /* :31 (__expf) */
+                    sum1 = SO_MAD((float) depth, weight, sum1);
                     sum2 += weight;
                 }
-            float q = sum1 / sum2;
+            float q = so_div(sum1, sum2);
             int r   = (q == q) ? (int) lrintf(q) : 0; /* __float2int_rn; NaN -> 0 */
             *(uint16_t *) ((char *) dst + (size_t) y * dst_step + (size_t) x * 2) = (uint16_t) r; /* :36 */
         }
@@ -339,7 +412,7 @@ void so_compute_dists(const uint16_t *depth, int dstep, float *dists, int sstep,
         for (int x = 0; x < cols; ++x) {
             float xl     = (x - cx) * fix;
             float yl     = (y - cy) * fiy;
-            float lambda = sqrtf(xl * xl + yl * yl + 1);
+            float lambda = so_sqrt(SO_MAD(xl, xl, yl * yl) + 1);
             srow[x]      = drow[x] * lambda * 0.001f;
         }
     }
@@ -670,6 +743,17 @@ static float tree_sum(const void *a, const void *b, size_t n, elem_fn fn, float 
         for (int t = 0; t < threads; ++t) {
             float my = 0.f;
             for (size_t i = (size_t) blk * threads * 2 + t; i < n; i += grid) {
+#if SO_NVCC_MODE
+                if (fn == el_data && (so_nvcc_mask & 16u)) { /* `mySum += d * d` contracts (reductor.cu:26-31) */
+                    float d = ((const f2 *) a)[i].x - ((const f2 *) b)[i].x;
+                    my      = fmaf(d, d, my);
+                    if (i + threads < n) {
+                        d  = ((const f2 *) a)[i + threads].x - ((const f2 *) b)[i + threads].x;
+                        my = fmaf(d, d, my);
+                    }
+                    continue;
+                }
+#endif
                 my += fn(a, b, i);
                 if (i + threads < n) my += fn(a, b, i + threads);
             }

@@ -14,6 +14,7 @@
 #include "sobfu_device.hpp"
 #include "sobfu_hip.h"
 #include "sobfu_host.hpp"
+#include "sobfu_launch.hpp"
 
 using namespace sobfu_hip;
 
@@ -45,6 +46,35 @@ struct RegFromPsiEl {  // same value, Jacobian (mode 1, vector_fields.cu:415-472
         float4 jx = half4(sub4(disp_at(psi, d, x1, y, z), disp_at(psi, d, x2, y, z)));
         float4 jy = half4(sub4(disp_at(psi, d, x, y1, z), disp_at(psi, d, x, y2, z)));
         float4 jz = half4(sub4(disp_at(psi, d, x, y, z1), disp_at(psi, d, x, y, z2)));
+        return norm_sq4(f4(jx.x, jy.x, jz.x)) + norm_sq4(f4(jx.y, jy.y, jz.y)) + norm_sq4(f4(jx.z, jy.z, jz.z));
+    }
+};
+
+// the same two elements on the solver's iteration format (tsdf-only 4-byte volumes, 12-byte psi): identical values, so the
+// energies printed at verbosity 1 / 2 do not need the API-format arrays
+struct DataElC {
+    const float *g, *n;
+    SOBFU_DEV float operator()(size_t i) const {
+        float d = g[i] - n[i];
+        return d * d;
+    }
+};
+struct RegFromPsi3El {
+    const float* psi;  // 3 floats per voxel
+    Dims d;
+    SOBFU_DEV float4 disp(int x, int y, int z) const {
+        const float* p = psi + 3 * vidx(d, x, y, z);
+        return sub4(f4(p[0], p[1], p[2]), f4((float) x, (float) y, (float) z));
+    }
+    SOBFU_DEV float operator()(size_t i) const {
+        int x = (int) (i % d.x), y = (int) ((i / d.x) % d.y), z = (int) (i / ((size_t) d.x * d.y));
+        int x1 = x + 1, x2 = x - 1, y1 = y + 1, y2 = y - 1, z1 = z + 1, z2 = z - 1;
+        if (x == 0) x2 = x + 1; else if (x == d.x - 1) x1 = x - 1;
+        if (y == 0) y2 = y + 1; else if (y == d.y - 1) y1 = y - 1;
+        if (z == 0) z2 = z + 1; else if (z == d.z - 1) z1 = z - 1;
+        float4 jx = half4(sub4(disp(x1, y, z), disp(x2, y, z)));
+        float4 jy = half4(sub4(disp(x, y1, z), disp(x, y2, z)));
+        float4 jz = half4(sub4(disp(x, y, z1), disp(x, y, z2)));
         return norm_sq4(f4(jx.x, jy.x, jz.x)) + norm_sq4(f4(jx.y, jy.y, jz.y)) + norm_sq4(f4(jx.z, jy.z, jz.z));
     }
 };
@@ -128,6 +158,15 @@ int run_sum(El el, int n, void* d_scratch, float* out, void* stream) {
 }
 
 }  // namespace
+
+namespace sobfu_hip {
+int data_energy_tsdf(const float* g1, const float* f1, int n, void* d_scratch, float* out, hipStream_t stream) {
+    return run_sum(DataElC{g1, f1}, n, d_scratch, out, stream);
+}
+int reg_energy_from_psi3(const float* psi3, int X, int Y, int Z, void* d_scratch, float* out, hipStream_t stream) {
+    return run_sum(RegFromPsi3El{psi3, Dims{X, Y, Z}}, X * Y * Z, d_scratch, out, stream);
+}
+}  // namespace sobfu_hip
 
 extern "C" {
 

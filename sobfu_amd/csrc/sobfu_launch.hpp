@@ -89,4 +89,8 @@ int launch_msg_scatter_table(float* field3, const float* buf, const uint32_t* d_
 int launch_compact_enter(const float* psi4, const float* pg2, const float* pn2, float* c_psi, float* c_g, float* c_n, float* c_f, int X, int Y,
                          int Z, hipStream_t stream);
 int launch_compact_leave(const float* c_psi, const float* pn2, float* psi4, float* pnp2, int X, int Y, int Z, hipStream_t stream);
+// the two energies of solver.cu:132-142 straight from the iteration format (reduce_kernels.hip): same tree, same values as
+// sobfu_hip_data_energy / sobfu_hip_reg_energy_sobolev_from_psi on the API-format arrays
+int data_energy_tsdf(const float* g1, const float* f1, int n, void* d_scratch, float* out, hipStream_t stream);
+int reg_energy_from_psi3(const float* psi3, int X, int Y, int Z, void* d_scratch, float* out, hipStream_t stream);
 }  // namespace sobfu_hip

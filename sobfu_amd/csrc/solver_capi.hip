@@ -87,6 +87,7 @@ struct sobfu_hip_solver {
         int done = 0;  // iterations known to have executed
         bool converged = false;
         float last_norm = 0.f;
+        bool inline_log = false;  // the verbose loop prints its lines as it goes; session_end then only adds the closing line
     } q;
 
     void log(const std::string& line) const {
@@ -277,45 +278,50 @@ int session_enqueue(sobfu_hip_solver* s, int n, bool poll, float* per_iter, hipS
     return 0;
 }
 
+// examine every max-norm row launched so far (synchronises the stream).  With a threshold that can fire, rows are examined in
+// order until the reference's break; otherwise all rows are read back at once.
+int session_drain(sobfu_hip_solver* s, float* per_iter, hipStream_t st) {
+    sobfu_hip_solver::Session& q = s->q;
+    if (q.launched == 0) return 0;
+    if (s->p.max_update_norm >= 0.f) {
+        if (q.in_flight) {
+            SOBFU_HIP_TRY(hipEventSynchronize(s->ev_chk));
+            session_examine(s, q.fl_to, per_iter);
+            q.in_flight = false;
+        }
+        if (!q.converged && q.checked < q.launched) {  // rows launched after the last copy was issued
+            SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) q.checked * kSlots, s->slots + (size_t) (q.checked + 1) * kSlots,
+                                         (size_t) (q.launched - q.checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
+            SOBFU_HIP_TRY(hipStreamSynchronize(st));
+            session_examine(s, q.launched, per_iter);
+        }
+    } else {
+        std::vector<uint32_t> hs((size_t) q.launched * kSlots);
+        SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + kSlots, hs.size() * 4, hipMemcpyDeviceToHost, st));
+        SOBFU_HIP_TRY(hipStreamSynchronize(st));
+        for (int k = 0; k < q.launched; ++k) {
+            const float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
+            if (per_iter) per_iter[k] = v;
+            q.last_norm = v;
+        }
+        q.done = q.launched;
+    }
+    return 0;
+}
+
 int session_end(sobfu_hip_solver* s, sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
     sobfu_hip_solver::Session& q = s->q;
     if (!q.active) return SOBFU_E_BADARG;
-    const sobfu_hip_solver_params& p = s->p;
     sobfu_hip_solver_report r{};
     r.last_max_update_norm = NAN;
     r.last_max_update_index = NAN;
     r.last_e_data = r.last_e_reg = NAN;
-    const bool can_converge = p.max_update_norm >= 0.f;
-    if (q.launched > 0) {
-        if (can_converge) {
-            if (q.in_flight) {
-                SOBFU_HIP_TRY(hipEventSynchronize(s->ev_chk));
-                session_examine(s, q.fl_to, per_iter);
-                q.in_flight = false;
-            }
-            if (!q.converged && q.checked < q.launched) {  // rows launched after the last copy was issued
-                SOBFU_HIP_TRY(hipMemcpyAsync(s->h_rows + (size_t) q.checked * kSlots, s->slots + (size_t) (q.checked + 1) * kSlots,
-                                             (size_t) (q.launched - q.checked) * kSlots * 4, hipMemcpyDeviceToHost, st));
-                SOBFU_HIP_TRY(hipStreamSynchronize(st));
-                session_examine(s, q.launched, per_iter);
-            }
-        } else {
-            std::vector<uint32_t> hs((size_t) q.launched * kSlots);
-            SOBFU_HIP_TRY(hipMemcpyAsync(hs.data(), s->slots + kSlots, hs.size() * 4, hipMemcpyDeviceToHost, st));
-            SOBFU_HIP_TRY(hipStreamSynchronize(st));
-            for (int k = 0; k < q.launched; ++k) {
-                const float v = slots_to_norm(hs.data() + (size_t) k * kSlots);
-                if (per_iter) per_iter[k] = v;
-                q.last_norm = v;
-            }
-            q.done = q.launched;
-        }
-    }
+    SOBFU_TRY(session_drain(s, per_iter, st));
     // `done` iterations actually executed (later launches were no-ops): psi.xyz back + phi_n o psi = apply(phi_n, psi), the
     // state solver.cu:168 leaves behind, in one pass
     if (q.compact) SOBFU_TRY(sobfu_hip::launch_compact_leave(s->c_psi, q.pn, q.psi, q.pnp, s->X, s->Y, s->Z, st));
     // the lines the reference prints at verbosity 0 (solver.cu:115-117,184,189), emitted after the fact
-    for (int it = 1; it <= q.done; ++it)
+    for (int it = 1; it <= q.done && !q.inline_log; ++it)
         if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
     if (q.converged) s->log("SOLVER CONVERGED AFTER " + std::to_string(q.done) + " ITERATIONS");
     else if (q.cap > 0 && q.done == q.cap) s->log("SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING");
@@ -328,58 +334,76 @@ int session_end(sobfu_hip_solver* s, sobfu_hip_solver_report* rep, float* per_it
     return 0;
 }
 
-// verbose (verbosity > 0): same kernels on the API-format arrays, plus the reference's energy / arg-max reductions and a host
-// sync per iteration (solver.cu:114-193 as written)
+// verbose (verbosity > 0).  The reference evaluates the two energies and prints the arg-max of the update only on REPORTING
+// iterations -- every one at verbosity 2; 1, 50 k and max_iter at verbosity 1 (solver.cu:132-142,173-181).  Everything between two
+// reporting iterations runs exactly like the quiet loop (iteration format, no host sync, device-side convergence gate); a
+// reporting iteration stays in the iteration format too: energies straight from the tsdf-only / 12-byte arrays, the pass B that
+// also stores `updates`, and the reference's arg-max reduction over them.  Lines, arrays and the iteration the solver stops at
+// are the reference's.
 int run_verbose(sobfu_hip_solver* s, const float* pg, const float* pn, float* pnp, float* psi, int max_iter,
                 sobfu_hip_solver_report* rep, float* per_iter, hipStream_t st) {
     const int X = s->X, Y = s->Y, Z = s->Z;
     const sobfu_hip_solver_params& p = s->p;
-    sobfu_hip_solver_report r{};
-    r.last_max_update_norm = NAN;
-    r.last_max_update_index = NAN;
-    r.last_e_data = r.last_e_reg = NAN;
-    SOBFU_TRY(sobfu_hip_apply(pn, pnp, psi, X, Y, Z, st));  // solver.cu:106
-    SOBFU_TRY(ensure_slots(s, max_iter));
-    SOBFU_HIP_TRY(hipMemsetAsync(s->slots, 0, (size_t) (max_iter + 1) * kSlots * 4, st));
+    auto reports = [&](int it) { return p.verbosity == 2 || it == 1 || it % 50 == 0 || it == max_iter; };
     SOBFU_TRY(ensure_updates(s));
-    float* upd = s->updates;
-    int done = 0;
-    bool converged = false;
-    for (int it = 1; it <= max_iter; ++it) {
-        if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
-        const bool report = (p.verbosity == 1 && (it == 1 || it % 50 == 0 || it == max_iter)) || p.verbosity == 2;
-        if (report) {  // solver.cu:132-142 (J of the displacement is rebuilt in registers, not stored)
-            SOBFU_TRY(sobfu_hip_data_energy(pg, pnp, (int) s->N, s->red_scratch, &r.last_e_data, st));
-            SOBFU_TRY(sobfu_hip_reg_energy_sobolev_from_psi(psi, X, Y, Z, s->red_scratch, &r.last_e_reg, st));
-            float e = r.last_e_data + p.w_reg * r.last_e_reg;
-            s->log("data energy + w_reg * reg energy = " + fmt_g(r.last_e_data) + " + " + fmt_g(p.w_reg) + " * " +
-                   fmt_g(r.last_e_reg) + " = " + fmt_g(e));
+    SOBFU_TRY(session_begin(s, pg, pn, pnp, psi, max_iter, st));
+    sobfu_hip_solver::Session& q = s->q;
+    q.inline_log = true;
+    float e_data = NAN, e_reg = NAN, arg = NAN;
+    auto fail = [&](int rc) {
+        q.active = false;
+        return rc;
+    };
+#define SOBFU_VTRY(expr)                    \
+    do {                                    \
+        const int rc_ = (int) (expr);       \
+        if (rc_ != 0) return fail(rc_);     \
+    } while (0)
+    for (int it = 1; it <= max_iter && !q.converged;) {
+        if (!reports(it)) {  // a run of quiet iterations it .. to
+            int to = it;
+            while (to + 1 <= max_iter && !reports(to + 1)) ++to;
+            SOBFU_VTRY(session_enqueue(s, to - it + 1, true, per_iter, st));
+            if (p.max_update_norm >= 0.f) SOBFU_VTRY(session_drain(s, per_iter, st));  // did the break fire inside the run?
+            it = to + 1;
+            continue;
         }
-        uint32_t* cur = s->slots + (size_t) it * kSlots;
-        SOBFU_TRY(sobfu_hip::launch_pass_a(pnp, pg, psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st, false));
-        SOBFU_TRY(sobfu_hip::launch_pass_b(s->nabla_U, psi, pn, pnp, upd, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st, 0, 0, 0, false));
+        if (it == 1 || it % 50 == 0) s->log("iter. no. " + std::to_string(it));
+        if (q.compact) {  // solver.cu:132-142 (J of the displacement is rebuilt in registers, not stored)
+            SOBFU_VTRY(sobfu_hip::data_energy_tsdf(q.it_pg, q.it_pnp, (int) s->N, s->red_scratch, &e_data, st));
+            SOBFU_VTRY(sobfu_hip::reg_energy_from_psi3(q.it_psi, X, Y, Z, s->red_scratch, &e_reg, st));
+        } else {
+            SOBFU_VTRY(sobfu_hip_data_energy(pg, pnp, (int) s->N, s->red_scratch, &e_data, st));
+            SOBFU_VTRY(sobfu_hip_reg_energy_sobolev_from_psi(psi, X, Y, Z, s->red_scratch, &e_reg, st));
+        }
+        const float e = e_data + p.w_reg * e_reg;
+        s->log("data energy + w_reg * reg energy = " + fmt_g(e_data) + " + " + fmt_g(p.w_reg) + " * " + fmt_g(e_reg) + " = " + fmt_g(e));
+        uint32_t* cur = s->slots + (size_t) it * kSlots;  // the row the next quiet iteration's gate reads
+        SOBFU_VTRY(sobfu_hip::launch_pass_a(q.it_pnp, q.it_pg, q.it_psi, s->nabla_U, p.w_reg, X, Y, Z, nullptr, 0.f, 0, st, q.compact));
+        SOBFU_VTRY(sobfu_hip::launch_pass_b(s->nabla_U, q.it_psi, q.it_pn, q.it_out, s->updates, cur, s->taps, p.alpha, X, Y, Z, nullptr, 0.f, 0, st, 0,
+                                            0, 0, q.compact));
         float mx[2];
-        SOBFU_TRY(sobfu_hip_max_update_norm(upd, (int) s->N, s->red_scratch, mx, st));  // solver.cu:172
-        r.last_max_update_norm  = mx[0];
-        r.last_max_update_index = mx[1];
+        SOBFU_VTRY(sobfu_hip_max_update_norm(s->updates, (int) s->N, s->red_scratch, mx, st));  // solver.cu:172 (synchronises)
         if (per_iter) per_iter[it - 1] = mx[0];
-        done = it;
-        if (report) {  // solver.cu:175-180 (index arithmetic reproduced as written)
+        arg = mx[1];
+        q.launched = q.checked = q.done = it;
+        q.last_norm = mx[0];
+        {  // solver.cu:175-180 (index arithmetic reproduced as written)
             int ix = (int) (mx[1] / (float) (X * Y));
             int iy = (int) ((mx[1] - (float) (ix * X * Y)) / (float) X);
             int iz = (int) (mx[1] - (float) (X * (iy + Y * ix)));
-            s->log("max. update norm " + fmt_g(mx[0]) + " at voxel (" + std::to_string(iz) + ", " + std::to_string(iy) +
-                   ", " + std::to_string(ix) + ")");
+            s->log("max. update norm " + fmt_g(mx[0]) + " at voxel (" + std::to_string(iz) + ", " + std::to_string(iy) + ", " + std::to_string(ix) + ")");
         }
-        if (mx[0] <= p.max_update_norm) {
-            converged = true;
-            break;
-        }
+        if (mx[0] <= p.max_update_norm) q.converged = true;  // solver.cu:183
+        ++it;
     }
-    if (converged) s->log("SOLVER CONVERGED AFTER " + std::to_string(done) + " ITERATIONS");
-    else if (done == max_iter) s->log("SOLVER REACHED MAX. NO. OF ITERATIONS WITHOUT CONVERGING");
-    r.iterations = done;
-    r.converged  = converged ? 1 : 0;
+#undef SOBFU_VTRY
+    const bool last_reported = q.done > 0 && reports(q.done);
+    sobfu_hip_solver_report r{};
+    SOBFU_TRY(session_end(s, &r, per_iter, st));
+    r.last_e_data = e_data;  // of the last reporting iteration
+    r.last_e_reg  = e_reg;
+    r.last_max_update_index = last_reported ? arg : NAN;  // the arg-max exists only where the reference would have printed it
     if (rep) *rep = r;
     return 0;
 }
@@ -461,7 +485,8 @@ int sobfu_hip_solver_create(sobfu_hip_solver** out, int X, int Y, int Z, const s
     }
     // the quiet path's compact state is part of the workspace from the start (like the reference's constructor, which
     // allocates everything up front): the first solve of a sequence pays no allocation
-    if (rc == 0 && s->compact && params->verbosity == 0) rc = ensure_compact(s);
+    if (rc == 0 && s->compact) rc = ensure_compact(s);
+    if (rc == 0 && params->verbosity > 0) rc = ensure_updates(s);
     if (rc != 0) {
         sobfu_hip_solver_destroy(s);
         return rc;

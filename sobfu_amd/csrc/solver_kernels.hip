@@ -1152,7 +1152,9 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
 // ISA in round 5: `global_load_dwordx3 ... off` without `nt`, while the 4-byte phi_n o psi store carries it); the buffer instructions
 // take the hint as an operand.
 template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0, int NTL = SOBFU_NT, bool PIPE = false, bool NTBUF = false>
-__global__ void __launch_bounds__(TX* WY, PIPE ? SOBFU_MINW_PIPE : SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
+// (the API-format instantiations -- 16-byte psi / nabla_U, 8-byte volumes: the launcher-level entry point and set_compact(0) -- get the
+// 128-VGPR budget: at 80 they spilled 12 - 28 B/lane to scratch)
+__global__ void __launch_bounds__(TX* WY, (PIPE || !COMPACT) ? SOBFU_MINW_PIPE : SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
     static_assert(!NTBUF || (COMPACT && !PIPE && NTL >= 1), "NTBUF: the plain march of the compact format with streaming hints");
     static_assert(!PIPE || (RPT == 1 && COMPACT && IDX32 && !WRITE_UPDATES && HL == 0), "the pipelined march exists for the compact solver format");
     constexpr int R = 3, TY = RPT * WY, LW = TX + 2 * R, LH = TY + 2 * R;

@@ -3,6 +3,7 @@
 // units be compiled, unchanged and from where they lie under /root/reference, against this repo's include/ (the drop-in claim), and
 // run on the HIP path (tests/test_reference_callers.py).
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -38,13 +39,15 @@ inline int run_all_tests() {
     for (const Registry::Entry& e : Registry::all()) {
         std::printf("[ RUN      ] %s.%s\n", e.suite.c_str(), e.name.c_str());
         std::fflush(stdout);
+        const auto t0 = std::chrono::steady_clock::now();
         Test* t = e.make();
         t->SetUp();
         t->TestBody();
         t->TearDown();
         const bool bad = t->failed_;
         delete t;
-        std::printf(bad ? "[  FAILED  ] %s.%s\n" : "[       OK ] %s.%s\n", e.suite.c_str(), e.name.c_str());
+        const long ms = (long) std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        std::printf(bad ? "[  FAILED  ] %s.%s (%ld ms)\n" : "[       OK ] %s.%s (%ld ms)\n", e.suite.c_str(), e.name.c_str(), ms);
         failed += bad ? 1 : 0;
     }
     std::printf("[==========] %zu tests ran, %d failed\n", Registry::all().size(), failed);

@@ -315,6 +315,41 @@ def test_solver_estimate_psi_matches_oracle(ops, oracle, verbosity):
     sv.close()
 
 
+@pytest.mark.parametrize("case", ["120 iterations", "break in a quiet run", "break on a reporting iteration", "API format"])
+def test_solver_verbosity1_fast_loop(ops, oracle, case):
+    """verbosity 1 = the quiet loop between the reporting iterations 1, 50 k, max_iter (solver.cu:132-133,173): same lines, same arrays,
+    same stopping iteration as the reference's loop, which evaluates everything on every iteration."""
+    from test_reference_fixtures import expected_log
+
+    dims, pg, pn = _run1_inputs(oracle)
+    ident = oracle.new_field(dims)
+    oracle.init_identity(ident)
+    full = oracle.estimate_psi(pg, pn, ident.copy(), max_iter=120, alpha=0.01, w_reg=0.4, verbosity=2, inverse_iters=0)["trace"]
+    assert np.all(np.diff(full[:, 2]) < 0)  # the max norms fall monotonically: a threshold between two of them fires at a known iteration
+    thr = {"break in a quiet run": float(full[60:62, 2].mean()), "break on a reporting iteration": float(full[48:50, 2].mean())}.get(case, -1.0)
+    psi = ident.copy()
+    r = oracle.estimate_psi(pg, pn, psi, max_iter=120, alpha=0.01, w_reg=0.4, verbosity=1, max_update_norm=thr)
+    assert r["iters"] == {"break in a quiet run": 62, "break on a reporting iteration": 50}.get(case, 120)
+    sv = ops.Solver(dims, max_iter=120, alpha=0.01, w_reg=0.4, verbosity=1, max_update_norm=thr)
+    sv.set_compact(case != "API format")
+    psi_d, psi_inv_d, pnp_d, pgi_d = dev(ident), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+    rep, hist = sv.estimate_psi(dev(pg), pgi_d, dev(pn), pnp_d, psi_d, psi_inv_d)
+    assert rep.iterations == r["iters"] and bool(rep.converged) == (thr > 0)
+    assert same(host(psi_d), psi) and same(host(pnp_d), r["phi_n_psi"]) and same(host(psi_inv_d), r["psi_inv"]) and same(host(pgi_d), r["phi_global_psi_inv"])
+    assert same(hist, r["trace"][:, 2])
+    assert "\n".join(sv.log_lines) + "\n" == expected_log(r["trace"], dims, 120, 0.4, thr, 1)
+    n_reports = sum(l.startswith("data energy") for l in sv.log_lines)
+    assert n_reports == {"break in a quiet run": 2, "break on a reporting iteration": 2}.get(case, 4)  # iterations 1, 50, 100, 120
+    last = r["iters"]
+    if last == 1 or last % 50 == 0 or last == 120:
+        assert rep.last_max_update_index == r["trace"][last - 1, 3]
+    else:
+        assert np.isnan(rep.last_max_update_index)  # the reference prints no arg-max for that iteration either
+    k = max(i for i in (1, 50, 100, 120) if i <= last) - 1
+    assert rep.last_e_data == r["trace"][k, 0] and rep.last_e_reg == r["trace"][k, 1]
+    sv.close()
+
+
 def test_solver_convergence_break(ops, oracle):
     """max_update_norm > 0: the device-side gate must stop at exactly the reference's iteration."""
     dims, pg, pn = _run1_inputs(oracle)

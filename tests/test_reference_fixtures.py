@@ -362,7 +362,7 @@ def test_hip_estimate_psi(name):
     f = load(name)
     mi, alpha, w_reg, s, lam, mun, verb = f["params"]
     dims = f["in_psi0"].shape[2::-1]
-    for verbosity, compact in ((int(verb), True), (0, True), (0, False), (2, True)):
+    for verbosity, compact in ((int(verb), True), (0, True), (0, False), (2, True), (2, False), (1, True), (1, False)):
         sv = ops.Solver(dims, max_iter=int(mi), alpha=alpha, w_reg=w_reg, s=int(s), lam=lam, max_update_norm=mun, verbosity=verbosity)
         sv.set_compact(compact)
         psi, psi_inv, pnp, pgi = _dev(f["in_psi0"]), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
