@@ -421,6 +421,14 @@ CORE_READY_AT = None  # every rank: when the timed legs were done (on_core)
 LINE_LOCK = None      # whoever takes it prints THE line (the normal path or the watchdog): exactly one JSON line on stdout either way
 
 
+def _core_line_with(reason):
+    """the early core line, marked: the run did NOT complete its harvest -- `late_failure` says why (the exit code stays 0 so that the
+    measured legs are not lost; a consumer that wants to tell a complete run from a salvaged one reads this key)"""
+    d = json.loads(CORE_LINE)
+    d["late_failure"] = reason
+    return json.dumps(d)
+
+
 def _arm_watchdog(args, rank):
     """--budget-s is a promise about when the line is on stdout.  Once the core of a tiled run's line exists (timed legs + bitwise
     self-checks done: on_core), a run still busy 25 s past its deadline (a harvest collective that never returns, a sick node) prints
@@ -432,16 +440,19 @@ def _arm_watchdog(args, rank):
     if args.deadline is None:
         return
 
+    grace = float(os.environ.get("SOBFU_BENCH_WATCHDOG_GRACE_S", "25"))  # (tests shorten it)
+
     def run():
         while True:
-            if CORE_READY_AT is not None and time.time() > max(args.deadline + 25.0, CORE_READY_AT + 30.0):
+            if CORE_READY_AT is not None and time.time() > max(args.deadline + grace, CORE_READY_AT + grace + 5.0):
                 if not LINE_LOCK.acquire(blocking=False):
                     return  # the normal path is printing the full line
                 if rank == 0 and CORE_LINE is not None:
                     import ctypes
 
                     ctypes.CDLL(None).fflush(None)
-                    print(CORE_LINE, flush=True)
+                    print(_core_line_with("watchdog: still running %.0f s past --budget-s; the harvest behind the timed legs was abandoned"
+                                          % (time.time() - args.deadline)), flush=True)
                 os._exit(0)
             time.sleep(0.5)
 
@@ -543,6 +554,19 @@ def make_line(args, P, res, world, force_tiled, full=True):
     for k in ("tiles", "legs", "tiled_autotune_us", "tiled_diag", "transport", "transport_fallback", "per_frame", "topology"):
         if res.get(k):
             out[k] = res[k]
+    if res.get("legs"):
+        # `value` stays on BASELINE config 4's grid (2 x 2 x 2 at N = 8).  The fastest (grid, transport) this machine showed is a
+        # first-class number beside it: the timed legs on the run's grid, and -- when the harvest ran -- every grid of N tiles on
+        # both transports (a 40-iteration sweep per grid: tiled_autotune_us)
+        here = "x".join(map(str, res["tiles"]["grid"]))
+        cands = [(leg["value"], here, t, "timed leg (the regions `value` is the median of)") for t, leg in res["legs"].items() if leg.get("value")]
+        for t, grids in (res.get("tiled_autotune_us") or {}).items():
+            cands += [(1e6 / us, g, t, "40-iteration sweep of every grid of N tiles (tiled_autotune_us), outside the timed regions") for g, us in grids.items()
+                      if us and g != here]
+        if cands:
+            v, g, t, how = max(cands)
+            out["best_grid"] = {"grid": [int(x) for x in g.split("x")], "transport": t, "value": v, "unit": "iterations/s", "how": how,
+                                "candidates": len(cands)}
     if GPU_STATE is not None:
         out["gpu_state"] = GPU_STATE.report()
     if res.get("tiled_parity") is not None:  # N > 1: every rank re-ran the whole solve alone and compared its tile bitwise
@@ -644,6 +668,8 @@ def main():
 
     out = make_line(args, P, res, world, force_tiled) if rank == 0 else None
     mismatch = res.get("tiled_parity") is False  # every rank holds the same verdict (MIN over ranks)
+    # ... and so does a frame tail on tiles that differs from the same tail on all-gathered sources
+    mismatch = mismatch or ((res.get("per_frame") or {}).get("tail") or {}).get("parity_vs_all_gather_tail") == "MISMATCH"
     if res.get("diag_hung_any"):
         # a diagnostics collective never returned on SOME rank (the verdict was agreed over a side channel that is not the
         # wedged communicator): nobody enters another collective -- every rank reports what was measured and leaves
@@ -687,7 +713,7 @@ def _main_guarded():
             import ctypes
 
             ctypes.CDLL(None).fflush(None)
-            print(CORE_LINE, flush=True)
+            print(_core_line_with("after the timed legs: %r" % (e,)), flush=True)
         mismatch = isinstance(e, SystemExit) and e.code == 3  # a MISMATCH verdict keeps its exit code
         os._exit(3 if mismatch else 0)
 

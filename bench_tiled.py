@@ -415,7 +415,8 @@ def frames_on_tiles(args, ranks, grid, transport, max_frames):
         frame_tail(solver, fu.phi_global, pgi_b, fu.psi, inv_b, gather=gather_fn, halo=None)
         same = torch.equal(L.owned(inv_a)[..., :3].contiguous().view(torch.int32), L.owned(inv_b)[..., :3].contiguous().view(torch.int32)) and \
             torch.equal(L.owned(pgi_a).contiguous().view(torch.int32), L.owned(pgi_b).contiguous().view(torch.int32))
-        tail_ok = ranks.min([1.0 if (same and mode_a == "halo") else 0.0])[0] == 1.0
+        tail_ok = ranks.min([1.0 if same else 0.0])[0] == 1.0  # the BITS decide; which path produced them (halo windows, or the all-gather
+        # fallback when the displacement outgrew a tile) is reported under tail.mode
     solver.close()
     worst = ranks.max(ms)
     timed = [w for w, i in zip(worst, iters) if i > 0] or worst  # frames before START_FRAME only fuse

@@ -357,8 +357,16 @@ typedef struct {
     size_t send_off, recv_off, count; /* in floats */
 } sobfu_hip_tiled_msg;
 /* The messages of one exchange and the boxes (6 ints each: x0, x1, y0, y1, z0, z1, local cells) they are packed from / scattered
- * to; returns their number (z-slabs on the RCCL transport send the same cells as plane ranges of the field itself). */
+ * to; returns their number (z-slabs on the RCCL transport send the same cells as plane ranges of the field itself).
+ * WHAT ACTUALLY TRAVELS on the RCCL / callback transports of a 3-D tile: only the first *n_packed of these messages (x / y faces and
+ * all edge strips) go through the packed send / receive buffers with the offsets and counts listed here.  The z-face messages that
+ * follow them in this list describe the cells (their boxes are right), but they are NOT packed: they travel IN PLACE as 4 whole
+ * padded planes of the nabla_U array (Lx x Ly x 4 cells) -- the list sobfu_hip_tiled_messages_inplace returns, with offsets into the
+ * field itself.  A transport that pre-posts its requests (MPI persistent requests, ...) must build them from BOTH lists. */
 int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int* send_boxes, int* recv_boxes, int max_msgs);
+/* The in-place list of one exchange (3-D tiles: the z faces; empty for z-slabs, whose plane messages are built per call) and, in
+ * *n_packed, how many messages of sobfu_hip_tiled_messages go through the buffers; returns the length of the in-place list. */
+int sobfu_hip_tiled_messages_inplace(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int max_msgs, int* n_packed);
 /* Timing of the SERIAL schedule's pieces with HIP events on the loop's stream around every stride-th iteration (0 = off;
  * max_samples events sets are created here, outside any timed region): ms[0] pass A, ms[1] the exchange (pack + transfer +
  * unpack, including the wait for the peers), ms[2] pass B -- sums over `samples` iterations since the last reset.  Call
@@ -368,9 +376,13 @@ int sobfu_hip_tiled_set_profiling(sobfu_hip_tiled* t, int stride, int max_sample
 int sobfu_hip_tiled_get_profile(sobfu_hip_tiled* t, float ms[3], int* samples, int reset);
 /* Pluggable transport for communicator-less handles (MPI, an in-process loopback for tests, ...).  `exchange` must deliver every
  * message: msgs[i].count floats at d_send + msgs[i].send_off arrive at d_recv + recv_off of the message rank msgs[i].peer posts
- * for this rank (d_send == d_recv for z-slabs, which exchange planes of the field in place); `allreduce_max` must leave the
- * element-wise maximum over all ranks in d_buf.  Both are called on the host in launch order and must order their work
- * after everything already enqueued on `stream` and before anything enqueued on it later. */
+ * for this rank; `allreduce_max` must leave the element-wise maximum over all ranks in d_buf.  Both are called on the host in
+ * launch order and must order their work after everything already enqueued on `stream` and before anything enqueued on it later.
+ * CALLS PER EXCHANGE: z-slabs: one, with d_send == d_recv == the field (planes in place).  3-D tiles: UP TO TWO -- first the packed
+ * list (d_send = the send buffer, d_recv = the receive buffer, the first n_packed messages of sobfu_hip_tiled_messages), then the
+ * in-place list (d_send == d_recv == the nabla_U array, the messages of sobfu_hip_tiled_messages_inplace: whole-plane offsets and
+ * counts); a list that is empty is not called.  A call never carries more than one message per peer; the two calls of one exchange
+ * may name the same peer.  Every rank makes the same sequence of calls, so a transport may match them by call order. */
 typedef int (*sobfu_hip_tiled_exchange_fn)(void* ctx, int rank, const float* d_send, float* d_recv, const sobfu_hip_tiled_msg* msgs,
                                            int n_msgs, void* stream);
 typedef int (*sobfu_hip_tiled_allreduce_fn)(void* ctx, int rank, uint32_t* d_buf, size_t n, void* stream);

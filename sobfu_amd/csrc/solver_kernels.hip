@@ -97,10 +97,7 @@ __global__ void __launch_bounds__(256) update_psi_kernel(float4* __restrict__ ps
 // Part 2: fused two-pass iteration
 // ============================================================================================================
 
-#ifndef SOBFU_TX
-#define SOBFU_TX 64
-#endif
-constexpr int TX = SOBFU_TX;  // tile width in lanes: 64 = one wave per tile row (32: a wave covers two rows of a 32-wide tile)
+constexpr int TX = 64;  // tile width in lanes: one wave per tile row (32-wide tiles measured slower: profiles/LABBOOK.md, round 5)
 
 // --- storage formats ------------------------------------------------------------------------------------------------
 // API format (COMPACT = false): the reference's layouts -- psi / nabla_U float4 (w == 0), TSDF volumes float2.
@@ -132,36 +129,15 @@ SOBFU_DEV void stv(void* base, size_t i, const float4& v) {
 }
 // streaming variants (nontemporal hint) for data a launch touches exactly once: they should not displace the lines that
 // neighbouring workgroups re-read from the XCD's L2 (nabla_U halo rows, phi_n corners)
-#ifndef SOBFU_NT
-#define SOBFU_NT 3  // 1 = pass B stores of psi / phi_n o psi, 2 = + pass B load of psi, 3 = + pass A load of phi_global (4: + nabla_U store, 5: + pass A inner rows: A slower, B faster, no net gain)
+// kNT = 3: pass B's stores of psi / phi_n o psi, its load of psi, and pass A's load of phi_global carry the hint on grids beyond the
+// Infinity Cache (template NTL = kNT; 0 on cache-resident grids).  Hinting the nabla_U store / pass A's inner rows as well was
+// within run-to-run noise (profiles/LABBOOK.md, round 5) and is gone.
 // NB (found in the ISA in round 5): hipcc keeps the hint of __builtin_nontemporal_load / _store on 4-byte accesses (`global_store_dword
 // ... nt`: phi_n o psi, phi_global, F) but DROPS it on the 4-byte-aligned 12-byte vector type -- the 12-byte variants below compile to
 // plain `global_load/store_dwordx3`.  Where the hint on a 12-byte access matters it goes through a buffer instruction, whose cache-policy
-// operand carries it (buf_ld3 / buf_st3: the pipelined march, and the plain march's psi load / store since round 5: template NTBUF,
-// + 3.4 % iterations/s at 256^3).  Levels 4 / 5 were therefore only ever measured on their 4-byte half; with real hints through buffer
-// instructions (round 5, profiles/r05_experiments/nta_ab_256.log) they are within the box's run-to-run noise: not kept.
-#endif
-template <bool C>
-SOBFU_DEV float4 ldv_nt(const void* base, size_t i) {
-    if (C) {
-        v3f v = __builtin_nontemporal_load((const v3f_u*) ((const float*) base + 3 * i));
-        return make_float4(v.x, v.y, v.z, 0.f);
-    }
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f v = __builtin_nontemporal_load((const v4f*) base + i);
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-template <bool C>
-SOBFU_DEV void stv_nt(void* base, size_t i, const float4& v) {
-    if (C) {
-        v3f o = {v.x, v.y, v.z};
-        __builtin_nontemporal_store(o, (v3f_u*) ((float*) base + 3 * i));
-    } else {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        v4f o = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(o, (v4f*) base + i);
-    }
-}
+// operand carries it (buf_ld3 / buf_st3: the pipelined march, and the plain march's psi load / store: template NTBUF, + 3.4 %
+// iterations/s at 256^3).
+constexpr int kNT = 3;
 // The same accesses as (uniform plane pointer) + (32-bit byte offset of the lane's cell in the plane): the address is a scalar base
 // plus one 32-bit lane register (global_load ... v_off, s[base]) instead of a 64-bit lane address per stream.
 template <bool C>
@@ -436,26 +412,14 @@ struct PassAArgs {
     BoxList boxes;  // the cells this launch produces
 };
 
-#ifndef SOBFU_PIN
-#define SOBFU_PIN 2  // bit 0: pass A, bit 1: pass B
-#endif
-#ifndef SOBFU_BG_AHEAD
-#define SOBFU_BG_AHEAD 1  // pass A requests phi_global one plane ahead (0: in the step that uses it)
-#endif
-// The marching loops store under a per-lane "this cell is mine" test, and the compiler sinks everything that consumes the step's
+// Pass B's marching loops store under a per-lane "this cell is mine" test, and the compiler sinks everything that consumes the step's
 // loads into that branch with the stores.  On the path around the branch it must then assume the loads still in flight, so at
 // the join -- the pipeline shift, the next step's halo staging -- it waits for vmcnt(0), which on the path that DID store also
 // waits for the stores' acknowledgement: once per plane per wave, on the critical chain.  Pinning the value about to be stored
 // in front of the branch makes the wait for its loads unconditional (same place: behind the arithmetic), the join then knows
-// that every load has landed, and the stores drain behind the next plane's work.
-template <int BIT>
-SOBFU_DEV void pin3(const float4& v) {
-    if (SOBFU_PIN & BIT) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z));
-}
-template <int BIT>
-SOBFU_DEV void loads_landed() {
-    if (SOBFU_PIN & BIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched (gfx9 encoding)
-}
+// that every load has landed, and the stores drain behind the next plane's work.  (Pass A gains nothing from the same pin: measured,
+// profiles/LABBOOK.md round 4.)
+SOBFU_DEV void pin3(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z)); }
 
 // --- buffer addressing (cache-resident launches) -------------------------------------------------------------------------------
 // A 128-bit buffer resource in SGPRs (base, bytes) + a 32-bit lane byte offset + a scalar byte offset (the plane): an address costs
@@ -543,7 +507,7 @@ struct PushDst {
 };
 SOBFU_DEV void st3_system(float* p, const float4& v);
 
-// NTL: streaming (nontemporal) hints, as SOBFU_NT -- for grids whose state exceeds the 256 MiB Infinity Cache; 0 for cache-resident
+// NTL: streaming (nontemporal) hints, kNT or 0 -- for grids whose state exceeds the 256 MiB Infinity Cache; 0 for cache-resident
 // ones (multi-GPU tiles, small grids), where the hints keep the data the NEXT launch reads out of the cache (2 x 2 x 2 tile of
 // 256^3: 54.4 -> 48.8 us per iteration without them)
 template <int RPT, int WY, bool COMPACT, int NTL, bool PUSHABLE = false>
@@ -612,7 +576,6 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
     if (gate_decide(gate, a.prev_slots, a.max_update_norm)) return;
 
     const bool ulo = (u == 0), uhi = (u == tg.DU - 1);
-    loads_landed<1>();  // the prologue's requests: the loop header then has nothing to wait for on the back edge either
     for (int z = zb; z < ze; ++z) {
         const int buf = (z - zb) & 1;
         // stage plane z
@@ -627,15 +590,9 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
         const size_t zn = (size_t) min(z + 1, d.z - 1) * plane, zcur = (size_t) z * plane;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            if (NTL >= 5 && COMPACT && RPT == 1 && wy > 0 && wy < WY - 1) {  // rows no y-neighbour tile re-reads
-                pn[r] = ldv_nt<COMPACT>(a.psi, zn + off[r]);
-                fn[r] = __builtin_nontemporal_load((const float*) a.pnp + zn + off[r]);
-            } else {
-                pn[r] = ldv<COMPACT>(a.psi, zn + off[r]);
-                fn[r] = ldt<COMPACT>(a.pnp, zn + off[r]);
-            }
-            if (SOBFU_BG_AHEAD) { if (z + 1 < ze) bgn[r] = ld_bg(zn + off[r]); }
-            else bg[r] = ld_bg(zcur + off[r]);
+            pn[r] = ldv<COMPACT>(a.psi, zn + off[r]);
+            fn[r] = ldt<COMPACT>(a.pnp, zn + off[r]);
+            if (z + 1 < ze) bgn[r] = ld_bg(zn + off[r]);
         }
         if (z + 1 < ze) {
 #pragma unroll
@@ -663,7 +620,6 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
             else { prm = t_psi[buf][lr - 1][lx + 1]; frm = prm.w; }
             const float4 o = potential_gradient_cell(pc[r], fc[r], bg[r], plp, plm, prp, prm, pn[r], pm[r], plp.w, plm.w, frp, frm, fn[r], fm[r], ulo,
                                                      uhi, vlo, vhi, zlo, zhi, a.w_reg);
-            pin3<1>(o);
             if (u < tg.u_hi && v < tg.v_hi) {
                 const size_t i = zcur + off[r];  // inside the box no clamp was active: off[r] is the cell itself
                 if (PUSHABLE && pd->base != nullptr) {  // a marching PUSH box: the rows of the message go to their destination ...
@@ -672,8 +628,7 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
                         st3_system(pd->base + 3 * j, o);
                     }
                     if (z >= pd->lz0 && z < pd->lz1) stv<COMPACT>(a.nU, i, o);  // ... and where the box stands in for the owned block, home too
-                } else if (NTL >= 4) stv_nt<COMPACT>(a.nU, i, o);
-                else stv<COMPACT>(a.nU, i, o);
+                } else stv<COMPACT>(a.nU, i, o);
             }
         }
         // shift the z pipeline
@@ -683,7 +638,7 @@ SOBFU_DEV void pass_a_march(const PassACore& a, const TileGeom& tg, const GateRe
             pc[r] = pn[r];
             fm[r] = fc[r];
             fc[r] = fn[r];
-            if (SOBFU_BG_AHEAD) bg[r] = bgn[r];
+            bg[r] = bgn[r];
         }
     }
 }
@@ -914,16 +869,7 @@ struct PassBArgs {
 #ifndef SOBFU_HLEAD_MIN_ZC
 #define SOBFU_HLEAD_MIN_ZC 24  // shortest march (planes) that uses the halo lead
 #endif
-#ifndef SOBFU_IDX32
-#define SOBFU_IDX32 1  // 1: 32-bit byte offsets for the phi_n corner gather of pass B (volumes below 2^30 voxels)
-#endif
-#ifndef SOBFU_PK
-#define SOBFU_PK 1  // 1: packed-fp32 tap arithmetic (v_pk_mul_f32 / v_pk_add_f32) in pass B
-#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef SOBFU_NT_BUF
-#define SOBFU_NT_BUF 1  // 1: the plain march's 12-byte psi load / store go through buffer instructions whose cache-policy operand carries the streaming hint
-#endif
 #ifndef SOBFU_MINW_B
 #define SOBFU_MINW_B 6  // waves/SIMD the register allocator must leave room for: <= 80 VGPR -> 3 workgroups of 8 waves per CU
 #endif
@@ -1122,7 +1068,7 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
             p.x -= uu.x;
             p.y -= uu.y;
             p.z -= uu.z;
-            pin3<2>(p);
+            pin3(p);
             if (mine) {
                 if (owned && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
                 if (st > 0) {  // apply_kernel (vector_fields.cu:95-98) of the plane of the step before
@@ -1151,7 +1097,7 @@ SOBFU_DEV void pass_b_march_pipe(const PassBArgs& a, const TileGeom& tg, const G
 // REAL.  hipcc drops the nontemporal flag of __builtin_nontemporal_load / _store on the 4-byte-aligned 12-byte vector type (found in the
 // ISA in round 5: `global_load_dwordx3 ... off` without `nt`, while the 4-byte phi_n o psi store carries it); the buffer instructions
 // take the hint as an operand.
-template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0, int NTL = SOBFU_NT, bool PIPE = false, bool NTBUF = false>
+template <int RPT, int WY, bool WRITE_UPDATES, bool COMPACT, bool DIRECT_OK, bool IDX32 = false, int HL = 0, int NTL = kNT, bool PIPE = false, bool NTBUF = false>
 // (the API-format instantiations -- 16-byte psi / nabla_U, 8-byte volumes: the launcher-level entry point and set_compact(0) -- get the
 // 128-VGPR budget: at 80 they spilled 12 - 28 B/lane to scratch)
 __global__ void __launch_bounds__(TX* WY, (PIPE || !COMPACT) ? SOBFU_MINW_PIPE : SOBFU_MINW_B) fused_smooth_update_apply_kernel(PassBArgs a) {
@@ -1343,7 +1289,6 @@ __global__ void __launch_bounds__(TX* WY, (PIPE || !COMPACT) ? SOBFU_MINW_PIPE :
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             // the lane-axis sum (l*) and the row-axis sum (r*) are the x and y convolutions
-#if SOBFU_PK
             // packed fp32 math: the {x, y} and {z, w} halves of a cell are adjacent register pairs (ds_read_b128), so each tap is
             // 2 v_pk_mul_f32 + 2 v_pk_add_f32 instead of 3 + 3 scalar ops (the w lane rides along; products are not contracted)
             v2f l01 = {0.f, 0.f}, l23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, z01 = {0.f, 0.f}, z23 = {0.f, 0.f};
@@ -1365,37 +1310,14 @@ __global__ void __launch_bounds__(TX* WY, (PIPE || !COMPACT) ? SOBFU_MINW_PIPE :
             }
             const v2f t01 = (l01 + r01) + z01;
             float tx = t01.x, ty = t01.y, tz = (l23.x + r23.x) + z23.x;
-#else
-            float slx = 0.f, sly = 0.f, slz = 0.f, srx = 0.f, sry = 0.f, srz = 0.f, szx = 0.f, szy = 0.f, szz = 0.f;
-#pragma unroll
-            for (int j = -R; j <= R; ++j) {
-                const float s = a.S.s[R - j];
-                float4 vl = (j == 0) ? q[r][3] : tile[buf][wy * RPT + r + R][lx + R + j];
-                slx += vl.x * s;
-                sly += vl.y * s;
-                slz += vl.z * s;
-                const int rr = r + j;
-                float4 vr = rr < 0 ? yt[rr + R < 0 ? 0 : (rr + R > R - 1 ? R - 1 : rr + R)]
-                                   : (rr >= RPT ? yb[rr - RPT > R - 1 ? R - 1 : (rr - RPT < 0 ? 0 : rr - RPT)]
-                                                : q[rr < 0 ? 0 : (rr >= RPT ? RPT - 1 : rr)][3]);
-                srx += vr.x * s;
-                sry += vr.y * s;
-                srz += vr.z * s;
-                float4 vz = q[r][3 + j];
-                szx += vz.x * s;
-                szy += vz.y * s;
-                szz += vz.z * s;
-            }
-            // ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)
-            float tx = (slx + srx) + szx, ty = (sly + sry) + szy, tz = (slz + srz) + szz;
-#endif
+            // = ((Sx*src) + (Sy*src)) + (Sz*src)  (rows assign, columns +=, depth +=)
             // update_psi_kernel (solver.cu:64-67)
             float4 uu = f4(tx * a.alpha, ty * a.alpha, tz * a.alpha);
             float4 p  = pv[r];
             p.x -= uu.x;
             p.y -= uu.y;
             p.z -= uu.z;
-            pin3<2>(p);
+            pin3(p);
             if (mine[r]) {
                 if (owned[r] && z >= a.own[4] && z < a.own[5]) msq = fmaxf(msq, norm_sq4(uu));
                 // inside the box no clamp was active: off[r] is the cell itself
@@ -1520,12 +1442,9 @@ __global__ void __launch_bounds__(256) msg_scatter_table_kernel(float* __restric
 }  // namespace
 
 // Tile configuration of the fused passes (see DESIGN.md "Kernel tuning").
-#ifndef SOBFU_RPT
-#define SOBFU_RPT 1
-#endif
-#ifndef SOBFU_WY
-#define SOBFU_WY 8
-#endif
+// tile of a workgroup: 64 lanes x 8 waves, one row per wave (rows-per-thread 2 / 4 and 4 / 16 waves were measured in rounds 1 - 2:
+// profiles/LABBOOK.md; the kernels keep RPT / WY as template parameters, the launchers instantiate this one shape)
+constexpr int kRPT = 1, kWY = 8;
 
 namespace sobfu_hip {
 
@@ -1576,7 +1495,7 @@ static int direct_wx(int ex) {
 // workgroup, i.e. many small workgroups that the dispatcher spreads over all CUs.
 // Only where the launch leaves the chip room (pass B of a tile: fewer workgroups than slots) -- in pass A, whose march fills every
 // slot, a thousand one-wave workgroups in front of it cost more than they save (`spread` = false: full workgroups).
-static int direct_wpg(int wx, bool spread) { return spread ? std::max(1, std::min(SOBFU_WY, wx / 4)) : SOBFU_WY; }
+static int direct_wpg(int wx, bool spread) { return spread ? std::max(1, std::min(kWY, wx / 4)) : kWY; }
 static int direct_groups(const LaunchBox& s, int wx, bool spread) {
     const int wyl = 64 / wx, wpg = direct_wpg(wx, spread);
     const long waves = (long) ((s.x1 - s.x0 + wx - 1) / wx) * ((s.y1 - s.y0 + wyl - 1) / wyl) * (s.z1 - s.z0);
@@ -1592,7 +1511,7 @@ static double box_cells(const LaunchBox& s) {
 static int finish_box(Box& b, const LaunchBox& s, int ty, int share, int refill, int zc_override, const char* env, bool spread, bool even = false) {
     b.x0 = s.x0; b.x1 = s.x1; b.y0 = s.y0; b.y1 = s.y1; b.z0 = s.z0; b.z1 = s.z1;
     b.kind = s.direct ? 1 : 0;
-    b.wpg = SOBFU_WY;
+    b.wpg = kWY;
     b.rem = 0;
     b.pair = 0;
     if (s.direct) {
@@ -1649,7 +1568,7 @@ static int finish_boxes(BoxList& L, const LaunchBox* boxes, int n, int ty, int c
 
 int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, float* nU, float w_reg, int X, int Y, int Z, const LaunchBox* boxes,
                         int n, const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact) {
-    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    constexpr int TY = kRPT * kWY;
     bool direct = false;
     for (int i = 0; i < n; ++i) direct = direct || (boxes[i].direct && box_cells(boxes[i]) > 0);
     if (direct) {  // thin boxes: the tile kernel (no messages, no signalling)
@@ -1658,12 +1577,12 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
         return launch_tile_pass_a(pnp, pg, psi, nU, w_reg, X, Y, Z, tb.data(), n, (TileSync*) nullptr, 0, 0, nullptr, 0, zc, stream, compact);
     }
     PassAArgs a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, prev_slots, max_update_norm}, {}};
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 4 * 8 / SOBFU_WY, 2, zc, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * 4 * 8 / kWY, 2, zc, "SOBFU_ZC_A");  // <= 52 VGPR, 22 KB LDS: 4 workgroups of 8 waves per CU
     if (groups == 0) return 0;
-    const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
-    if (compact && cache_resident(X, Y, Z)) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, 0>), grid, block, 0, stream, a);
-    else if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, SOBFU_NT>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((fused_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, 0>), grid, block, 0, stream, a);
+    const dim3 grid((unsigned) groups), block(TX, kWY);
+    if (compact && cache_resident(X, Y, Z)) hipLaunchKernelGGL((fused_potential_gradient_kernel<kRPT, kWY, true, 0>), grid, block, 0, stream, a);
+    else if (compact) hipLaunchKernelGGL((fused_potential_gradient_kernel<kRPT, kWY, true, kNT>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((fused_potential_gradient_kernel<kRPT, kWY, false, 0>), grid, block, 0, stream, a);
     return (int) hipGetLastError();
 }
 
@@ -1671,7 +1590,7 @@ int launch_pass_a_boxes(const float* pnp, const float* pg, const float* psi, flo
 // result goes to `dst` only) are numbered first, then the others.  sync / seq / wait / row: the direct transport's signalling.
 // the launch geometry of a tile's pass A: push boxes first; returns the workgroups (< 0: too many boxes)
 static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, int X, int Y, int Z, int zc) {
-    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    constexpr int TY = kRPT * kWY;
     L.n = 0;
     int live = 0, total = 0;
     for (int i = 0; i < n; ++i) live += (box_cells(boxes[i].box) > 0 && !boxes[i].box.direct && boxes[i].dst == nullptr) ? 1 : 0;
@@ -1686,7 +1605,7 @@ static int fill_tile_boxes(TileBoxList& L, const TileLaunchBox* boxes, int n, in
             // tile is sized for TWO workgroups per CU -- the push boxes take slots too, and at that size 8-plane marches beat the 4-plane ones that
             // filling all four slots per CU would give (2 x 2 x 2 tile of 256^3: pass A 19.8 -> 19.1 us, 1 x 2 x 4: 18.9 -> 17.2)
             const int zc_box = zc > 0 ? zc : ((s.dst != nullptr && !s.box.direct) ? std::min(8, s.box.z1 - s.box.z0) : 0);
-            total += finish_box(t.b, s.box, TY, std::max(256 * (cache_resident(X, Y, Z) ? 2 : 4) * 8 / SOBFU_WY / std::max(live, 1), 1), 2, zc_box,
+            total += finish_box(t.b, s.box, TY, std::max(256 * (cache_resident(X, Y, Z) ? 2 : 4) * 8 / kWY / std::max(live, 1), 1), 2, zc_box,
                                 "SOBFU_ZC_A", false);
             t.push.base = s.dst;  // (member by member: the list is looked up by its bytes, padding included -- the caller zeroed it)
             t.push.ox = s.ox; t.push.oy = s.oy; t.push.oz = s.oz; t.push.px = s.px; t.push.py = s.py;
@@ -1711,13 +1630,14 @@ struct CachedBoxes {
     uint64_t hash;
     TileBoxList* host;  // pinned
     TileBoxList* dev;
-    hipStream_t up_stream;  // the stream the upload was enqueued on ...
-    hipEvent_t uploaded;    // ... and its completion: a launch on ANOTHER stream that finds the entry waits for it (until it is known done)
+    hipEvent_t uploaded;    // completion of the upload: a launch that finds the entry waits for it on its own stream until it is known done
     bool ready;
+    uint64_t retired;       // generation in which the entry left the look-up (graveyard entries)
 };
 constexpr size_t kMaxCachedLists = 256;
 static std::vector<CachedBoxes> g_box_cache, g_box_graveyard;
 static std::mutex g_box_cache_mutex;
+static uint64_t g_box_generation = 0;  // retirements so far
 static uint64_t bytes_hash(const void* p, size_t n) {  // FNV-1a
     const unsigned char* b = (const unsigned char*) p;
     uint64_t h = 1469598103934665603ull;
@@ -1728,7 +1648,7 @@ static int device_boxes(const TileBoxList& L, TileBoxList** out, hipStream_t str
     int dev = 0;
     SOBFU_HIP_TRY(hipGetDevice(&dev));
     const uint64_t h = bytes_hash(&L, sizeof L);
-    std::lock_guard<std::mutex> lock(g_box_cache_mutex);
+    std::unique_lock<std::mutex> lock(g_box_cache_mutex);
     size_t on_dev = 0;
     for (CachedBoxes& c : g_box_cache) {
         if (c.device != dev) continue;
@@ -1736,32 +1656,40 @@ static int device_boxes(const TileBoxList& L, TileBoxList** out, hipStream_t str
         if (c.hash == h && std::memcmp(c.host, &L, sizeof L) == 0) {
             if (!c.ready) {
                 if (hipEventQuery(c.uploaded) == hipSuccess) c.ready = true;
-                else if (stream != c.up_stream) SOBFU_HIP_TRY(hipStreamWaitEvent(stream, c.uploaded, 0));
+                else SOBFU_HIP_TRY(hipStreamWaitEvent(stream, c.uploaded, 0));  // (also on the uploading stream: a no-op there, and a recycled stream handle cannot fool it)
             }
             *out = c.dev;
             return 0;
         }
     }
-    if (on_dev >= kMaxCachedLists) {  // rare: this device's entries retire.  Two generations: what retired LAST time is freed now (after a
-        // device drain), what retires now is only taken out of the look-up -- a thread that has just looked an entry up and is about to
-        // launch with it (the lock is not held across the launch) still finds it alive
+    if (on_dev >= kMaxCachedLists) {  // rare: this device's entries retire.  Two generations: what retired in an EARLIER generation is
+        // freed now, after a device drain; what retires now is only taken out of the look-up -- a thread that has just looked an entry up
+        // and is about to launch with it (the lock is not held across the launch) still finds it alive.  The drain runs WITHOUT the lock:
+        // with in-process ranks on the direct transport a kernel in flight may be waiting for a peer whose host thread needs this cache.
+        const uint64_t gen = g_box_generation;
+        lock.unlock();
         SOBFU_HIP_TRY(hipDeviceSynchronize());
+        lock.lock();
         for (size_t k = 0; k < g_box_graveyard.size();) {
-            if (g_box_graveyard[k].device == dev) {
+            if (g_box_graveyard[k].device == dev && g_box_graveyard[k].retired <= gen) {  // retired before the drain began
                 (void) hipFree(g_box_graveyard[k].dev);
                 (void) hipHostFree(g_box_graveyard[k].host);
                 (void) hipEventDestroy(g_box_graveyard[k].uploaded);
                 g_box_graveyard.erase(g_box_graveyard.begin() + (long) k);
             } else ++k;
         }
-        for (size_t k = 0; k < g_box_cache.size();) {
-            if (g_box_cache[k].device == dev) {
-                g_box_graveyard.push_back(g_box_cache[k]);
-                g_box_cache.erase(g_box_cache.begin() + (long) k);
-            } else ++k;
+        if (g_box_generation == gen) {  // nobody else retired this device's entries while the lock was open
+            g_box_generation += 1;
+            for (size_t k = 0; k < g_box_cache.size();) {
+                if (g_box_cache[k].device == dev) {
+                    g_box_cache[k].retired = g_box_generation;
+                    g_box_graveyard.push_back(g_box_cache[k]);
+                    g_box_cache.erase(g_box_cache.begin() + (long) k);
+                } else ++k;
+            }
         }
     }
-    CachedBoxes c{dev, h, nullptr, nullptr, stream, nullptr, false};
+    CachedBoxes c{dev, h, nullptr, nullptr, nullptr, false, 0};
     hipError_t e = hipHostMalloc((void**) &c.host, sizeof L, hipHostMallocDefault);
     if (e == hipSuccess) {
         std::memcpy(c.host, &L, sizeof L);
@@ -1785,10 +1713,10 @@ static int launch_tile_boxes(const TileBoxList* d_boxes, int groups, const float
                              bool compact) {
     if (groups == 0) return 0;
     TilePassAArgsP a{{pnp, pg, psi, nU, {X, Y, Z}, w_reg, nullptr, 0.f}, d_boxes, {sync, seq, wait, row, row_index}};
-    const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
-    if (compact && cache_resident(X, Y, Z)) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, 0>), grid, block, 0, stream, a);
-    else if (compact) hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, true, SOBFU_NT>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((tile_potential_gradient_kernel<SOBFU_RPT, SOBFU_WY, false, 0>), grid, block, 0, stream, a);
+    const dim3 grid((unsigned) groups), block(TX, kWY);
+    if (compact && cache_resident(X, Y, Z)) hipLaunchKernelGGL((tile_potential_gradient_kernel<kRPT, kWY, true, 0>), grid, block, 0, stream, a);
+    else if (compact) hipLaunchKernelGGL((tile_potential_gradient_kernel<kRPT, kWY, true, kNT>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((tile_potential_gradient_kernel<kRPT, kWY, false, 0>), grid, block, 0, stream, a);
     return (int) hipGetLastError();
 }
 
@@ -1855,13 +1783,13 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
                         float alpha, int X, int Y, int Z, int pX, int pY, int pZ, const int own[6], const LaunchBox* boxes, int n,
                         const uint32_t* prev_slots, float max_update_norm, int zc, hipStream_t stream, bool compact, float* psi_out, int prev_rows,
                         bool sys_acquire) {
-    constexpr int TY = SOBFU_RPT * SOBFU_WY;
+    constexpr int TY = kRPT * kWY;
     PassBArgs a{nU, psi, phi_n, pnp, (float4*) updates, slots, {X, Y, Z}, {}, alpha, {}, prev_slots, max_update_norm, {pX, pY, pZ},
                 {own[0], own[1], own[2], own[3], own[4], own[5]}, prev_rows, psi_out ? psi_out : psi, sys_acquire ? 1 : 0};
     for (int i = 0; i < 7; ++i) a.S.s[i] = taps[i];
     if ((size_t) X * Y * 16 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // in-plane byte offsets are 32-bit
     if (sys_acquire && (size_t) X * Y * Z * 12 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;  // scope-carrying loads are buffer loads: arrays below 4 GiB
-    const bool idx32 = SOBFU_IDX32 && (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB
+    const bool idx32 = (size_t) pX * pY * pZ < ((size_t) 1 << 30);  // tsdf-only phi_n below 4 GiB: 32-bit byte offsets for the corner gather
     // the solver's own format (compact, 32-bit gather offsets, no `updates`): streaming hints only for grids beyond the Infinity
     // Cache; the pipelined march where the launch is latency-bound (cache-resident sizes; SOBFU_PIPE_B=0/1 overrides)
     const bool resident = cache_resident(X, Y, Z);
@@ -1873,7 +1801,7 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
     // workgroups a CU holds: <= 80 VGPR (launch bounds) and 32 - 48 KB LDS: 3 of 8 waves; the pipelined march (<= 128 VGPR): 2
     // cache-resident launches are ONE resident round of workgroups, which lasts as long as its longest march: the planes are
     // split evenly over as many z-chunks as fill the marching workgroups' share of the chip
-    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / SOBFU_WY, 6, zc, "SOBFU_ZC_B", resident && pipe);
+    const int groups = finish_boxes(a.boxes, boxes, n, TY, 256 * (pipe ? 2 : 3) * 8 / kWY, 6, zc, "SOBFU_ZC_B", resident && pipe);
     if (groups == 0) return 0;
     bool direct = false;
     int zc_max = 0;
@@ -1882,21 +1810,21 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
         if (a.boxes.b[i].kind == 0) zc_max = std::max(zc_max, a.boxes.b[i].zc + (a.boxes.b[i].rem > 0 ? 1 : 0));  // the first `rem` chunks march one plane more
         if (a.boxes.b[i].kind == 0 && pipe && resident && SOBFU_PAIR_B) a.boxes.b[i].pair = 1;  // neighbouring z-chunks march towards / away from each other
     }
-    const dim3 grid((unsigned) groups), block(TX, SOBFU_WY);
+    const dim3 grid((unsigned) groups), block(TX, kWY);
 #define SOBFU_LAUNCH_B(UPD, CMP, DIR) \
-    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, UPD, CMP, DIR>), grid, block, 0, stream, a)
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<kRPT, kWY, UPD, CMP, DIR>), grid, block, 0, stream, a)
 #define SOBFU_LAUNCH_BX(DIR, HLV, NTV, PIP) \
-    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, 0, stream, a)
-    const bool ntbuf = SOBFU_NT_BUF && SOBFU_NT >= 1 && (size_t) X * Y * Z * 12 < ((size_t) 1 << 32);  // buffer instructions: arrays below 4 GiB
+    hipLaunchKernelGGL((fused_smooth_update_apply_kernel<kRPT, kWY, false, true, DIR, true, HLV, NTV, PIP>), grid, block, 0, stream, a)
+    const bool ntbuf = (size_t) X * Y * Z * 12 < ((size_t) 1 << 32);  // the plain march's 12-byte psi load / store as buffer instructions (their cache-policy operand carries the streaming hint): arrays below 4 GiB
     if (direct) {
         if (updates && compact) SOBFU_LAUNCH_B(true, true, true);
         else if (updates) SOBFU_LAUNCH_B(true, false, true);
         else if (compact && idx32) {
             if (resident && pipe) SOBFU_LAUNCH_BX(true, 0, 0, true);
             else if (resident) SOBFU_LAUNCH_BX(true, 0, 0, false);
-            else if (pipe) SOBFU_LAUNCH_BX(true, 0, SOBFU_NT, true);
-            else if (ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, true, true, 0, SOBFU_NT, false, SOBFU_NT_BUF != 0>), grid, block, 0, stream, a);
-            else SOBFU_LAUNCH_BX(true, 0, SOBFU_NT, false);
+            else if (pipe) SOBFU_LAUNCH_BX(true, 0, kNT, true);
+            else if (ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<kRPT, kWY, false, true, true, true, 0, kNT, false, true>), grid, block, 0, stream, a);
+            else SOBFU_LAUNCH_BX(true, 0, kNT, false);
         }
         else if (compact) SOBFU_LAUNCH_B(false, true, true);
         else SOBFU_LAUNCH_B(false, false, true);
@@ -1907,13 +1835,13 @@ int launch_pass_b_boxes(const float* nU, float* psi, const float* phi_n, float* 
             // long marches (big grids): halo requests run SOBFU_HLEAD planes ahead; short ones (small grids, multi-GPU tiles) skip
             // the extra prologue round trip
             const bool lead = SOBFU_HLEAD > 0 && zc_max >= SOBFU_HLEAD_MIN_ZC && !resident && !pipe;
-            if (lead && ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, SOBFU_HLEAD, SOBFU_NT, false, SOBFU_NT_BUF != 0>), grid, block, 0, stream, a);
-            else if (lead) SOBFU_LAUNCH_BX(false, SOBFU_HLEAD, SOBFU_NT, false);
+            if (lead && ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<kRPT, kWY, false, true, false, true, SOBFU_HLEAD, kNT, false, true>), grid, block, 0, stream, a);
+            else if (lead) SOBFU_LAUNCH_BX(false, SOBFU_HLEAD, kNT, false);
             else if (resident && pipe) SOBFU_LAUNCH_BX(false, 0, 0, true);
             else if (resident) SOBFU_LAUNCH_BX(false, 0, 0, false);
-            else if (pipe) SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, true);
-            else if (ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<SOBFU_RPT, SOBFU_WY, false, true, false, true, 0, SOBFU_NT, false, SOBFU_NT_BUF != 0>), grid, block, 0, stream, a);
-            else SOBFU_LAUNCH_BX(false, 0, SOBFU_NT, false);
+            else if (pipe) SOBFU_LAUNCH_BX(false, 0, kNT, true);
+            else if (ntbuf) hipLaunchKernelGGL((fused_smooth_update_apply_kernel<kRPT, kWY, false, true, false, true, 0, kNT, false, true>), grid, block, 0, stream, a);
+            else SOBFU_LAUNCH_BX(false, 0, kNT, false);
         }
         else if (compact) SOBFU_LAUNCH_B(false, true, false);
         else SOBFU_LAUNCH_B(false, false, false);

@@ -642,6 +642,10 @@ int sobfu_hip_tiled_exports_get(const sobfu_hip_tiled* t, sobfu_hip_tiled_export
 int sobfu_hip_tiled_connect(sobfu_hip_tiled* t, int n_peers, const int* peer_ranks, const sobfu_hip_tiled_exports* peers) {
     SOBFU_CHECK_ARGS(t && n_peers >= 0 && (n_peers == 0 || (peer_ranks && peers)) && !t->q.active && !t->comm);
     if (t->world > kMaxSync) return SOBFU_E_UNSUPPORTED;
+    // Cells other GPUs stored are read at system scope, which only the pipelined march of pass B does (launch_pass_b_boxes): it needs
+    // 32-bit gather offsets (phi_n below 2^30 voxels) and buffer addressing (the local arrays below 4 GiB).  Refused HERE, not by a
+    // launch in the middle of a solve whose pass A has already pushed into the peers.
+    if ((size_t) t->X * t->Y * t->Z >= ((size_t) 1 << 30) || (size_t) t->L[0] * t->L[1] * t->L[2] * 12 >= ((size_t) 1 << 32)) return SOBFU_E_UNSUPPORTED;
     if (t->grows_own) {  // a longer solve on the unconnected handle moved the rows to a private array: back to the exported ones
         SOBFU_HIP_TRY(hipFree(t->grows_own));
         if (t->slots) SOBFU_HIP_TRY(hipFree(t->slots));
@@ -846,6 +850,15 @@ int sobfu_hip_tiled_messages(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs
         if (recv_boxes) std::memcpy(recv_boxes + 6 * i, t->rboxes.data() + 6 * i, 6 * sizeof(int));
     }
     return n;  // number of messages of an exchange
+}
+
+int sobfu_hip_tiled_messages_inplace(const sobfu_hip_tiled* t, sobfu_hip_tiled_msg* msgs, int max_msgs, int* n_packed) {
+    if (!t) return SOBFU_E_BADARG;
+    if (n_packed) *n_packed = t->n_packed;
+    const int n = (int) t->zmsgs.size();
+    for (int i = 0; i < n && i < max_msgs; ++i)
+        if (msgs) msgs[i] = t->zmsgs[i];
+    return n;
 }
 
 // Delivers the messages of one exchange from d_send to d_recv (RCCL grouped send/recv, or the user transport) and, in the same RCCL

@@ -496,6 +496,13 @@ class NativeTiledSolver:
         if self._connect_group:
             self.connect_ipc()
 
+    def messages_inplace(self):
+        """-> (the in-place message list of one exchange [(peer, send_off, recv_off, count) in floats of the nabla_U array], n_packed):
+        what a pluggable transport sees in the SECOND call of a 3-D tile's exchange (include/sobfu_hip.h, sobfu_hip_tiled_messages_inplace)"""
+        mm, n_packed = (TiledMsg * 18)(), C.c_int(0)
+        n = self._lib.lib().sobfu_hip_tiled_messages_inplace(self._h, mm, 18, C.byref(n_packed))
+        return [(mm[i].peer, mm[i].send_off, mm[i].recv_off, mm[i].count) for i in range(n)], n_packed.value
+
     # -- direct transport ----------------------------------------------------------------------------------------------
     def exports(self):
         e = TiledExports()

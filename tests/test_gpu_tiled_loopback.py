@@ -120,6 +120,65 @@ def run_world(dims, grid, psi0, pg, pn, n_iters, thr, schedule=None):
     return out, full
 
 
+def test_transport_sees_what_the_queries_announce():
+    """the pluggable-transport contract of include/sobfu_hip.h on a 2 x 2 x 2 split: every exchange is TWO calls -- the packed list
+    (send buffer -> receive buffer: the first n_packed messages of sobfu_hip_tiled_messages) and the in-place list (the nabla_U array
+    onto itself: exactly sobfu_hip_tiled_messages_inplace) -- so a transport that pre-posts its requests can build them up front"""
+    import torch
+
+    from sobfu_amd import tiled
+    from sobfu_amd.synthetic import hash_field
+
+    dims, grid = (24, 20, 16), (2, 2, 2)
+    X, Y, Z = dims
+    solvers = [tiled.NativeTiledSolver(dims, alpha=0.05, w_reg=0.4, max_update_norm=-1.0, dry=(8, r), grid=grid) for r in range(8)]
+    lb = Loopback(solvers)
+    calls = [[] for _ in range(8)]
+
+    def spy(rank, send, recv, msgs, stream):
+        calls[rank].append((send == recv, [tuple(m) for m in msgs]))
+        return lb.exchange(rank, send, recv, msgs, stream)
+
+    for s in solvers:
+        s.set_transport(spy, lb.allreduce)
+    pg = hash_field((Z, Y, X, 2), 41, 1.0)
+    pn = hash_field((Z, Y, X, 2), 42, 1.0)
+    psi0 = np.zeros((Z, Y, X, 4), np.float32)
+    psi0[..., 0], psi0[..., 1], psi0[..., 2] = np.arange(X)[None, None, :], np.arange(Y)[None, :, None], np.arange(Z)[:, None, None]
+    pn_d, errs = torch.from_numpy(pn).cuda(), []
+
+    def rank_main(r):
+        try:
+            s = solvers[r]
+            with torch.cuda.stream(torch.cuda.Stream()):
+                s.iterate(torch.from_numpy(np.ascontiguousarray(s.layout.take(pg))).cuda(), pn_d, s.new_local(2),
+                          torch.from_numpy(np.ascontiguousarray(s.layout.take(psi0))).cuda(), 2)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            lb.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for r, s in enumerate(solvers):
+        inplace, n_packed = s.messages_inplace()
+        assert len(inplace) == 1 and n_packed == 5  # x face, y face and the three edge strips through the buffers; the z face in place
+        assert len(s.layout.messages()) == n_packed + len(inplace)
+        assert len(calls[r]) == 4  # two exchanges (one per iteration), two calls each
+        for k in (0, 2):
+            same_base, msgs = calls[r][k]
+            assert not same_base and len(msgs) == n_packed and len({m[0] for m in msgs}) == n_packed  # one message per peer in a call
+            same_base, msgs = calls[r][k + 1]
+            assert same_base and msgs == inplace
+        Lx, Ly = s.layout.L[0], s.layout.L[1]
+        assert all(cnt == 3 * Lx * Ly * 4 for _, _, _, cnt in inplace)  # 4 whole padded planes of 12-byte cells
+        s.close()
+
+
 def run_world_direct(dims, grid, psi0, pg, pn, n_iters, thr, stepped, solves=1, kw=None, keep_halo_lines_hot=False):
     """N ranks on the DIRECT transport in one process.  stepped: one host thread drives all ranks phase by phase (pass A incl.
     the pushes | pass B | ... | end-of-solve handshake) with the in-kernel waits off -- any number of ranks; else one thread
