@@ -20,9 +20,14 @@
  *       warp-field statistics that the reference's own code printed for test/solver_test.cpp:109-132
  *       and for a two-frame depth pipeline; convolution impulse responses).
  * PARITY UNPINNED FOR THE HOT PATH by reference-held vectors: the reference's solver tests assert nothing
- * (test/solver_test.cpp:109-208), so convolution / update / apply / loop / inverse / fusion are pinned by (3)
- * only -- numbers produced by running the reference's sources under a host-emulation shim,
- * which is evidence, not a vector the reference holds.  Marching cubes: pinned by (2) for its tables only.
+ * (test/solver_test.cpp:109-208), so convolution / update / apply / loop / inverse / fusion are tied to the
+ * reference only by (3) and by (4) below -- arrays produced by running the reference's own sources under a
+ * host-emulation shim, which is evidence, not a vector the reference holds (a build through stand-in headers
+ * pins nothing by the task's rules: the parity grade is "partial").  Marching cubes: (2) for its tables, (4).
+ *   (4) tests/golden/ref_*.npz (tests/test_reference_fixtures.py): full arrays of every launcher, of whole
+ *       Solver::estimate_psi runs, of SobFusion::operator() frame by frame and of MarchingCubes::run, computed by
+ *       the reference's source lines under tools/ref_emulation/ and regenerable byte-identically in the build
+ *       container (tests/golden/make_reference_fixtures.py, which also re-derives the numbers of (3)).
  *
  * Arithmetic conventions: IEEE-754 binary32, round-to-nearest, no FTZ,
  * NO floating-point contraction (build with -ffp-contract=off); FMAs only where the reference spells

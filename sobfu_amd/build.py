@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 # solver_kernels.hip: hipcc's SLP vectoriser turns the 7-tap y chain of the compact pass B into <7 x float> shuffles that
 # it lowers through 64 B/lane of scratch (pass B 390 us instead of 180 us at 256^3); without SLP the kernels also need
-# ~30 fewer VGPRs.  Measured, interleaved A/B: DESIGN.md section 4.1.
+# ~30 fewer VGPRs.  Measured, interleaved A/B: profiles/LABBOOK.md section 4.1.
 PER_FILE_FLAGS = {"solver_kernels.hip": ["-fno-slp-vectorize"]}
 
 

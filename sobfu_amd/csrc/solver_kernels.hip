@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(TX* WY, (PIPE || !COMPACT) ? SOBFU_MINW_PIPE :
 
     // Direct transport (a.sys_acquire): the 4-cell halo rims of nabla_U were stored into this GPU's memory by kernels of OTHER GPUs
     // (write-through at system scope, acknowledged before their arrival flag went out; the flag was seen by this rank's pass A before
-    // it retired: DESIGN.md section 6.1).  An invalidate at this kernel's entry (`buffer_inv sc0 sc1` by every wave) was built and
+    // it retired: DESIGN.md section 6.2).  An invalidate at this kernel's entry (`buffer_inv sc0 sc1` by every wave) was built and
     // measured: + 39 us per launch on a 128^3 tile -- waves start at different times and every late invalidate throws away what the
     // early waves had fetched.  Instead the pipelined march reads nabla_U at system scope on such handles (buf_ld3_scope).
     const GateRegs gate = gate_load(a.prev_slots, a.prev_rows, a.sys_acquire != 0);
