@@ -5,6 +5,7 @@ removed at the end -- only arrays come back).
 
     python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run)
     python tests/golden/make_reference_fixtures.py --check    # regenerates into memory and compares with the committed files
+    python tests/golden/make_reference_fixtures.py --check --only=ref_kernels_17x9x5,ref_mc_14x11x9   # a quick subset (the CPU suite runs this)
 
 WHAT THIS EVIDENCE IS: shim evidence.  The emulation needs stand-ins for CUDA / OpenCV / PCL headers the image lacks, so by the
 task's rules it is not a reference build and pins nothing: the oracle's parity grade stays "partial" (DESIGN.md section 2).  It
@@ -282,6 +283,26 @@ def check_appendix_b(fx):
     assert close(c1["stats_psi_f1"][1], a10["l2"]) and close(c1["stats_psi_f1"][2], a10["max"])
 
 
+def make_some(emu, emu_smem, names):
+    """a subset (the quick regeneration check of tests/test_reference_recipe.py): small fixtures only"""
+    fx = {}
+    for n in names:
+        if n == "ref_kernels_17x9x5":
+            fx[n] = kernels_fixture(emu, (17, 9, 5), 911, 1.4)
+            smem = kernels_fixture(emu_smem, (17, 9, 5), 911, 1.4)
+            assert all(np.array_equal(np.asarray(fx[n][k]).view(np.uint8), np.asarray(smem[k]).view(np.uint8)) for k in fx[n])
+        elif n == "ref_solver_20x12x9":
+            d = (20, 12, 9)
+            fx[n] = solver_fixture(emu, d, rand_volume(d, 901), rand_volume(d, 902), warped_identity(d, 903, 0.7), 4, alpha=0.05, w_reg=0.4)
+        elif n == "ref_mc_14x11x9":
+            fx[n] = mc_fixture(emu, (14, 11, 9))
+        elif n == "ref_depth_32x32x32":
+            fx[n] = depth_fixture(emu, (32, 32, 32))
+        else:
+            raise SystemExit("--only knows ref_kernels_17x9x5, ref_solver_20x12x9, ref_mc_14x11x9, ref_depth_32x32x32")
+    return fx
+
+
 def make_all(emu, emu_smem):
     fx = {}
     # per-launcher outputs on the sizes of SURVEY Appendix B run 4 (odd sizes exercise every clamp / partial tile); the two larger
@@ -331,9 +352,10 @@ def make_all(emu, emu_smem):
     return fx
 def main():
     check = "--check" in sys.argv
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
     emu, emu_smem = Emu("610"), Emu(None)
     try:
-        fx = make_all(emu, emu_smem)
+        fx = make_some(emu, emu_smem, only[0]) if only else make_all(emu, emu_smem)
     finally:
         emu.close(), emu_smem.close()
     bad = 0
