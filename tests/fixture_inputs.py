@@ -5,7 +5,7 @@ import hashlib
 
 import numpy as np
 
-from sobfu_amd.synthetic import hash_field
+from sobfu_amd.synthetic import hash_field, render_ellipsoid_depth, render_sphere_depth
 
 F32 = np.float32
 # raw S=7, lambda=0.1 taps of the reference's table (src/sobfu/solver.cpp:190-198), normalised the way decompose_sobolev_filter does
@@ -74,3 +74,16 @@ def mc_volume(dims):
 
 def digest(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8).copy()
+
+
+def snoopy_frame(intr, n):
+    """frame n (0..6) of the synthetic VolumeDeform-style sequence of BASELINE config 2: a breathing, drifting ellipsoid in front of the camera"""
+    a = [0.0, 0.35, 0.7, 1.0, 1.25, 1.32, 1.33][n]
+    c = (0.004 * np.sin(a), 0.003 * (1 - np.cos(a)), 0.50 + 0.003 * a)
+    r = (0.15 * (1 + 0.04 * np.sin(a)), 0.13 * (1 - 0.03 * np.sin(a)), 0.14 * (1 + 0.02 * a))
+    return render_ellipsoid_depth(c, r, intr)
+
+
+def translating_sphere_frame(intr, n, rows=480, cols=640):
+    """frame n of SURVEY 8(d) input 1: a sphere of radius 0.1 m at 0.75 m moving 5 mm along x per frame"""
+    return render_sphere_depth((0.005 * n, 0.0, 0.75), 0.1, intr, rows=rows, cols=cols)

@@ -3,7 +3,8 @@ container through the host emulation of tools/ref_emulation/ (builder-authored s
 + a coroutine block scheduler; the reference's files are compiled where they lie, generated copies live in a temp dir that is
 removed at the end -- only arrays come back).
 
-    python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run)
+    python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run; ~18 min, almost all of it
+                                                              # BASELINE config 3: 50 iterations at 256^3 in a single-threaded emulator)
     python tests/golden/make_reference_fixtures.py --check    # regenerates into memory and compares with the committed files
     python tests/golden/make_reference_fixtures.py --check --only=ref_kernels_17x9x5,ref_mc_14x11x9   # a quick subset (the CPU suite runs this)
 
@@ -35,9 +36,9 @@ sys.path.insert(0, ROOT)
 
 import build as emu_build  # noqa: E402  (tools/ref_emulation/build.py)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from fixture_inputs import (digest, identity, kernel_inputs, mc_volume, rand_volume, sphere_volume,  # noqa: E402  (numpy-only generators)
-                            warped_identity)
-from sobfu_amd.synthetic import render_sphere_depth  # noqa: E402  (pure numpy)
+from fixture_inputs import (digest, identity, kernel_inputs, mc_volume, rand_volume, snoopy_frame, sphere_volume,  # noqa: E402  (numpy-only generators)
+                            translating_sphere_frame, warped_identity)
+from sobfu_amd.synthetic import render_sphere_depth  # noqa: E402,F401  (pure numpy)
 
 F32 = np.float32
 
@@ -153,25 +154,39 @@ def solver_fixture(emu, dims, phi_global, phi_n, psi0, iters, verbosity=2, per_i
     return r
 
 
-def solver_test_fixture(emu):
-    """The set-up of the reference's own test/solver_test.cpp:109-132 (AlignmentTestSphereTranslation), cut to 10 iterations at
-    verbosity 2: 64^3, size 0.25, trunc 10 vox, eta 2 vox, max weight 128, S=7, lambda 0.1, alpha 0.01, w_reg 0.4 -- SURVEY
-    Appendix B run 1.  Digest form; the state after 3 iterations comes from the same run stopped at max_iter = 3."""
-    dims = (64, 64, 64)
-    P = dict(X=64, Y=64, Z=64, size_x=0.25, size_y=0.25, size_z=0.25, trunc_vox=10.0, eta_vox=2.0, max_weight=128.0, s=7, alpha=0.01, w_reg=0.4,
-             max_update_norm=-1.0, verbosity=2, max_iter=10, sphere_cx=0.13, sphere_cy=0.13, sphere_cz=0.13, sphere2_cx=0.125, sphere2_cy=0.13,
-             sphere2_cz=0.13, sphere_r=0.012)
-    P["lambda"] = 0.1
+def sphere_solver_fixture(emu, P, after=None):
+    """Solver::estimate_psi on two initSphere volumes from the identity (the shape of the reference's own test/solver_test.cpp:109-132), in
+    digest form.  after = k: also the state after k iterations (the same deterministic run stopped at max_iter = k)."""
+    dims = (int(P["X"]), int(P["Y"]), int(P["Z"]))
+    P = dict(P)
+    P.setdefault("lambda", 0.1)
     V, Fd = (np.float32, vol_shape(dims)), (np.float32, fld_shape(dims))
     outs = dict(phi_global=V, phi_n=V, psi=Fd, phi_n_psi=V, psi_inv=Fd, phi_global_psi_inv=V)
     r = emu.run("solver", {}, outs, **P)
-    r3 = emu.run("solver", {}, dict(psi=Fd), **dict(P, max_iter=3, verbosity=0))
-    r["psi_after3"] = r3["psi"]
-    r["probe_psi_30_32_32"] = np.stack([r3["psi"][32, 32, 30], r["psi"][32, 32, 30]])
-    c = compact(r, keep=("probe_psi_30_32_32",))
-    c["stats_psi_after3"] = displacement_stats(r3["psi"])
+    X, Y = dims[0], dims[1]
+    probe = (dims[2] // 2, Y // 2, X // 2 - 2)
+    r["probe_psi"] = r["psi"][probe][None].copy()
+    keep = ["probe_psi"]
+    if after:
+        ra = emu.run("solver", {}, dict(psi=Fd), **dict(P, max_iter=after, verbosity=0))
+        r["psi_after%d" % after] = ra["psi"]
+        r["probe_psi"] = np.stack([ra["psi"][probe], r["psi"][probe]])
+    c = compact(r, keep=tuple(keep))
+    if after:
+        c["stats_psi_after%d" % after] = displacement_stats(r["psi_after%d" % after])
     c["params"] = np.array([P[k] for k in sorted(P)], np.float64)
     c["param_names"] = ",".join(sorted(P))
+    return c
+
+
+def solver_test_fixture(emu):
+    """The set-up of the reference's own test/solver_test.cpp:109-132 (AlignmentTestSphereTranslation), cut to 10 iterations at
+    verbosity 2: 64^3, size 0.25, trunc 10 vox, eta 2 vox, max weight 128, S=7, lambda 0.1, alpha 0.01, w_reg 0.4 -- SURVEY
+    Appendix B run 1.  The state after 3 iterations comes from the same run stopped at max_iter = 3."""
+    c = sphere_solver_fixture(emu, dict(X=64, Y=64, Z=64, size_x=0.25, size_y=0.25, size_z=0.25, trunc_vox=10.0, eta_vox=2.0, max_weight=128.0, s=7, alpha=0.01,
+                                        w_reg=0.4, max_update_norm=-1.0, verbosity=2, max_iter=10, sphere_cx=0.13, sphere_cy=0.13, sphere_cz=0.13,
+                                        sphere2_cx=0.125, sphere2_cy=0.13, sphere2_cz=0.13, sphere_r=0.012), after=3)
+    c["probe_psi_30_32_32"] = c.pop("probe_psi")  # voxel (30, 32, 32): the one SURVEY Appendix B quotes
     return c
 
 
@@ -209,14 +224,13 @@ def depth_fixture(emu, dims):
     return r
 
 
-def frames_fixture(emu, P, centres, full_last=True):
-    """SobFusion::operator() (sob_fusion.cpp:71-145) over depth frames of a translating sphere (SURVEY 8(d) input 1).  Every array of
-    every frame in digest form; the last frame's arrays in full when full_last."""
+def frames_fixture(emu, P, depths, full_last=True):
+    """SobFusion::operator() (sob_fusion.cpp:71-145) over a list of depth frames.  Every array of every frame in digest form; the last
+    frame's arrays in full when full_last."""
     dims = (int(P["X"]), int(P["Y"]), int(P["Z"]))
-    n = len(centres)
+    n = len(depths)
     P = dict(P, frames=n)
-    intr = (P["fx"], P["fy"], P["cx"], P["cy"])
-    ins = {"depth_%d" % f: render_sphere_depth(c, 0.1, intr, rows=int(P["rows"]), cols=int(P["cols"])) for f, c in enumerate(centres)}
+    ins = {"depth_%d" % f: d for f, d in enumerate(depths)}
     V, Fd = (np.float32, vol_shape(dims)), (np.float32, fld_shape(dims))
     outs = {}
     for f in range(n):
@@ -336,17 +350,35 @@ def make_all(emu, emu_smem):
     small = dict(DEPTH_P, X=32, Y=32, Z=32, size_x=0.5, size_y=0.5, size_z=0.5, trunc_vox=5.0, eta_vox=2.0, t_z=0.5, max_weight=64.0, start_frame=1, s=7,
                  alpha=0.1, w_reg=0.2, max_iter=12, max_update_norm=1e-4, verbosity=2)
     small["lambda"] = 0.1
-    fx["ref_frames_32x32x32"] = frames_fixture(emu, small, [(0.005 * f, 0.0, 0.75) for f in range(3)])
+    small_intr = (small["fx"], small["fy"], small["cx"], small["cy"])
+    small_depths = [translating_sphere_frame(small_intr, f, rows=small["rows"], cols=small["cols"]) for f in range(3)]
+    fx["ref_frames_32x32x32"] = frames_fixture(emu, small, small_depths)
     # START_FRAME = 2: frame 1 is fused without a solve (sob_fusion.cpp:136-139)
-    fx["ref_frames_gated_32x32x32"] = frames_fixture(emu, dict(small, start_frame=2, max_iter=5), [(0.005 * f, 0.0, 0.75) for f in range(3)], full_last=False)
+    fx["ref_frames_gated_32x32x32"] = frames_fixture(emu, dict(small, start_frame=2, max_iter=5), small_depths, full_last=False)
     # BASELINE config 1 = SURVEY 8(d) input 1 = Appendix B run 2: 64^3, 640 x 480, two frames, 10 iterations (params/config1_sphere_64.ini)
     cfg1 = dict(rows=480, cols=640, fx=570.342, fy=570.342, cx=320.0, cy=240.0, trunc_depth=1.5, bilateral_ksz=7, bilateral_ss=4.5, bilateral_sd=0.005,
                 X=64, Y=64, Z=64, size_x=0.5, size_y=0.5, size_z=0.5, trunc_vox=5.0, eta_vox=2.0, t_z=0.5, max_weight=128.0, start_frame=1, s=7,
                 alpha=0.1, w_reg=0.2, max_iter=10, max_update_norm=-1.0, verbosity=2)
     cfg1["lambda"] = 0.1
-    fx["ref_config1_64"] = frames_fixture(emu, cfg1, [(0.0, 0.0, 0.75), (0.005, 0.0, 0.75)], full_last=False)
-    for k in [k for k in fx["ref_config1_64"] if k.startswith("in_depth")]:  # 640 x 480 inputs: regenerated by the test from synthetic.py
-        fx["ref_config1_64"]["sha256_" + k] = digest(fx["ref_config1_64"].pop(k))
+    cfg1_intr = (cfg1["fx"], cfg1["fy"], cfg1["cx"], cfg1["cy"])
+    fx["ref_config1_64"] = frames_fixture(emu, cfg1, [translating_sphere_frame(cfg1_intr, f) for f in range(2)], full_last=False)
+    # BASELINE config 2: 128^3, params_snoopy.ini values (params/config2_snoopy_128.ini), the 7-frame VolumeDeform-style sequence: frames
+    # 1 - 3 are fused without a solve (START_FRAME 4), frames 4 - 6 solve from a warm-started psi; MAX_ITER capped at 16 as in the GPU tests
+    cfg2 = dict(rows=480, cols=640, fx=517.0, fy=517.0, cx=320.0, cy=240.0, trunc_depth=3.0, bilateral_ksz=7, bilateral_ss=4.5, bilateral_sd=0.01,
+                X=128, Y=128, Z=128, size_x=0.9, size_y=0.9, size_z=0.9, trunc_vox=10.0, eta_vox=5.0, t_z=0.05, max_weight=128.0, start_frame=4, s=7,
+                alpha=0.1, w_reg=0.2, max_iter=16, max_update_norm=1e-3, verbosity=1)
+    cfg2["lambda"] = 0.1
+    fx["ref_config2_128"] = frames_fixture(emu, cfg2, [snoopy_frame((517.0, 517.0, 320.0, 240.0), f) for f in range(7)], full_last=False)
+    for name in ("ref_config1_64", "ref_config2_128"):  # 640 x 480 inputs: regenerated by the tests from tests/fixture_inputs.py
+        for k in [k for k in fx[name] if k.startswith("in_depth")]:
+            fx[name]["sha256_" + k] = digest(fx[name].pop(k))
+    # BASELINE config 3, the roofline config and bench.py's own workload: 256^3, params_boxing.ini solver values, 50 iterations from two
+    # initSphere volumes 1.3 voxels apart (bench.boxing_params / sphere_pair), then the 48-sweep inverse and the canonical warp
+    vs3 = float(F32(0.75) / F32(256))
+    fx["ref_config3_256"] = sphere_solver_fixture(emu, dict(X=256, Y=256, Z=256, size_x=0.75, size_y=0.75, size_z=0.75, trunc_vox=48.0, eta_vox=3.0, max_weight=128.0,
+                                                            s=7, alpha=0.001, w_reg=0.6, max_update_norm=1e-10, verbosity=1, max_iter=50, sphere_cx=0.375,
+                                                            sphere_cy=0.375, sphere_cz=0.375, sphere2_cx=0.375 + 1.3 * vs3, sphere2_cy=0.375, sphere2_cz=0.375,
+                                                            sphere_r=0.2))
     fx["ref_mc_14x11x9"] = mc_fixture(emu, (14, 11, 9))
     check_appendix_b(fx)
     return fx

@@ -73,11 +73,10 @@ def config2():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     P = params.read_ini(os.path.join(ROOT, "params", "config2_snoopy_128.ini"))
 
-    def frame(n):  # the sequence of tests/test_gpu_configs.py::snoopy_frame
-        a = [0.0, 0.35, 0.7, 1.0, 1.25, 1.32, 1.33][n]
-        c = (0.004 * np.sin(a), 0.003 * (1 - np.cos(a)), 0.50 + 0.003 * a)
-        r = (0.15 * (1 + 0.04 * np.sin(a)), 0.13 * (1 - 0.03 * np.sin(a)), 0.14 * (1 + 0.02 * a))
-        return synthetic.render_ellipsoid_depth(c, r, P["intr"])
+    from fixture_inputs import snoopy_frame
+
+    def frame(n):
+        return snoopy_frame(P["intr"], n)
 
     depths = [frame(n) for n in range(7)]
     return lambda: run_frames(P, depths, 16)

@@ -52,11 +52,12 @@ def same(a, b):
 
 
 def snoopy_frame(P, n):
-    """frame n of the synthetic VolumeDeform-style sequence: a breathing, drifting ellipsoid in front of the camera"""
-    a = [0.0, 0.35, 0.7, 1.0, 1.25, 1.32, 1.33][n]
-    c = (0.004 * np.sin(a), 0.003 * (1 - np.cos(a)), 0.50 + 0.003 * a)
-    r = (0.15 * (1 + 0.04 * np.sin(a)), 0.13 * (1 - 0.03 * np.sin(a)), 0.14 * (1 + 0.02 * a))
-    return synthetic.render_ellipsoid_depth(c, r, P["intr"])
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fixture_inputs import snoopy_frame as frame
+
+    return frame(P["intr"], n)
 
 
 @pytest.mark.parametrize("threshold", ["ini", 0.08])

@@ -98,7 +98,7 @@ def test_fixture_inventory():
     names = sorted(n[:-4] for n in os.listdir(G) if n.startswith("ref_") and n.endswith(".npz"))
     assert names == sorted(["ref_kernels_%dx%dx%d" % d for d in KERNEL_DIMS] + SOLVER_NAMES +
                            ["ref_solver_test_64", "ref_tsdf_30x24x18", "ref_depth_32x32x32", "ref_frames_32x32x32", "ref_frames_gated_32x32x32",
-                            "ref_config1_64", "ref_mc_14x11x9"])
+                            "ref_config1_64", "ref_config2_128", "ref_config3_256", "ref_mc_14x11x9"])
     assert sum(os.path.getsize(os.path.join(G, n + ".npz")) for n in names) < 4 << 20  # small fixtures
 
 
@@ -181,6 +181,34 @@ def test_oracle_solver_test_setup_64(oracle):
     assert same(psi[32, 32, 30], f["probe_psi_30_32_32"][1])
 
 
+def _sphere_pair(O, P, dims):
+    _, vs, trunc, eta = _tsdf_params(P, dims)
+    pg, pn = O.new_volume(dims), O.new_volume(dims)
+    O.init_sphere(pg, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    O.init_sphere(pn, vs, trunc, eta, (P["sphere2_cx"], P["sphere2_cy"], P["sphere2_cz"]), P["sphere_r"])
+    return pg, pn
+
+
+def test_oracle_config3_256(oracle):
+    """BASELINE config 3 = bench.py's workload: 256^3, params_boxing.ini solver values, 50 iterations from two initSphere volumes, the
+    48-sweep inverse and the canonical warp -- against the digests of the reference's own Solver::estimate_psi under emulation"""
+    import bench
+
+    f = load("ref_config3_256")
+    P, dims = f["P"], (256, 256, 256)
+    B = bench.boxing_params(256)
+    c0, c1, r = bench.sphere_pair(B)
+    assert (P["sphere_cx"], P["sphere2_cx"], P["sphere_r"], P["alpha"], P["w_reg"], P["max_update_norm"]) == (c0[0], c1[0], r, B["alpha"], B["w_reg"], B["max_update_norm"])
+    pg, pn = _sphere_pair(oracle, P, dims)
+    check(f, "phi_global", pg), check(f, "phi_n", pn)
+    psi = FI.identity(dims)
+    res = oracle.estimate_psi(pg, pn, psi, max_iter=50, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=P["max_update_norm"], verbosity=1)
+    for k, v in (("psi", psi), ("phi_n_psi", res["phi_n_psi"]), ("psi_inv", res["psi_inv"]), ("phi_global_psi_inv", res["phi_global_psi_inv"])):
+        check(f, k, v)
+    assert expected_log(res["trace"], dims, 50, P["w_reg"], P["max_update_norm"], 1) == f["log"]
+    assert same(psi[128, 128, 126][None], f["probe_psi"])
+
+
 def _tsdf_params(P, dims):
     size = np.array([P["size_x"], P["size_y"], P["size_z"]], np.float32)
     vs = (size / np.array(dims, np.float32)).astype(np.float32)  # Params::voxel_sizes
@@ -257,11 +285,17 @@ class OracleFusion:
 
 
 def _frame_inputs(f, n):
+    """the depth frames the emulation consumed: stored, or regenerated by tests/fixture_inputs.py and checked against their digests"""
     P = f["P"]
     intr = (P["fx"], P["fy"], P["cx"], P["cy"])
     out = []
     for i in range(n):
-        d = f["in_depth_%d" % i] if "in_depth_%d" % i in f else render_sphere_depth((0.005 * i, 0.0, 0.75), 0.1, intr, rows=int(P["rows"]), cols=int(P["cols"]))
+        if "in_depth_%d" % i in f:
+            d = f["in_depth_%d" % i]
+        elif n == 7:  # BASELINE config 2's sequence
+            d = FI.snoopy_frame(intr, i)
+        else:
+            d = FI.translating_sphere_frame(intr, i, rows=int(P["rows"]), cols=int(P["cols"]))
         check(f, "in_depth_%d" % i, d)
         out.append(d)
     return out
@@ -282,9 +316,10 @@ def _check_frames(f, fusion_factory, host=np.asarray):
     return fu
 
 
-@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64"])
+@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128"])
 def test_oracle_frame_pipeline(oracle, name):
-    """every volume and field of every frame of SobFusion::operator(), and every line it printed; ref_config1_64 is BASELINE config 1"""
+    """every volume and field of every frame of SobFusion::operator(), and every line it printed; ref_config1_64 / ref_config2_128 are
+    BASELINE configs 1 and 2 (config 2: seven frames, START_FRAME 4, psi warm-started from frame to frame, MAX_ITER capped at 16)"""
     f = load(name)
     fu = _check_frames(f, lambda P: OracleFusion(oracle, P))
     assert fu.log == f["log"]
@@ -409,6 +444,34 @@ def test_hip_solver_test_setup_64():
 
 
 @pytest.mark.gpu
+def test_hip_config3_256():
+    """the bench's own workload on the bench's own code path (default configuration) against the reference's Solver::estimate_psi under
+    emulation: 50 iterations + inverse + warp at 256^3, digests of psi, phi_n o psi, psi^-1, phi_global o psi^-1, and the log"""
+    import torch
+
+    import oracle as O
+    from sobfu_amd import ops
+
+    if torch.cuda.mem_get_info()[0] < 8 * 2 ** 30:
+        pytest.skip("needs ~4 GiB of HBM")
+    f = load("ref_config3_256")
+    P, dims = f["P"], (256, 256, 256)
+    pg, pn = _sphere_pair(O, P, dims)  # the reference's volumes (libm powf), rebuilt on the CPU and checked against the fixture
+    check(f, "phi_global", pg), check(f, "phi_n", pn)
+    for verbosity in (1, 0):
+        sv = ops.Solver(dims, max_iter=50, alpha=P["alpha"], w_reg=P["w_reg"], max_update_norm=P["max_update_norm"], verbosity=verbosity)
+        psi, psi_inv, pnp, pgi = _dev(FI.identity(dims)), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+        rep, _ = sv.estimate_psi(_dev(pg), pgi, _dev(pn), pnp, psi, psi_inv)
+        assert rep.iterations == 50
+        for k, v in (("psi", psi), ("phi_n_psi", pnp), ("psi_inv", psi_inv), ("phi_global_psi_inv", pgi)):
+            check(f, k, v)
+        if verbosity == 1:
+            assert "\n".join(sv.log_lines) + "\n" == f["log"]
+        sv.close()
+        del psi, psi_inv, pnp, pgi
+
+
+@pytest.mark.gpu
 def test_hip_tsdf_builders():
     from sobfu_amd import ops
 
@@ -471,7 +534,7 @@ class HipFusion:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64"])
+@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128"])
 def test_hip_frame_pipeline(name):
     """the product's frame driver against every array of the reference's SobFusion::operator().  The bilateral filter uses the
     device's expf; on these inputs its output is identical to the reference's (asserted through phi_global of frame 0 being

@@ -1,6 +1,6 @@
 // Block scheduler for the host emulation (see shim/cuda_runtime.h for what this is and is not).
 //
-// A launch runs its blocks one after another; the threads of a block are ucontext coroutines.  __syncthreads() and the warp
+// A launch runs its blocks one after another; the threads of a block are coroutines (a small hand-written switch on x86-64, ucontext elsewhere).  __syncthreads() and the warp
 // exchanges switch back to the scheduler, which resumes every live thread once per phase in thread-id order and sets
 // threadIdx before each resume.  A thread that returns early simply stops taking part (the reference's kernels return
 // before barriers only for threads that no later phase depends on).  Warp-synchronous code without a barrier would NOT be
@@ -18,12 +18,52 @@ uint3 tIdx, bIdx;
 dim3 bDim, gDim;
 
 namespace {
+// Context switch.  x86-64: a dozen instructions (callee-saved registers, MXCSR / x87 control word, the stack pointer) instead of
+// swapcontext's two signal-mask system calls -- the convolution kernels alone make millions of switches per launch at 128^3 and up.
+// Elsewhere: ucontext.
+#if defined(__x86_64__)
+extern "C" void cuemu_switch(void** save_sp, void* load_sp);
+__asm__(R"(
+    .text
+    .globl cuemu_switch
+    .type cuemu_switch, @function
+cuemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size cuemu_switch, .-cuemu_switch
+)");
+struct Thread {
+    void* sp;
+    bool done;
+};
+void* sched_sp;
+#else
 struct Thread {
     ucontext_t ctx;
     bool done;
 };
-enum { kStack = 256 << 10 };
 ucontext_t sched;
+#endif
+enum { kStack = 256 << 10 };
 std::vector<Thread> threads;
 std::vector<void*> stacks;
 std::vector<unsigned long long> xbuf;  // one exchange slot per thread
@@ -31,10 +71,48 @@ std::vector<char> smem(64 << 10);
 body cur_body;
 int cur = -1, n_threads = 0;
 
+void to_scheduler() {
+#if defined(__x86_64__)
+    cuemu_switch(&threads[cur].sp, sched_sp);
+#else
+    swapcontext(&threads[cur].ctx, &sched);
+#endif
+}
 void trampoline() {
     cur_body.fn(cur_body.closure);
     threads[cur].done = true;
-    swapcontext(&threads[cur].ctx, &sched);
+    to_scheduler();
+    abort();  // a finished thread is never resumed
+}
+void prepare(int t) {  // thread t will start in trampoline() on its own stack when first resumed
+    threads[t].done = false;
+#if defined(__x86_64__)
+    // what cuemu_switch pops: [mxcsr | x87 cw] r15 r14 r13 r12 rbx rbp <return address>; after its `ret` the stack pointer must
+    // be 8 modulo 16, as at any function entry
+    uintptr_t top = ((uintptr_t) stacks[t] + kStack) & ~(uintptr_t) 15;
+    void** sp     = (void**) (top - 8);  // where rsp points after the `ret`
+    *--sp         = (void*) &trampoline;
+    for (int k = 0; k < 6; ++k) *--sp = nullptr;
+    --sp;
+    unsigned int csr = 0x1F80;  // default MXCSR; default x87 control word
+    unsigned short cw = 0x037F;
+    memcpy((char*) sp, &csr, 4);
+    memcpy((char*) sp + 4, &cw, 2);
+    threads[t].sp = sp;
+#else
+    getcontext(&threads[t].ctx);
+    threads[t].ctx.uc_stack.ss_sp   = stacks[t];
+    threads[t].ctx.uc_stack.ss_size = kStack;
+    threads[t].ctx.uc_link          = 0;
+    makecontext(&threads[t].ctx, trampoline, 0);
+#endif
+}
+void resume(int t) {
+#if defined(__x86_64__)
+    cuemu_switch(&sched_sp, threads[t].sp);
+#else
+    swapcontext(&sched, &threads[t].ctx);
+#endif
 }
 void set_tid(int t) {
     cur    = t;
@@ -59,26 +137,19 @@ void launch_impl(const cfg& c, body b) {
         for (unsigned gy = 0; gy < c.grid.y; ++gy)
             for (unsigned gx = 0; gx < c.grid.x; ++gx) {
                 bIdx = uint3{gx, gy, gz};
-                for (int t = 0; t < n_threads; ++t) {
-                    getcontext(&threads[t].ctx);
-                    threads[t].ctx.uc_stack.ss_sp   = stacks[t];
-                    threads[t].ctx.uc_stack.ss_size = kStack;
-                    threads[t].ctx.uc_link          = 0;
-                    threads[t].done                 = false;
-                    makecontext(&threads[t].ctx, trampoline, 0);
-                }
+                for (int t = 0; t < n_threads; ++t) prepare(t);
                 for (int live = n_threads; live;)
                     for (int t = 0; t < n_threads; ++t)
                         if (!threads[t].done) {
                             set_tid(t);
-                            swapcontext(&sched, &threads[t].ctx);
+                            resume(t);
                             if (threads[t].done) --live;
                         }
             }
     cur = -1;
 }
 
-void syncthreads() { swapcontext(&threads[cur].ctx, &sched); }
+void syncthreads() { to_scheduler(); }
 void* dynamic_smem() { return smem.data(); }
 
 // lane src of the caller's warp, as it was when that lane made the same call; the caller's own value when src is outside
