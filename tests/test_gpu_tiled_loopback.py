@@ -781,6 +781,31 @@ def test_config4_256_cubed_on_2x2x2_tiles_direct_transport():
     assert np.array_equal(pnp_t.view(np.uint32), pnp_r.cpu().numpy().view(np.uint32))
 
 
+def test_config4_tiles_against_the_emulated_reference_256():
+    """BASELINE config 4 against the reference's own Solver::estimate_psi under emulation (tests/golden/ref_config3_256.npz: config 4 is
+    config 3's workload on tiles): 2 x 2 x 2 tiles of 128^3 on the direct transport, 50 iterations with the ini's threshold live; the
+    assembled psi and phi_n o psi hash to the digests of the reference's arrays."""
+    import torch
+
+    import oracle as O
+    from test_reference_fixtures import _sphere_pair, check, load
+
+    if torch.cuda.mem_get_info()[0] < 24 * 2 ** 30:
+        pytest.skip("needs ~16 GiB of HBM")
+    f = load("ref_config3_256")
+    P, dims = f["P"], (256, 256, 256)
+    pg, pn = _sphere_pair(O, P, dims)  # the reference's input volumes (libm powf), checked against the fixture
+    check(f, "phi_global", pg), check(f, "phi_n", pn)
+    psi0 = np.zeros((256, 256, 256, 4), np.float32)
+    psi0[..., 0], psi0[..., 1], psi0[..., 2] = np.arange(256)[None, None, :], np.arange(256)[None, :, None], np.arange(256)[:, None, None]
+    kw = dict(alpha=P["alpha"], w_reg=P["w_reg"], s=7, lam=0.1)
+    out, (psi_t, pnp_t) = run_world_direct(dims, (2, 2, 2), psi0, pg, pn, 50, P["max_update_norm"], True, 1, kw)
+    assert all(done == 50 for done, _, _, _ in out)
+    psi4 = np.zeros_like(psi0)
+    psi4[..., :3] = psi_t[..., :3]  # (the w lane of the reference's psi is 0; the tiles carry xyz)
+    check(f, "psi", psi4), check(f, "phi_n_psi", pnp_t)
+
+
 def test_box_list_cache_turnover_leaves_live_handles_alone():
     """A process that keeps creating tile handles keeps creating box lists; the library's cache of their device copies is bounded
     (256 per device) and retires its entries when full.  A handle that was created BEFORE the turnover -- its planned pass-A launches
