@@ -87,3 +87,9 @@ def snoopy_frame(intr, n):
 def translating_sphere_frame(intr, n, rows=480, cols=640):
     """frame n of SURVEY 8(d) input 1: a sphere of radius 0.1 m at 0.75 m moving 5 mm along x per frame"""
     return render_sphere_depth((0.005 * n, 0.0, 0.75), 0.1, intr, rows=rows, cols=cols)
+
+
+def bench_sequence_frame(intr, size, t_z, vx, n):
+    """frame n of the sequence bench.py's per-frame pipeline uses (bench_frames): a sphere of radius 0.2 * size in the middle of the
+    volume's depth range, translating 1.3 voxels per frame"""
+    return render_sphere_depth((1.3 * vx * n, 0.0, t_z + 0.5 * size), 0.2 * size, intr)

@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 import build as emu_build  # noqa: E402  (tools/ref_emulation/build.py)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from fixture_inputs import (digest, identity, kernel_inputs, mc_volume, rand_volume, snoopy_frame, sphere_volume,  # noqa: E402  (numpy-only generators)
+from fixture_inputs import (bench_sequence_frame, digest, identity, kernel_inputs, mc_volume, rand_volume, snoopy_frame, sphere_volume,  # noqa: E402  (numpy-only generators)
                             translating_sphere_frame, warped_identity)
 from sobfu_amd.synthetic import render_sphere_depth  # noqa: E402,F401  (pure numpy)
 
@@ -312,13 +312,34 @@ def make_some(emu, emu_smem, names):
             fx[n] = mc_fixture(emu, (14, 11, 9))
         elif n == "ref_depth_32x32x32":
             fx[n] = depth_fixture(emu, (32, 32, 32))
+        elif n == "ref_config5_values_96":
+            fx[n] = make_all(emu, emu_smem, only_config5=True)[n]
         else:
             raise SystemExit("--only knows ref_kernels_17x9x5, ref_solver_20x12x9, ref_mc_14x11x9, ref_depth_32x32x32")
     return fx
 
 
-def make_all(emu, emu_smem):
+def _config5(emu, fx):
+    # BASELINE config 5's parameter set (params_umbrella.ini values, params/config5_umbrella_512.ini) on a grid the emulation can run: 96^3
+    # (the voxel-unit parameters follow the voxel size, as apps/sobfu_headless --dims does), bench.py's own depth sequence, 6 iterations
+    # per frame.  The 512^3 size itself is covered HIP-vs-oracle (tests/test_gpu_configs.py::test_config5_512_vs_oracle).
+    cfg5 = dict(rows=480, cols=640, fx=570.342, fy=570.342, cx=320.0, cy=240.0, trunc_depth=1.5, bilateral_ksz=7, bilateral_ss=4.5, bilateral_sd=0.04,
+                X=96, Y=96, Z=96, size_x=1.0, size_y=1.0, size_z=1.0, trunc_vox=8.0, eta_vox=3.0, t_z=0.3, max_weight=128.0, start_frame=1, s=7,
+                alpha=0.001, w_reg=0.2, max_iter=6, max_update_norm=1e-10, verbosity=2)
+    cfg5["lambda"] = 0.1
+    vx5 = float(F32(1.0) / F32(96))
+    fx["ref_config5_values_96"] = frames_fixture(emu, cfg5, [bench_sequence_frame((570.342, 570.342, 320.0, 240.0), 1.0, 0.3, vx5, f) for f in range(3)],
+                                                 full_last=False)
+    k5 = "ref_config5_values_96"
+    for k in [k for k in fx[k5] if k.startswith("in_depth")]:
+        fx[k5]["sha256_" + k] = digest(fx[k5].pop(k))
+    return fx
+
+
+def make_all(emu, emu_smem, only_config5=False):
     fx = {}
+    if only_config5:
+        return _config5(emu, fx)
     # per-launcher outputs on the sizes of SURVEY Appendix B run 4 (odd sizes exercise every clamp / partial tile); the two larger
     # grids in digest form (their inputs are regenerated by tests/fixture_inputs.py from the seed in params)
     for dims, seed, amp, full in (((17, 9, 5), 911, 1.4, True), ((20, 12, 9), 921, 0.7, True), ((40, 24, 20), 931, 2.5, False), ((32, 32, 32), 941, 0.9, False)):
@@ -369,6 +390,7 @@ def make_all(emu, emu_smem):
                 alpha=0.1, w_reg=0.2, max_iter=16, max_update_norm=1e-3, verbosity=1)
     cfg2["lambda"] = 0.1
     fx["ref_config2_128"] = frames_fixture(emu, cfg2, [snoopy_frame((517.0, 517.0, 320.0, 240.0), f) for f in range(7)], full_last=False)
+    _config5(emu, fx)
     for name in ("ref_config1_64", "ref_config2_128"):  # 640 x 480 inputs: regenerated by the tests from tests/fixture_inputs.py
         for k in [k for k in fx[name] if k.startswith("in_depth")]:
             fx[name]["sha256_" + k] = digest(fx[name].pop(k))

@@ -98,7 +98,7 @@ def test_fixture_inventory():
     names = sorted(n[:-4] for n in os.listdir(G) if n.startswith("ref_") and n.endswith(".npz"))
     assert names == sorted(["ref_kernels_%dx%dx%d" % d for d in KERNEL_DIMS] + SOLVER_NAMES +
                            ["ref_solver_test_64", "ref_tsdf_30x24x18", "ref_depth_32x32x32", "ref_frames_32x32x32", "ref_frames_gated_32x32x32",
-                            "ref_config1_64", "ref_config2_128", "ref_config3_256", "ref_mc_14x11x9"])
+                            "ref_config1_64", "ref_config2_128", "ref_config3_256", "ref_config5_values_96", "ref_mc_14x11x9"])
     assert sum(os.path.getsize(os.path.join(G, n + ".npz")) for n in names) < 4 << 20  # small fixtures
 
 
@@ -294,6 +294,8 @@ def _frame_inputs(f, n):
             d = f["in_depth_%d" % i]
         elif n == 7:  # BASELINE config 2's sequence
             d = FI.snoopy_frame(intr, i)
+        elif int(P["X"]) == 96:  # config 5's values on 96^3: bench.py's own sequence
+            d = FI.bench_sequence_frame(intr, float(P["size_x"]), float(P["t_z"]), float(np.float32(P["size_x"]) / np.float32(P["X"])), i)
         else:
             d = FI.translating_sphere_frame(intr, i, rows=int(P["rows"]), cols=int(P["cols"]))
         check(f, "in_depth_%d" % i, d)
@@ -316,7 +318,7 @@ def _check_frames(f, fusion_factory, host=np.asarray):
     return fu
 
 
-@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128"])
+@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128", "ref_config5_values_96"])
 def test_oracle_frame_pipeline(oracle, name):
     """every volume and field of every frame of SobFusion::operator(), and every line it printed; ref_config1_64 / ref_config2_128 are
     BASELINE configs 1 and 2 (config 2: seven frames, START_FRAME 4, psi warm-started from frame to frame, MAX_ITER capped at 16)"""
@@ -534,7 +536,7 @@ class HipFusion:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128"])
+@pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128", "ref_config5_values_96"])
 def test_hip_frame_pipeline(name):
     """the product's frame driver against every array of the reference's SobFusion::operator().  The bilateral filter uses the
     device's expf; on these inputs its output is identical to the reference's (asserted through phi_global of frame 0 being
