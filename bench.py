@@ -43,6 +43,18 @@ C_PASS_A = 32           # F r4 + G r4 + psi r12 + nabla_U w12
 C_ITER = C_PASS_A + C_PASS_B
 
 
+def kernel_source_sha256():
+    """SHA-256 of the iteration kernels' source: solver_kernels.hip and the parts it includes (what profiles/pmc_latest.json is stamped with)"""
+    import hashlib
+
+    d = os.path.join(ROOT, "sobfu_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ["solver_kernels.hip"] + sorted(f for f in os.listdir(d) if f.startswith("solver_") and f.endswith(".inl")):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def boxing_params(dim):
     """params/params_boxing.ini with VOL_DIMS overridden (SURVEY 8(d) input 3)."""
     size = np.float32(0.75)
@@ -482,8 +494,7 @@ def make_line(args, P, res, world, force_tiled, full=True):
             with open(path) as f:
                 pj = json.load(f)
             pmc, pmc_file = pj.get("pass_b_hbm_bytes_per_launch"), "profiles/" + name
-            with open(os.path.join(ROOT, "sobfu_amd", "csrc", "solver_kernels.hip"), "rb") as f:
-                pmc_stale = pj.get("kernel_source_sha256") != hashlib.sha256(f.read()).hexdigest()  # measured on other kernels?
+            pmc_stale = pj.get("kernel_source_sha256") != kernel_source_sha256()  # measured on other kernels?
     NL = res.get("launch_cells") or N  # cells one launch produces on one GPU (the largest tile's owned cells when tiled)
     ach_b = gbps(NL * B_PASS_B, ms_b)
     phys_b = gbps(NL * C_PASS_B, ms_b)

@@ -40,7 +40,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_hip(force: bool = False, extra_flags=(), verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(ROOT, "include", "sobfu_hip.h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".inl"))] + [os.path.join(ROOT, "include", "sobfu_hip.h")]
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs, jobs = [], []
     for src in SOURCES:

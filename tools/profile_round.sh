@@ -19,8 +19,11 @@ for db in sorted(glob.glob("$O/pmc*/r_results.db")):
     for name, cn, avg, n in c.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events where name like '%fused_%' group by name, counter_name"):
         k = "pass_a" if "potential" in name else "pass_b"
         rows.setdefault(k, {})[cn] = avg
-import hashlib
-out = {"kernel_source_sha256": hashlib.sha256(open("$R/sobfu_amd/csrc/solver_kernels.hip", "rb").read()).hexdigest(),
+import hashlib, os
+h = hashlib.sha256()  # solver_kernels.hip and the parts it includes (bench.kernel_source_sha256)
+for name in ["solver_kernels.hip"] + sorted(f for f in os.listdir("$R/sobfu_amd/csrc") if f.startswith("solver_") and f.endswith(".inl")):
+    h.update(open("$R/sobfu_amd/csrc/" + name, "rb").read())
+out = {"kernel_source_sha256": h.hexdigest(),
        "note": "rocprofv3 --pmc, one counter set per run, averages per launch at 256^3; FETCH_SIZE/WRITE_SIZE in KiB. "
                "Correction factors MEASURED on this part with streaming copies of known size in the kernels' own access widths "
                "(12-byte dwordx3, 4-byte dword, 16-byte; plain and nontemporal -- tools/calibrate_counters.sh, "
