@@ -3,8 +3,8 @@ container through the host emulation of tools/ref_emulation/ (builder-authored s
 + a coroutine block scheduler; the reference's files are compiled where they lie, generated copies live in a temp dir that is
 removed at the end -- only arrays come back).
 
-    python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run; ~18 min, almost all of it
-                                                              # BASELINE config 3: 50 iterations at 256^3 in a single-threaded emulator)
+    python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run; ~3 min on 8 cores, most of it
+                                                              # BASELINE config 3: 50 iterations at 256^3 under emulation)
     python tests/golden/make_reference_fixtures.py --check    # regenerates into memory and compares with the committed files
     python tests/golden/make_reference_fixtures.py --check --only=ref_kernels_17x9x5,ref_mc_14x11x9   # a quick subset (the CPU suite runs this)
 

@@ -4,7 +4,7 @@ What happens, all inside a scratch directory (default: a fresh tempfile.mkdtemp(
 
   1. the reference's .cu files are copied and their `kernel<<<cfg>>>(args);` launch statements are rewritten, by ONE regular
      expression, into `CUEMU_LAUNCH((kernel), (cfg), (args));` -- a macro of shim/cuda_runtime.h that runs the same kernel
-     function over the same grid on the CPU (cuemu.cpp);
+     function over the same grid on the CPU (cuemu.cpp: blocks spread over host threads, the threads of a block as coroutines);
   2. a copy of include/sobfu/cuda/utils.hpp gets its one `extern __shared__ int __smem[];` turned into a read of the launch's
      dynamic shared buffer (g++ has no notion of an unsized extern shared array);
   3. the copies, the reference's host .cpp files IN PLACE under /root/reference, cuemu.cpp and driver.cpp are compiled with
@@ -51,7 +51,7 @@ def build(work=None, arch="610", verbose=False):
     os.makedirs(os.path.join(gen, "sobfu", "cuda"), exist_ok=True)
     launches = 0
     objs = []
-    flags = ["-std=c++14", "-O2", "-ffp-contract=off", "-fpermissive", "-w", "-I" + gen, "-I" + os.path.join(HERE, "shim"),
+    flags = ["-std=c++14", "-O2", "-ffp-contract=off", "-fopenmp", "-fpermissive", "-w", "-I" + gen, "-I" + os.path.join(HERE, "shim"),
              "-I" + os.path.join(REF, "include")]
     if arch:
         flags.append("-DCUEMU_ARCH=" + arch)
@@ -81,7 +81,7 @@ def build(work=None, arch="610", verbose=False):
     if failed:
         raise RuntimeError("emulation build failed")
     exe = os.path.join(work, "ref_emu")
-    subprocess.check_call(["g++", *objs, "-o", exe])
+    subprocess.check_call(["g++", "-fopenmp", *objs, "-o", exe])
     if verbose:
         print("ref_emu: %d launch statements rewritten across %d files -> %s" % (launches, len(CU), exe))
     return exe

@@ -1,21 +1,28 @@
 // Block scheduler for the host emulation (see shim/cuda_runtime.h for what this is and is not).
 //
-// A launch runs its blocks one after another; the threads of a block are coroutines (a small hand-written switch on x86-64, ucontext elsewhere).  __syncthreads() and the warp
+// A launch spreads its blocks over host threads; on each of them blocks run one after another and the threads of a block are coroutines (a small hand-written switch on x86-64, ucontext elsewhere).  __syncthreads() and the warp
 // exchanges switch back to the scheduler, which resumes every live thread once per phase in thread-id order and sets
 // threadIdx before each resume.  A thread that returns early simply stops taking part (the reference's kernels return
 // before barriers only for threads that no later phase depends on).  Warp-synchronous code without a barrier would NOT be
 // emulated correctly; none of the translation units compiled by build.py contains any (kfusion's Block::reduce, which does,
 // is used by proj_icp.cu only).
+#include <omp.h>
 #include <sys/mman.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <vector>
 
 #include <cuda_runtime.h>  // last: it turns 'asm' into a macro
 
 namespace cuemu {
-uint3 tIdx, bIdx;
+thread_local uint3 tIdx, bIdx;
 dim3 bDim, gDim;
+int max_threads = [] {
+    const char* e = getenv("CUEMU_THREADS");
+    const int n   = e ? atoi(e) : omp_get_max_threads();
+    return n > 0 ? n : 1;
+}();
 
 namespace {
 // Context switch.  x86-64: a dozen instructions (callee-saved registers, MXCSR / x87 control word, the stack pointer) instead of
@@ -55,21 +62,23 @@ struct Thread {
     void* sp;
     bool done;
 };
-void* sched_sp;
+thread_local void* sched_sp;
 #else
 struct Thread {
     ucontext_t ctx;
     bool done;
 };
-ucontext_t sched;
+thread_local ucontext_t sched;
 #endif
 enum { kStack = 256 << 10 };
-std::vector<Thread> threads;
-std::vector<void*> stacks;
-std::vector<unsigned long long> xbuf;  // one exchange slot per thread
-std::vector<char> smem(64 << 10);
-body cur_body;
-int cur = -1, n_threads = 0;
+// per HOST thread: the coroutines of the block it is running
+thread_local std::vector<Thread> threads;
+thread_local std::vector<void*> stacks;
+thread_local std::vector<unsigned long long> xbuf;  // one exchange slot per thread of the block
+thread_local std::vector<char> smem;
+thread_local int cur = -1;
+body cur_body;      // per launch
+int n_threads = 0;  // threads of a block
 
 void to_scheduler() {
 #if defined(__x86_64__)
@@ -122,31 +131,37 @@ void set_tid(int t) {
 }
 }  // namespace
 
-void launch_impl(const cfg& c, body b) {
-    if (cur >= 0) fprintf(stderr, "cuemu: nested launch\n"), abort();
-    bDim = c.block, gDim = c.grid, cur_body = b;
-    n_threads = (int) (c.block.x * c.block.y * c.block.z);
+// Blocks of a launch are independent by the programming model, so they are spread over host threads (OpenMP); the threads of a
+// block stay coroutines of ONE host thread.  Every array the fixtures record is independent of the block order; the one kernel whose
+// OUTPUT ORDER depends on it (marching cubes' atomic append) is run with max_threads = 1 by the driver.
+static void run_block(const cfg& c, unsigned gx, unsigned gy, unsigned gz) {
     if ((int) threads.size() < n_threads) threads.resize(n_threads), xbuf.resize(n_threads);
     while ((int) stacks.size() < n_threads) {
         void* s = mmap(0, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (s == MAP_FAILED) perror("cuemu: mmap"), abort();
         stacks.push_back(s);
     }
-    if (smem.size() < c.smem) smem.resize(c.smem);
-    for (unsigned gz = 0; gz < c.grid.z; ++gz)
-        for (unsigned gy = 0; gy < c.grid.y; ++gy)
-            for (unsigned gx = 0; gx < c.grid.x; ++gx) {
-                bIdx = uint3{gx, gy, gz};
-                for (int t = 0; t < n_threads; ++t) prepare(t);
-                for (int live = n_threads; live;)
-                    for (int t = 0; t < n_threads; ++t)
-                        if (!threads[t].done) {
-                            set_tid(t);
-                            resume(t);
-                            if (threads[t].done) --live;
-                        }
+    if (smem.size() < std::max<size_t>(c.smem, 64 << 10)) smem.resize(std::max<size_t>(c.smem, 64 << 10));
+    bIdx = uint3{gx, gy, gz};
+    for (int t = 0; t < n_threads; ++t) prepare(t);
+    for (int live = n_threads; live;)
+        for (int t = 0; t < n_threads; ++t)
+            if (!threads[t].done) {
+                set_tid(t);
+                resume(t);
+                if (threads[t].done) --live;
             }
     cur = -1;
+}
+
+void launch_impl(const cfg& c, body b) {
+    if (cur >= 0) fprintf(stderr, "cuemu: nested launch\n"), abort();
+    bDim = c.block, gDim = c.grid, cur_body = b;
+    n_threads = (int) (c.block.x * c.block.y * c.block.z);
+    const long nb = (long) c.grid.x * c.grid.y * c.grid.z;
+    const int nt  = (int) std::min<long>(max_threads, nb);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt) if (nt > 1)
+    for (long i = 0; i < nb; ++i) run_block(c, (unsigned) (i % c.grid.x), (unsigned) ((i / c.grid.x) % c.grid.y), (unsigned) (i / ((long) c.grid.x * c.grid.y)));
 }
 
 void syncthreads() { to_scheduler(); }

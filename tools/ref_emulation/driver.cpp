@@ -227,6 +227,7 @@ static void scenario_mc() {
     const size_t N = (size_t) p.volume_dims[0] * p.volume_dims[1] * p.volume_dims[2];
     kfusion::cuda::TsdfVolume v(p);
     v.data().upload(read_bin<float>("volume", N * 2).data(), N * 8);
+    cuemu::max_threads = 1;  // getOccupiedVoxels appends by atomicAdd: the order of its output is the order blocks run in
     kfusion::cuda::MarchingCubes mc;
     mc.setPose(p.volume_pose);
     kfusion::cuda::DeviceArray<pcl::PointXYZ> vb((size_t) arg("buffer"));

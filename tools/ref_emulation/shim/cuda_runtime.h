@@ -39,7 +39,7 @@
 #define __forceinline__ inline
 #define __noinline__
 #define __constant__ static
-#define __shared__ static  // one block runs at a time, so a function-local static IS the block's shared array
+#define __shared__ static thread_local  // a host thread runs one block at a time, so its function-local static IS the block's shared array
 #define __launch_bounds__(...)
 
 using std::isnan;
@@ -75,8 +75,9 @@ static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char
 // ---------------------------------------------------------------- execution model (tools/ref_emulation/cuemu.cpp)
 typedef struct cuemu_stream* cudaStream_t;
 namespace cuemu {
-extern uint3 tIdx, bIdx;
+extern thread_local uint3 tIdx, bIdx;  // blocks of a launch are spread over host threads (cuemu.cpp)
 extern dim3 bDim, gDim;
+extern int max_threads;                // host threads a launch may use (CUEMU_THREADS; 1 = blocks in launch order)
 struct cfg {
     dim3 grid, block;
     size_t smem;
@@ -219,9 +220,13 @@ template <class T>
 static inline cudaError_t cudaMemcpyFromSymbol(void* d, const T& sym, size_t n, size_t off = 0, cudaMemcpyKind = cudaMemcpyDeviceToHost) {
     return memcpy(d, (const char*) &sym + off, n), cudaSuccess;
 }
-// threads of the emulation never run concurrently, so the atomics are plain read-modify-writes
-static inline int atomicAdd(int* a, int v) { int old = *a; *a = old + v; return old; }
-static inline unsigned int atomicInc(unsigned int* a, unsigned int limit) { unsigned int old = *a; *a = old >= limit ? 0 : old + 1; return old; }
+// blocks may run on different host threads: real atomics
+static inline int atomicAdd(int* a, int v) { return __atomic_fetch_add(a, v, __ATOMIC_SEQ_CST); }
+static inline unsigned int atomicInc(unsigned int* a, unsigned int limit) {
+    unsigned int old = __atomic_load_n(a, __ATOMIC_SEQ_CST);
+    while (!__atomic_compare_exchange_n(a, &old, old >= limit ? 0u : old + 1u, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
 
 // ---------------------------------------------------------------- legacy texture references (point-sampled, zero border)
 enum cudaTextureReadMode { cudaReadModeElementType, cudaReadModeNormalizedFloat };
