@@ -3,8 +3,8 @@ container through the host emulation of tools/ref_emulation/ (builder-authored s
 + a coroutine block scheduler; the reference's files are compiled where they lie, generated copies live in a temp dir that is
 removed at the end -- only arrays come back).
 
-    python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run; ~3 min on 8 cores, most of it
-                                                              # BASELINE config 3: 50 iterations at 256^3 under emulation)
+    python tests/golden/make_reference_fixtures.py            # rewrites the fixtures (byte-identical on every run; ~6 min on 8 cores: BASELINE config 2's 808 iterations
+                                                              # at 128^3 and config 3's 50 at 256^3 under emulation)
     python tests/golden/make_reference_fixtures.py --check    # regenerates into memory and compares with the committed files
     python tests/golden/make_reference_fixtures.py --check --only=ref_kernels_17x9x5,ref_mc_14x11x9   # a quick subset (the CPU suite runs this)
 
@@ -383,11 +383,12 @@ def make_all(emu, emu_smem, only_config5=False):
     cfg1["lambda"] = 0.1
     cfg1_intr = (cfg1["fx"], cfg1["fy"], cfg1["cx"], cfg1["cy"])
     fx["ref_config1_64"] = frames_fixture(emu, cfg1, [translating_sphere_frame(cfg1_intr, f) for f in range(2)], full_last=False)
-    # BASELINE config 2: 128^3, params_snoopy.ini values (params/config2_snoopy_128.ini), the 7-frame VolumeDeform-style sequence: frames
-    # 1 - 3 are fused without a solve (START_FRAME 4), frames 4 - 6 solve from a warm-started psi; MAX_ITER capped at 16 as in the GPU tests
+    # BASELINE config 2 as the ini states it: 128^3, params_snoopy.ini values (params/config2_snoopy_128.ini: MAX_ITER 2048, MAX_UPDATE_NORM
+    # 1e-3), the 7-frame VolumeDeform-style sequence: frames 1 - 3 are fused without a solve (START_FRAME 4), frames 4 - 6 solve from a
+    # warm-started psi until the threshold fires (after 612, 143 and 53 iterations)
     cfg2 = dict(rows=480, cols=640, fx=517.0, fy=517.0, cx=320.0, cy=240.0, trunc_depth=3.0, bilateral_ksz=7, bilateral_ss=4.5, bilateral_sd=0.01,
                 X=128, Y=128, Z=128, size_x=0.9, size_y=0.9, size_z=0.9, trunc_vox=10.0, eta_vox=5.0, t_z=0.05, max_weight=128.0, start_frame=4, s=7,
-                alpha=0.1, w_reg=0.2, max_iter=16, max_update_norm=1e-3, verbosity=1)
+                alpha=0.1, w_reg=0.2, max_iter=2048, max_update_norm=1e-3, verbosity=1)
     cfg2["lambda"] = 0.1
     fx["ref_config2_128"] = frames_fixture(emu, cfg2, [snoopy_frame((517.0, 517.0, 320.0, 240.0), f) for f in range(7)], full_last=False)
     _config5(emu, fx)

@@ -321,7 +321,8 @@ def _check_frames(f, fusion_factory, host=np.asarray):
 @pytest.mark.parametrize("name", ["ref_frames_32x32x32", "ref_frames_gated_32x32x32", "ref_config1_64", "ref_config2_128", "ref_config5_values_96"])
 def test_oracle_frame_pipeline(oracle, name):
     """every volume and field of every frame of SobFusion::operator(), and every line it printed; ref_config1_64 / ref_config2_128 are
-    BASELINE configs 1 and 2 (config 2: seven frames, START_FRAME 4, psi warm-started from frame to frame, MAX_ITER capped at 16)"""
+    BASELINE configs 1 and 2 (config 2 as its ini states it: seven frames, START_FRAME 4, psi warm-started from frame to frame, MAX_ITER 2048 with
+    the 1e-3 threshold firing after 612, 143 and 53 iterations)"""
     f = load(name)
     fu = _check_frames(f, lambda P: OracleFusion(oracle, P))
     assert fu.log == f["log"]

@@ -1,6 +1,6 @@
 """The emulated-reference recipe is regenerable: in the build container (where /root/reference is mounted) a subset of
 tests/golden/ref_*.npz is rebuilt from a clean temp dir through tools/ref_emulation/ and must come out BYTE-IDENTICAL to the
-committed files (the full set: `python tests/golden/make_reference_fixtures.py --check`, ~3 min).  Also: nothing outside
+committed files (the full set: `python tests/golden/make_reference_fixtures.py --check`, ~6 min).  Also: nothing outside
 tests/golden/ imports the recipe, and the recipe keeps no reference text in the repo."""
 import os
 import re
