@@ -24,11 +24,16 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+
 #include <cuda_runtime.h>
+#ifndef REF_HIP_BUILD  // (tools/ref_hipbuild compiles this driver too, without SobFusion / marching cubes: their kernels use 32-wide warp intrinsics and PTX)
 #define private public  // SobFusion keeps phi_global & co. private; the dumps need to read them
 #include <sobfu/sob_fusion.hpp>
 #undef private
 #include <kfusion/cuda/marching_cubes.hpp>
+#endif
+#include <kfusion/precomp.hpp>
 #include <sobfu/solver.hpp>
 
 static std::string g_dir;
@@ -203,6 +208,27 @@ static void scenario_depth() {
     dump("volume", v.data());
 }
 
+// wall time of Solver::estimate_psi as the reference runs it (a host sync and a 128 KB read-back per iteration, solver.cu:172):
+// `repeat` solves of max_iter iterations from two initSphere volumes; prints seconds per solve (meaningful on the GPU build only)
+static void scenario_time() {
+    Params p = make_params();
+    cv::Ptr<kfusion::cuda::TsdfVolume> pg(new kfusion::cuda::TsdfVolume(p)), pgi(new kfusion::cuda::TsdfVolume(p)), pn(new kfusion::cuda::TsdfVolume(p)),
+        pnp(new kfusion::cuda::TsdfVolume(p));
+    pg->initSphere(make_float3((float) arg("sphere_cx"), (float) arg("sphere_cy"), (float) arg("sphere_cz")), (float) arg("sphere_r"));
+    pn->initSphere(make_float3((float) arg("sphere2_cx"), (float) arg("sphere2_cy"), (float) arg("sphere2_cz")), (float) arg("sphere_r"));
+    sobfu::cuda::Solver solver(p);
+    std::ofstream out(g_dir + "/out_time.txt");
+    for (int r = 0; r < (int) arg("repeat", 3); ++r) {
+        auto psi = std::make_shared<sobfu::cuda::DeformationField>(p.volume_dims), psi_inv = std::make_shared<sobfu::cuda::DeformationField>(p.volume_dims);
+        cudaDeviceSynchronize();
+        const auto t0 = std::chrono::steady_clock::now();
+        solver.estimate_psi(pg, pgi, pn, pnp, psi, psi_inv);
+        cudaDeviceSynchronize();
+        out << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "\n";
+    }
+}
+
+#ifndef REF_HIP_BUILD
 static void scenario_frames() {
     Params p = make_params();
     const int n = (int) arg("frames");
@@ -240,6 +266,8 @@ static void scenario_mc() {
     write_bin("normals", hn.data(), hn.size() * 16);
 }
 
+#endif  // REF_HIP_BUILD
+
 int main(int argc, char** argv) {
     if (argc < 3) return fprintf(stderr, "usage: ref_emu <scenario> <dir> key=value ...\n"), 2;
     const std::string scenario = argv[1];
@@ -261,8 +289,11 @@ int main(int argc, char** argv) {
     else if (scenario == "solver") scenario_solver();
     else if (scenario == "tsdf") scenario_tsdf();
     else if (scenario == "depth") scenario_depth();
+    else if (scenario == "time") scenario_time();
+#ifndef REF_HIP_BUILD
     else if (scenario == "frames") scenario_frames();
     else if (scenario == "mc") scenario_mc();
+#endif
     else return fprintf(stderr, "ref_emu: unknown scenario %s\n", scenario.c_str()), 2;
     std::cout.flush();
     std::cout.rdbuf(old);

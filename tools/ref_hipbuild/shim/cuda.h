@@ -1,0 +1,3 @@
+// forwards to tools/ref_hipbuild/shim/cuda_runtime.h
+#pragma once
+#include <cuda_runtime.h>
