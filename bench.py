@@ -120,6 +120,40 @@ def cpu_baseline(P, budget_s=12.0):
                                      "w_reg 0.2, S=7, lambda 0.1, two analytic spheres) after 12 warm-up iterations: >= 0.5 s each"}}
 
 
+def reference_build_on_this_gpu(P, repeat=2):
+    """Part of the baseline leg: oracle/_ref/reference_hip_ieee -- the reference's own .cu / .cpp files compiled for gfx950 by hipcc through a
+    CUDA -> HIP name-map header in the build container (tools/ref_hipbuild; shim evidence, arrays bit-identical to this repo's) -- runs its
+    Solver::estimate_psi on this workload.  The iteration rate is the difference of a 100- and a 50-iteration solve.  None when the binary
+    is not there (it cannot be built on the GPU box: the reference does not travel)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "reference_hip_ieee")
+    if not os.path.exists(exe):
+        return None
+    dim = P["dims"][0]
+    c0, c1, r = sphere_pair(P)
+    kw = dict(X=dim, Y=dim, Z=dim, size_x=0.75, size_y=0.75, size_z=0.75, trunc_vox=48.0, eta_vox=3.0, max_weight=128.0, s=P["s"], alpha=P["alpha"], w_reg=P["w_reg"],
+              max_update_norm=P["max_update_norm"], verbosity=0, sphere_cx=c0[0], sphere_cy=c0[1], sphere_cz=c0[2], sphere2_cx=c1[0], sphere2_cy=c1[1],
+              sphere2_cz=c1[2], sphere_r=r, repeat=repeat)
+    kw["lambda"] = P["lam"]
+    t = {}
+    for n in (50, 100):
+        d = tempfile.mkdtemp(prefix="ref_hip_")
+        try:
+            a = subprocess.run([exe, "time", d, "max_iter=%d" % n] + ["%s=%r" % (k, float(v)) for k, v in kw.items()], capture_output=True, text=True, timeout=120)
+            if a.returncode != 0:
+                return {"error": (a.stdout + a.stderr)[-300:]}
+            t[n] = min(float(x) for x in open(os.path.join(d, "out_time.txt")).read().split())
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"value": 50.0 / (t[100] - t[50]), "unit": "iterations/s", "s_per_solve_50": t[50], "s_not_iterations": t[50] - (t[100] - t[50]),
+            "kind": "the reference's own kernels and host loop (ten kernels, a host synchronisation and a 128 KB read-back per iteration, solver.cu:114-193), "
+                    "compiled by hipcc for gfx950 through a CUDA -> HIP name-map header (tools/ref_hipbuild; shim evidence, not a supported build of the reference)",
+            "sample": "Solver::estimate_psi of 50 and of 100 iterations on the same %d^3 workload, best of %d each; rate = 50 / (t100 - t50)" % (dim, repeat)}
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -585,6 +619,14 @@ def make_line(args, P, res, world, force_tiled, full=True):
     if world == 1 and not args.no_cpu_baseline and full:
         if _left(args) > 45.0:
             out["cpu_baseline"] = cpu_baseline(P)
+            try:
+                rb = reference_build_on_this_gpu(P)
+            except Exception as e:  # a baseline beside the line, never a reason to lose it
+                rb = {"error": repr(e)[:300]}
+            if rb is not None:
+                if rb.get("value"):
+                    rb["this_repo_over_reference_build"] = out["value"] / rb["value"]
+                out["reference_build_on_this_gpu"] = rb
         else:
             skipped.append("cpu_baseline")
     if args.budget_s > 0:

@@ -43,6 +43,9 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s" and c["sample"]
     assert c["one_core"]["cores"] == 1 and c["one_core"]["value"] > 0
     assert c["config1_64"]["all_cores"]["value"] > 0 and c["config1_64"]["one_core"]["value"] > 0
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "reference_hip_ieee")):  # the baseline leg's second number: the reference's kernels on this GPU
+        rb = d["reference_build_on_this_gpu"]
+        assert rb["value"] > 0 and rb["unit"] == "iterations/s" and rb["this_repo_over_reference_build"] > 2.0 and "shim evidence" in rb["kind"], rb
 
 
 def test_gpus_n_self_launches_replicas():

@@ -18,19 +18,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def reference_rate(dim=256, repeat=3):
-    """-> dict(iterations_per_s, s_per_solve_50, s_fixed): the reference build on bench.py's workload at dim^3"""
+    """-> dict(iterations_per_s, s_per_solve_50, s_not_iterations): bench.reference_build_on_this_gpu on bench.py's workload at dim^3"""
     import bench
-    import ref_hip_runner as R
 
-    P = bench.boxing_params(dim)
-    c0, c1, r = bench.sphere_pair(P)
-    kw = dict(X=dim, Y=dim, Z=dim, size_x=0.75, size_y=0.75, size_z=0.75, trunc_vox=48.0, eta_vox=3.0, max_weight=128.0, s=7, alpha=P["alpha"], w_reg=P["w_reg"],
-              max_update_norm=P["max_update_norm"], verbosity=0, sphere_cx=c0[0], sphere_cy=c0[1], sphere_cz=c0[2], sphere2_cx=c1[0], sphere2_cy=c1[1],
-              sphere2_cz=c1[2], sphere_r=r, repeat=repeat)
-    kw["lambda"] = P["lam"]
-    t50 = min(R.run("ieee", "time", {}, {}, max_iter=50, **kw)["time"])
-    t100 = min(R.run("ieee", "time", {}, {}, max_iter=100, **kw)["time"])
-    return {"iterations_per_s": 50.0 / (t100 - t50), "s_per_solve_50": t50, "s_not_iterations": t50 - (t100 - t50)}
+    r = bench.reference_build_on_this_gpu(bench.boxing_params(dim), repeat=repeat)
+    assert r and r.get("value"), r
+    return {"iterations_per_s": r["value"], "s_per_solve_50": r["s_per_solve_50"], "s_not_iterations": r["s_not_iterations"]}
 
 
 def main():
