@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsobfu_hip.so")
-SOURCES = ["tsdf_kernels.hip", "field_kernels.hip", "reduce_kernels.hip", "solver_kernels.hip", "solver_capi.hip", "tiled_capi.hip", "mc_kernels.hip"]
+SOURCES = ["tsdf_kernels.hip", "field_kernels.hip", "reduce_kernels.hip", "solver_kernels.hip", "launcher_kernels.hip", "solver_capi.hip", "tiled_capi.hip", "mc_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 

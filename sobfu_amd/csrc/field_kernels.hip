@@ -12,6 +12,14 @@ namespace {
 #define VOXEL_XYZ(d)                                                         \
     const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z; \
     if (x >= (d).x || y >= (d).y) return;
+// the same under the XCD-aware tile map (sobfu_device.hpp) -- for the stencils, whose work per voxel is uniform.  NOT for the warps and the
+// inverse: their cost follows the data (fixed-point sweeps until the value repeats), a band of tile rows per XCD then leaves the XCDs that
+// own the middle of the volume with most of the work (inverse + warp at 256^3: 630 -> 800 us, measured in round 6).
+#define VOXEL_XYZ_XCD(d)                                                     \
+    int bx_, by_, z;                                                         \
+    xcd_tile(bx_, by_, z);                                                   \
+    const int x = bx_ * kBX + threadIdx.x, y = by_ * kBY + threadIdx.y;      \
+    if (x >= (d).x || y >= (d).y) return;
 
 // init_identity_kernel -- vector_fields.cu:64-79.  (float) z equals the reference's z-fold sum of 1.f exactly.
 // base: global coordinates of local cell (0, 0, 0) (multi-GPU tiles; 0 on a single GPU)
@@ -22,12 +30,13 @@ __global__ void __launch_bounds__(256) init_identity_kernel(float4* __restrict__
 
 // apply_kernel -- vector_fields.cu:81-100
 // pd: dims of phi (the whole volume); d: dims of psi / out (== pd on a single GPU, a z-slab on multiple GPUs)
+template <bool NT>
 __global__ void __launch_bounds__(256) apply_kernel(const float2* __restrict__ phi, float2* __restrict__ out,
                                                     const float4* __restrict__ psi, Dims d, Dims pd) {
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
-    float4 p = psi[i];
-    out[i]   = interp_tsdf(phi, pd, p.x, p.y, p.z);
+    float4 p = ld4<NT>(&psi[i]);
+    st2<NT>(&out[i], interp_tsdf(phi, pd, p.x, p.y, p.z));
 }
 
 // estimate_inverse_kernel x n_sweeps -- vector_fields.cu:111-138.  A sweep reads psi (never written) and the
@@ -60,17 +69,19 @@ SOBFU_DEV float4 inverse_fixed_point(const float4* __restrict__ psi, const Dims&
     return v;
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
                                                                   Dims d, Dims pd, Dims base, int n_sweeps) {
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
     const float4 id = f4((float) (x + base.x), (float) (y + base.y), (float) (z + base.z));
-    psi_inv[i] = inverse_fixed_point(psi, pd, psi_inv[i], id, n_sweeps);
+    st4<NT>(&psi_inv[i], inverse_fixed_point(psi, pd, ld4<NT>(&psi_inv[i]), id, n_sweeps));
 }
 
 // The tail of Solver::estimate_psi in one pass (solver.cu:196-199): psi^-1 <- identity, 48 sweeps, phi_global o psi^-1.
 // The lane still holds psi^-1(x) when it warps phi_global there: no identity field is written and read back, psi^-1 is not
 // re-read by the warp.
+template <bool NT>
 __global__ void __launch_bounds__(256) inverse_from_identity_and_warp_kernel(const float4* __restrict__ psi, float4* __restrict__ psi_inv,
                                                                              const float2* __restrict__ phi, float2* __restrict__ phi_warped,
                                                                              Dims d, int n_sweeps) {
@@ -78,8 +89,8 @@ __global__ void __launch_bounds__(256) inverse_from_identity_and_warp_kernel(con
     size_t i = vidx(d, x, y, z);
     const float4 id = f4((float) x, (float) y, (float) z);
     const float4 v  = inverse_fixed_point(psi, d, id, id, n_sweeps);
-    psi_inv[i]      = v;
-    phi_warped[i]   = interp_tsdf(phi, d, v.x, v.y, v.z);
+    st4<NT>(&psi_inv[i], v);
+    st2<NT>(&phi_warped[i], interp_tsdf(phi, d, v.x, v.y, v.z));
 }
 
 // ---- the per-frame tail of a multi-GPU tile on a WINDOW of the sources instead of the whole volume --------------------------------
@@ -171,21 +182,26 @@ __global__ void __launch_bounds__(256) tile_max_displacement_kernel(const float4
 }
 
 // TsdfDifferentiator::operator() -- vector_fields.cu:157-208 (mirrored neighbour on boundary faces => exact 0)
+// (A z-marching form of the three differentiators -- centre values of planes z - 1, z, z + 1 in registers -- was measured in round 6: no
+// faster; their memory traffic is already the compulsory one, 1.05 - 1.15 x: profiles/r06/launcher_table_256.md.)
+template <bool NT>
 __global__ void __launch_bounds__(256) tsdf_gradient_kernel(const float2* __restrict__ vol, float4* __restrict__ grad, Dims d) {
-    VOXEL_XYZ(d);
+    VOXEL_XYZ_XCD(d);
     int x1 = x + 1, x2 = x - 1, y1 = y + 1, y2 = y - 1, z1 = z + 1, z2 = z - 1;
     if (x == 0) x2 = x + 1; else if (x == d.x - 1) x1 = x - 1;
     if (y == 0) y2 = y + 1; else if (y == d.y - 1) y1 = y - 1;
     if (z == 0) z2 = z + 1; else if (z == d.z - 1) z1 = z - 1;
+    x1 = min(x1, d.x - 1), x2 = min(x2, d.x - 1), y1 = min(y1, d.y - 1), y2 = min(y2, d.y - 1), z1 = min(z1, d.z - 1), z2 = min(z2, d.z - 1);  // (an extent of 1: the reference reads out of bounds)
     float nx = (vol[vidx(d, x1, y, z)].x - vol[vidx(d, x2, y, z)].x) / 2.f;
     float ny = (vol[vidx(d, x, y1, z)].x - vol[vidx(d, x, y2, z)].x) / 2.f;
     float nz = (vol[vidx(d, x, y, z1)].x - vol[vidx(d, x, y, z2)].x) / 2.f;
-    grad[vidx(d, x, y, z)] = f4(nx, ny, nz);
+    st4<NT>(&grad[vidx(d, x, y, z)], f4(nx, ny, nz));
 }
 
 // SecondOrderDifferentiator::laplacian -- vector_fields.cu:291-337 (both neighbours <- centre on a boundary face)
+template <bool NT>
 __global__ void __launch_bounds__(256) laplacian_kernel(const float4* __restrict__ psi, float4* __restrict__ L, Dims d) {
-    VOXEL_XYZ(d);
+    VOXEL_XYZ_XCD(d);
     int x1 = x + 1, x2 = x - 1, y1 = y + 1, y2 = y - 1, z1 = z + 1, z2 = z - 1;
     if (x == 0 || x == d.x - 1) x1 = x2 = x;
     if (y == 0 || y == d.y - 1) y1 = y2 = y;
@@ -197,32 +213,54 @@ __global__ void __launch_bounds__(256) laplacian_kernel(const float4* __restrict
     v = add4(v, psi[vidx(d, x, y2, z)]);
     v = add4(v, psi[vidx(d, x, y, z1)]);
     v = add4(v, psi[vidx(d, x, y, z2)]);
-    L[vidx(d, x, y, z)] = mul4(v, -1.f);
+    st4<NT>(&L[vidx(d, x, y, z)], mul4(v, -1.f));
 }
 
-// Differentiator::operator()(J, mode) -- vector_fields.cu:415-472
-template <int MODE>
+// Differentiator::operator()(J, mode) -- vector_fields.cu:415-472.  A voxel's Jacobian is 4 x float4 = 64 B: stored lane by lane, each of the
+// four store instructions of a wave scatters 16-byte pieces at a 64-byte stride (eight write requests per 128-byte line: 488 us at 256^3, the
+// write path saturated).  Here a wave transposes its 64 Jacobians through 4 KiB of LDS and stores four CONTIGUOUS 1 KiB segments.
+template <int MODE, bool NT>
 __global__ void __launch_bounds__(256) jacobian_kernel(const float4* __restrict__ psi, float4* __restrict__ J, Dims d) {
-    VOXEL_XYZ(d);
+    __shared__ float4 t_rows[kBY][4 * kBX];  // per wave: voxel l's row r at [4 * l + r]
+    int bx_, by_, z;
+    xcd_tile(bx_, by_, z);
+    const int x0 = bx_ * kBX, lane = threadIdx.x, y = by_ * kBY + threadIdx.y;
+    if (y >= d.y) return;                    // (wave-uniform: a wave is one row)
+    const int x = min(x0 + lane, d.x - 1);   // lanes beyond the row compute a copy of its last voxel and store nothing
     int x1 = x + 1, x2 = x - 1, y1 = y + 1, y2 = y - 1, z1 = z + 1, z2 = z - 1;
     if (x == 0) x2 = x + 1; else if (x == d.x - 1) x1 = x - 1;
     if (y == 0) y2 = y + 1; else if (y == d.y - 1) y1 = y - 1;
     if (z == 0) z2 = z + 1; else if (z == d.z - 1) z1 = z - 1;
+    x1 = min(x1, d.x - 1), x2 = min(x2, d.x - 1), y1 = min(y1, d.y - 1), y2 = min(y2, d.y - 1), z1 = min(z1, d.z - 1), z2 = min(z2, d.z - 1);  // (an extent of 1: the reference reads out of bounds)
     auto P = [&](int a, int b, int c) { return MODE == 0 ? psi[vidx(d, a, b, c)] : disp_at(psi, d, a, b, c); };
-    float4 jx = half4(sub4(P(x1, y, z), P(x2, y, z)));
-    float4 jy = half4(sub4(P(x, y1, z), P(x, y2, z)));
-    float4 jz = half4(sub4(P(x, y, z1), P(x, y, z2)));
-    float4* o = J + 4 * vidx(d, x, y, z);
-    o[0] = f4(jx.x, jy.x, jz.x);
-    o[1] = f4(jx.y, jy.y, jz.y);
-    o[2] = f4(jx.z, jy.z, jz.z);
-    o[3] = f4(0.f, 0.f, 0.f);  // the reference leaves row 3 uninitialised
+    const float4 jx = half4(sub4(P(x1, y, z), P(x2, y, z)));
+    const float4 jy = half4(sub4(P(x, y1, z), P(x, y2, z)));
+    const float4 jz = half4(sub4(P(x, y, z1), P(x, y, z2)));
+    float4* t = t_rows[threadIdx.y];
+    t[4 * lane + 0] = f4(jx.x, jy.x, jz.x);
+    t[4 * lane + 1] = f4(jx.y, jy.y, jz.y);
+    t[4 * lane + 2] = f4(jx.z, jy.z, jz.z);
+    t[4 * lane + 3] = f4(0.f, 0.f, 0.f);  // the reference leaves row 3 uninitialised
+    __builtin_amdgcn_wave_barrier();      // the wave's own LDS traffic is in order: no workgroup barrier
+    float4* o = J + 4 * vidx(d, x0, y, z);
+    const int n = 4 * min(kBX, d.x - x0);  // float4s this wave owns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = i * kBX + lane;
+        if (e < n) st4<NT>(&o[e], t[e]);
+    }
 }
 
 }  // namespace
 
 #define LAUNCH_VOXEL(kern, X, Y, Z, stream, ...) \
-    hipLaunchKernelGGL(kern, voxel_grid(X, Y, Z), voxel_block(), 0, (hipStream_t) (stream), __VA_ARGS__)
+    hipLaunchKernelGGL((kern), voxel_grid(X, Y, Z), voxel_block(), 0, (hipStream_t) (stream), __VA_ARGS__)
+// kern<.., NT>: the streaming instantiation on grids beyond the Infinity Cache (launcher_streams, sobfu_device.hpp), the plain one below
+#define LAUNCH_VOXEL_NT(kern_streaming, kern_plain, X, Y, Z, stream, ...)                     \
+    do {                                                                                     \
+        if (launcher_streams(X, Y, Z)) LAUNCH_VOXEL(kern_streaming, X, Y, Z, stream, __VA_ARGS__); \
+        else LAUNCH_VOXEL(kern_plain, X, Y, Z, stream, __VA_ARGS__);                          \
+    } while (0)
 
 extern "C" {
 
@@ -247,7 +285,7 @@ int sobfu_hip_tile3_init_identity(float* d_psi, int Lx, int Ly, int Lz, int xb, 
 int sobfu_hip_tile3_apply(const float* d_phi, int Xg, int Yg, int Zg, float* d_phi_warped, const float* d_psi, int Lx, int Ly, int Lz,
                           void* stream) {
     SOBFU_CHECK_ARGS(d_phi && d_phi_warped && d_psi && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0 && d_phi != d_phi_warped);
-    LAUNCH_VOXEL(apply_kernel, Lx, Ly, Lz, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{Lx, Ly, Lz},
+    LAUNCH_VOXEL(apply_kernel<false>, Lx, Ly, Lz, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{Lx, Ly, Lz},
                  Dims{Xg, Yg, Zg});
     return (int) hipGetLastError();
 }
@@ -257,7 +295,7 @@ int sobfu_hip_tile3_estimate_inverse(const float* d_psi, int Xg, int Yg, int Zg,
     SOBFU_CHECK_ARGS(d_psi && d_psi_inv && Lx > 0 && Ly > 0 && Lz > 0 && Xg > 0 && Yg > 0 && Zg > 0 && xb >= 0 && yb >= 0 && zb >= 0 &&
                      n_sweeps >= 0 && d_psi != d_psi_inv);
     if (n_sweeps == 0) return 0;
-    LAUNCH_VOXEL(inverse_fixed_point_kernel, Lx, Ly, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{Lx, Ly, Lz},
+    LAUNCH_VOXEL(inverse_fixed_point_kernel<false>, Lx, Ly, Lz, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{Lx, Ly, Lz},
                  Dims{Xg, Yg, Zg}, Dims{xb, yb, zb}, n_sweeps);
     return (int) hipGetLastError();
 }
@@ -305,16 +343,16 @@ int sobfu_hip_tile3_max_displacement(const float* d_psi, int Lx, int Ly, int Lz,
 
 int sobfu_hip_apply(const float* d_phi, float* d_phi_warped, const float* d_psi, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_phi && d_phi_warped && d_psi && X > 0 && Y > 0 && Z > 0 && d_phi != d_phi_warped);
-    LAUNCH_VOXEL(apply_kernel, X, Y, Z, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{X, Y, Z},
-                 Dims{X, Y, Z});
+    LAUNCH_VOXEL_NT(apply_kernel<true>, apply_kernel<false>, X, Y, Z, stream, (const float2*) d_phi, (float2*) d_phi_warped, (const float4*) d_psi, Dims{X, Y, Z},
+                    Dims{X, Y, Z});
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_estimate_inverse(const float* d_psi, float* d_psi_inv, int X, int Y, int Z, int n_sweeps, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && d_psi_inv && X > 0 && Y > 0 && Z > 0 && n_sweeps >= 0 && d_psi != d_psi_inv);
     if (n_sweeps == 0) return 0;
-    LAUNCH_VOXEL(inverse_fixed_point_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, Dims{X, Y, Z},
-                 Dims{0, 0, 0}, n_sweeps);
+    LAUNCH_VOXEL_NT(inverse_fixed_point_kernel<true>, inverse_fixed_point_kernel<false>, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, Dims{X, Y, Z}, Dims{X, Y, Z},
+                    Dims{0, 0, 0}, n_sweeps);
     return (int) hipGetLastError();
 }
 
@@ -322,27 +360,27 @@ int sobfu_hip_inverse_and_warp(const float* d_psi, float* d_psi_inv, const float
                                int n_sweeps, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && d_psi_inv && d_phi && d_phi_warped && X > 0 && Y > 0 && Z > 0 && n_sweeps >= 0 && d_psi != d_psi_inv &&
                      d_phi != d_phi_warped);
-    LAUNCH_VOXEL(inverse_from_identity_and_warp_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, (const float2*) d_phi,
-                 (float2*) d_phi_warped, Dims{X, Y, Z}, n_sweeps);
+    LAUNCH_VOXEL_NT(inverse_from_identity_and_warp_kernel<true>, inverse_from_identity_and_warp_kernel<false>, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_psi_inv, (const float2*) d_phi,
+                    (float2*) d_phi_warped, Dims{X, Y, Z}, n_sweeps);
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_tsdf_gradient(const float* d_vol, float* d_grad, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_vol && d_grad && X > 0 && Y > 0 && Z > 0);
-    LAUNCH_VOXEL(tsdf_gradient_kernel, X, Y, Z, stream, (const float2*) d_vol, (float4*) d_grad, Dims{X, Y, Z});
+    LAUNCH_VOXEL_NT(tsdf_gradient_kernel<true>, tsdf_gradient_kernel<false>, X, Y, Z, stream, (const float2*) d_vol, (float4*) d_grad, Dims{X, Y, Z});
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_laplacian(const float* d_psi, float* d_L, int X, int Y, int Z, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && d_L && X > 0 && Y > 0 && Z > 0 && d_psi != d_L);
-    LAUNCH_VOXEL(laplacian_kernel, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_L, Dims{X, Y, Z});
+    LAUNCH_VOXEL_NT(laplacian_kernel<true>, laplacian_kernel<false>, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_L, Dims{X, Y, Z});
     return (int) hipGetLastError();
 }
 
 int sobfu_hip_jacobian(const float* d_psi, float* d_J, int X, int Y, int Z, int mode, void* stream) {
     SOBFU_CHECK_ARGS(d_psi && d_J && X > 0 && Y > 0 && Z > 0 && (mode == 0 || mode == 1));
-    if (mode == 0) LAUNCH_VOXEL(jacobian_kernel<0>, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_J, Dims{X, Y, Z});
-    else LAUNCH_VOXEL(jacobian_kernel<1>, X, Y, Z, stream, (const float4*) d_psi, (float4*) d_J, Dims{X, Y, Z});
+    if (mode == 0) LAUNCH_VOXEL_NT((jacobian_kernel<0, true>), (jacobian_kernel<0, false>), X, Y, Z, stream, (const float4*) d_psi, (float4*) d_J, Dims{X, Y, Z});
+    else LAUNCH_VOXEL_NT((jacobian_kernel<1, true>), (jacobian_kernel<1, false>), X, Y, Z, stream, (const float4*) d_psi, (float4*) d_J, Dims{X, Y, Z});
     return (int) hipGetLastError();
 }
 

@@ -101,6 +101,37 @@ SOBFU_DEV float2 pack_tsdf(float sdf, float trunc, float weight) {
     return make_float2(sdf / trunc, weight);
 }
 
+// ---- streaming (nontemporal) accesses of the launcher-for-launcher kernels (template parameter NT) -- for arrays a launch reads or writes
+// exactly once, on grids whose arrays exceed the 256 MiB Infinity Cache (launcher_streams below).  Measured at 256^3 (round 6,
+// profiles/r06/launcher_table_256.md): a plainly stored output allocates in the caches and the stencil's re-read taps lose them --
+// laplacian 121 -> 87 us, TSDF gradient 105 -> 65, convolution_rows 105 -> 77 with nothing but the hint on the output store.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+SOBFU_DEV void st4(float4* p, const float4& v) {
+    if (NT) __builtin_nontemporal_store((v4f_t){v.x, v.y, v.z, v.w}, (v4f_t*) p);
+    else *p = v;
+}
+template <bool NT>
+SOBFU_DEV void st2(float2* p, const float2& v) {
+    if (NT) __builtin_nontemporal_store((v2f_t){v.x, v.y}, (v2f_t*) p);
+    else *p = v;
+}
+template <bool NT>
+SOBFU_DEV float4 ld4(const float4* p) {
+    if (!NT) return *p;
+    const v4f_t t = __builtin_nontemporal_load((const v4f_t*) p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+template <bool NT>
+SOBFU_DEV float2 ld2(const float2* p) {
+    if (!NT) return *p;
+    const v2f_t t = __builtin_nontemporal_load((const v2f_t*) p);
+    return make_float2(t.x, t.y);
+}
+// grids of more cells than this stream (a float4 field of 3.3 M cells is 53 MB: a launcher chain's few arrays still fit the Infinity Cache)
+inline bool launcher_streams(int X, int Y, int Z) { return (long) X * Y * Z > 3300000L; }
+
 // ---- launch geometry ---------------------------------------------------------------------------------
 // Per-voxel kernels: one wave spans 64 consecutive x (1 KiB float4 / 512 B float2 coalesced segments),
 // 4 rows per workgroup, one z-slice per blockIdx.z -> >= 16k workgroups at 256^3 (vs. the reference's
@@ -108,5 +139,36 @@ SOBFU_DEV float2 pack_tsdf(float sdf, float trunc, float weight) {
 constexpr int kBX = 64, kBY = 4;
 inline dim3 voxel_block() { return dim3(kBX, kBY, 1); }
 inline dim3 voxel_grid(int X, int Y, int Z) { return dim3((X + kBX - 1) / kBX, (Y + kBY - 1) / kBY, Z); }
+
+// XCD-aware workgroup -> tile map of those kernels.  The hardware deals consecutive workgroups (x fastest) round-robin to the 8 XCDs, each
+// with its own 4 MB L2.  Numbered as launched, a tile's +-y neighbours (the next workgroup but gx) sit on other XCDs, so a y stencil's rows
+// are fetched into several L2s.  Here XCD k owns the k-th eighth of the y range (a band of gy / 8 tile rows) at EVERY z: +-y neighbours
+// share its L2 except at the seven band seams, and +-z neighbours (the same tile of the next plane) stay on it as well -- a band of seven
+// float4 planes is 0.9 MB at 256^2.  (Whole z ranges per XCD were measured too: a 7-plane window of whole planes does not fit the L2 --
+// convolution_depth 183 -> 343 us.)  Grids whose tile-row count is not a multiple of 8 keep the launch order.  For kernels whose work per
+// voxel is uniform only: see VOXEL_XYZ_XCD in field_kernels.hip.
+SOBFU_DEV void xcd_tile(int& bx, int& by, int& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    if ((gy & 7u) != 0u) {
+        bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+        return;
+    }
+    const unsigned w = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), k = w & 7u, j = w >> 3;
+    const unsigned band = gy >> 3, per = gx * band;  // tile rows per band, tiles of a band in one plane
+    const unsigned z = j / per, rem = j - z * per, row = rem / gx;
+    bx = (int) (rem - row * gx);
+    by = (int) (k * band + row);
+    bz = (int) z;
+}
+
+// Marching launchers (a lane owns an (x, y) column of a z chunk; grid = voxel_grid(X, Y, chunks)): planes per chunk -- >= 512 workgroups on
+// the chip when the grid allows it (two per CU: long chunks beat occupancy, measured), never chunks shorter than 8 planes (a chunk re-reads
+// its z halo when it starts)
+inline int march_zc(int X, int Y, int Z) {
+    const long tiles = (long) ((X + kBX - 1) / kBX) * ((Y + kBY - 1) / kBY);
+    const long chunks = 512 / tiles > 1 ? 512 / tiles : 1;
+    const long zc = (Z + chunks - 1) / chunks;
+    return (int) (zc > 8 ? zc : 8);
+}
 
 }  // namespace sobfu_hip

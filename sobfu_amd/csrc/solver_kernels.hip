@@ -1,8 +1,8 @@
 // Solver kernels for gfx950.
 //
-// Part 1 -- launcher-for-launcher counterparts of include/sobfu/solver.hpp:109-136 (potential gradient, the
-//           three 1-D Sobolev convolutions, psi update), one lane per voxel, 3-D grids.
-// Part 2 -- the MI355X-native two-pass decomposition of one solver iteration (solver.cu:114-193):
+// (The launcher-for-launcher counterparts of include/sobfu/solver.hpp:109-136 -- potential gradient, the three 1-D Sobolev
+//  convolutions, psi update -- live in launcher_kernels.hip.)
+// The MI355X-native two-pass decomposition of one solver iteration (solver.cu:114-193):
 //             pass A  fused_potential_gradient : grad(phi_n o psi) + (-Lap psi) + combine      -> nabla_U
 //             pass B  fused_smooth_update_apply: (Sx+Sy+Sz) nabla_U, psi -= alpha*.., phi_n o psi, max||u||^2
 //           Both march along z with a register pipeline for the z taps and stage each xy plane (plus a
@@ -10,7 +10,7 @@
 //           HBM once per tile (+ halo), 112 B/voxel/iteration algorithmic traffic instead of the reference's
 //           456 B/voxel.
 //
-// Arithmetic is op-for-op the reference's (see sobfu_device.hpp): results are bit-identical to Part 1.
+// Arithmetic is op-for-op the reference's (see sobfu_device.hpp): results are bit-identical to the launcher-for-launcher kernels.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -35,67 +35,7 @@ struct Taps {
 };
 constexpr int kMaxMsgs = 18;  // 6 face + 12 edge neighbours of a 3-D tile
 
-// ============================================================================================================
-// Part 1: reference-shaped launchers
-// ============================================================================================================
-
-// calculate_potential_gradient_kernel -- solver.cu:15-33
-__global__ void __launch_bounds__(256) potential_gradient_kernel(const float2* __restrict__ pnp, const float2* __restrict__ pg,
-                                                                 const float4* __restrict__ grad, const float4* __restrict__ L,
-                                                                 float4* __restrict__ nU, float w_reg, size_t N) {
-    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float d = pnp[i].x - pg[i].x;
-    nU[i]   = add4(mul4(grad[i], d), mul4(L[i], w_reg));
-}
-
-// convolution_{rows,columns,depth}_kernel -- solver.cu:237-446: sum = 0; for j=-3..3: sum += S[3-j]*src(clamp(i+j))
-template <int AXIS>
-__global__ void __launch_bounds__(256) conv1d_kernel(float4* __restrict__ dst, const float4* __restrict__ src, Taps S, Dims d) {
-    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y, z = blockIdx.z;
-    if (x >= d.x || y >= d.y) return;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-    for (int j = -3; j <= 3; ++j) {
-        int xx = x, yy = y, zz = z;
-        if (AXIS == 0) xx = min(max(x + j, 0), d.x - 1);
-        if (AXIS == 1) yy = min(max(y + j, 0), d.y - 1);
-        if (AXIS == 2) zz = min(max(z + j, 0), d.z - 1);
-        float4 v = src[vidx(d, xx, yy, zz)];
-        float s  = S.s[3 - j];
-        sx += v.x * s;
-        sy += v.y * s;
-        sz += v.z * s;
-    }
-    float4* o = dst + vidx(d, x, y, z);
-    if (AXIS == 0) {
-        *o = f4(sx, sy, sz);  // rows assign (solver.cu:290)
-    } else {                  // columns / depth accumulate, w untouched (solver.cu:366,443; utils.hpp:253-258)
-        float4 c = *o;
-        c.x += sx;
-        c.y += sy;
-        c.z += sz;
-        *o = c;
-    }
-}
-
-// update_psi_kernel -- solver.cu:53-69
-__global__ void __launch_bounds__(256) update_psi_kernel(float4* __restrict__ psi, const float4* __restrict__ nUS,
-                                                         float4* __restrict__ updates, float alpha, size_t N) {
-    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float4 u   = mul4(nUS[i], alpha);
-    updates[i] = u;
-    float4 p   = psi[i];
-    p.x -= u.x;
-    p.y -= u.y;
-    p.z -= u.z;
-    psi[i] = p;
-}
-
-// ============================================================================================================
-// Part 2: fused two-pass iteration (device code in four included parts, one translation unit)
-// ============================================================================================================
+// the fused two-pass iteration: device code in four included parts, one translation unit
 #include "solver_iter_common.inl"
 #include "solver_pass_a.inl"
 #include "solver_pass_b.inl"
@@ -595,37 +535,6 @@ int launch_compact_leave(const float* c_psi, const float* pn2, float* psi4, floa
 }  // namespace sobfu_hip
 
 extern "C" {
-
-int sobfu_hip_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_grad, const float* d_L,
-                                 float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream) {
-    SOBFU_CHECK_ARGS(d_phi_n_psi && d_phi_global && d_grad && d_L && d_nabla_U && X > 0 && Y > 0 && Z > 0);
-    size_t N = (size_t) X * Y * Z;
-    hipLaunchKernelGGL(potential_gradient_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                       (const float2*) d_phi_n_psi, (const float2*) d_phi_global, (const float4*) d_grad, (const float4*) d_L,
-                       (float4*) d_nabla_U, w_reg, N);
-    return (int) hipGetLastError();
-}
-
-#define CONV_IMPL(name, AXIS)                                                                                       \
-    int name(float* d_dst, const float* d_src, const float taps[7], int w, int h, int d, void* stream) {            \
-        SOBFU_CHECK_ARGS(d_dst && d_src && taps && w > 0 && h > 0 && d > 0 && d_dst != d_src);                       \
-        Taps S;                                                                                                     \
-        for (int i = 0; i < 7; ++i) S.s[i] = taps[i];                                                               \
-        hipLaunchKernelGGL(conv1d_kernel<AXIS>, voxel_grid(w, h, d), voxel_block(), 0, (hipStream_t) stream,         \
-                           (float4*) d_dst, (const float4*) d_src, S, Dims{w, h, d});                               \
-        return (int) hipGetLastError();                                                                             \
-    }
-CONV_IMPL(sobfu_hip_convolution_rows, 0)
-CONV_IMPL(sobfu_hip_convolution_columns, 1)
-CONV_IMPL(sobfu_hip_convolution_depth, 2)
-
-int sobfu_hip_update_psi(float* d_psi, const float* d_nabla_U_S, float* d_updates, float alpha, int X, int Y, int Z, void* stream) {
-    SOBFU_CHECK_ARGS(d_psi && d_nabla_U_S && d_updates && X > 0 && Y > 0 && Z > 0);
-    size_t N = (size_t) X * Y * Z;
-    hipLaunchKernelGGL(update_psi_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                       (float4*) d_psi, (const float4*) d_nabla_U_S, (float4*) d_updates, alpha, N);
-    return (int) hipGetLastError();
-}
 
 int sobfu_hip_fused_potential_gradient(const float* d_phi_n_psi, const float* d_phi_global, const float* d_psi,
                                        float* d_nabla_U, float w_reg, int X, int Y, int Z, void* stream) {

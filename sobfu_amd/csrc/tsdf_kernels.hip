@@ -54,6 +54,9 @@ __global__ void __launch_bounds__(256) integrate_depth_kernel(IntegrateArgs a) {
 
 // TsdfIntegrator::operator()(phi_global, phi_n_psi) -- tsdf_volume.cu:103-130.  Pure streaming: 1-D grid,
 // two voxels (one float4) per lane.
+// (Streaming hints were measured on the three kernels above in round 6 and are NOT used: the conditional 8-byte stores of the fusion and of
+// integrate(depth) leave partial lines that the L2 merges only when they are stored plainly -- fusion 66 -> 106 us with the hints at 256^3;
+// the write-only initialisers gain nothing.)
 __global__ void __launch_bounds__(256) integrate_fuse_kernel(float2* __restrict__ g, const float2* __restrict__ n,
                                                              size_t N, float max_weight) {
     size_t i = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) * 2;
@@ -251,6 +254,8 @@ int sobfu_hip_bilateral_filter(const uint16_t* d_src, int sstep, uint16_t* d_dst
                                float sigma_spatial, float sigma_depth, void* stream) {
     SOBFU_CHECK_ARGS(d_src && d_dst && rows > 0 && cols > 0 && ksz > 0);
     sigma_depth *= 1000;  // metres -> mm (imgproc.cu:43)
+    // (VALU-bound on the 49 correctly rounded expf of a pixel -- the reference's build uses the 2-instruction __expf; block shapes 64x1 .. 16x16
+    //  all give 16 - 17 us at 640 x 480, measured in round 6)
     hipLaunchKernelGGL(bilateral_kernel, img_grid(rows, cols), dim3(64, 4), 0, (hipStream_t) stream, d_src, sstep, d_dst,
                        dstep, rows, cols, ksz, 0.5f / (sigma_spatial * sigma_spatial), 0.5f / (sigma_depth * sigma_depth));
     return (int) hipGetLastError();

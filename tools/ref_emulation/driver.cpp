@@ -13,6 +13,7 @@
 //            initSphere volumes from the identity (the set-up of the reference's test/solver_test.cpp:109-132)
 //   tsdf     kfusion::cuda::TsdfVolume::init{Sphere,Box,Ellipsoid,Plane,Torus}                 (tsdf_volume.cpp:108-146)
 //   depth    depthBilateralFilter -> depthTruncation -> computeDists -> TsdfVolume::integrate  (imgproc.cpp, tsdf_volume.cpp:95)
+//   launchers  timing aid: every launcher above `repeat` times, nothing written (GPU build)
 //   frames   SobFusion::operator() frame by frame (sob_fusion.cpp:71-145); its private volumes are read for the dumps
 //   mc       kfusion::cuda::MarchingCubes::run                                                 (marching_cubes.cpp:24-79)
 #include <cassert>
@@ -208,6 +209,67 @@ static void scenario_depth() {
     dump("volume", v.data());
 }
 
+// timing aid for the GPU build (tools/ref_hipbuild/launcher_table.py reads the per-kernel times from rocprofv3): every L1 launcher of the kernels and
+// depth scenarios `repeat` times back to back on the same uploaded arrays, nothing dumped
+static void scenario_launchers() {
+    Params p = make_params();
+    const int X = p.volume_dims[0], Y = p.volume_dims[1], Z = p.volume_dims[2], rep = (int) arg("repeat", 10);
+    const size_t N = (size_t) X * Y * Z;
+    const int3 dims = make_int3(X, Y, Z);
+    const float3 vsz = make_float3(1.f, 1.f, 1.f);
+    const float trunc = 1.f, eta = 1.f, max_weight = p.tsdf_max_weight;
+    auto up = [&](const char* name, size_t floats) {
+        kfusion::cuda::CudaData d;
+        d.upload(read_bin<float>(name, floats).data(), floats * 4);
+        return d;
+    };
+    auto fresh = [&](size_t floats) { return kfusion::cuda::CudaData(floats * 4); };
+    kfusion::cuda::CudaData vol = up("phi_n_psi", N * 2), pg = up("phi_global", N * 2), psi = up("psi", N * 4), fuse = up("fuse_in", N * 2);
+    kfusion::cuda::CudaData taps = up("taps", 7), grad = fresh(N * 4), L = fresh(N * 4), J1 = fresh(N * 16), nU = fresh(N * 4), nUS = fresh(N * 4),
+                            warped = fresh(N * 2), inv = fresh(N * 4);
+    kfusion::device::TsdfVolume vol_d(vol.ptr<float2>(), dims, vsz, trunc, eta, max_weight), pg_d(pg.ptr<float2>(), dims, vsz, trunc, eta, max_weight),
+        warped_d(warped.ptr<float2>(), dims, vsz, trunc, eta, max_weight), fuse_d(fuse.ptr<float2>(), dims, vsz, trunc, eta, max_weight);
+    sobfu::device::DeformationField psi_d(psi.ptr<float4>(), dims), inv_d(inv.ptr<float4>(), dims);
+    sobfu::device::TsdfGradient grad_d(grad.ptr<float4>(), dims);
+    sobfu::device::Laplacian L_d(L.ptr<float4>(), dims);
+    sobfu::device::PotentialGradient nU_d(nU.ptr<float4>(), dims), nUS_d(nUS.ptr<float4>(), dims);
+    sobfu::device::Jacobian J1_d(J1.ptr<Mat4f>(), dims);
+    sobfu::device::Reductor r(dims, vsz.x, trunc);
+    sobfu::device::set_convolution_kernel(taps.ptr<float>());
+    sobfu::device::Differentiator diff(psi_d);
+#define REP(...) for (int i_ = 0; i_ < rep; ++i_) { __VA_ARGS__; }
+    REP(sobfu::device::apply(vol_d, warped_d, psi_d))
+    REP(sobfu::device::TsdfDifferentiator(vol_d).calculate(grad_d))
+    REP(sobfu::device::SecondOrderDifferentiator(psi_d).calculate(L_d))
+    REP(diff.calculate_deformation_jacobian(J1_d))
+    REP(sobfu::device::calculate_potential_gradient(vol_d, pg_d, grad_d, L_d, nU_d, p.w_reg))
+    REP(sobfu::device::convolution_rows(nUS.ptr<float4>(), nU.ptr<float4>(), X, Y, Z))
+    REP(sobfu::device::convolution_columns(nUS.ptr<float4>(), nU.ptr<float4>(), X, Y, Z))
+    REP(sobfu::device::convolution_depth(nUS.ptr<float4>(), nU.ptr<float4>(), X, Y, Z))
+    sobfu::device::convolution_rows(nUS.ptr<float4>(), nU.ptr<float4>(), X, Y, Z);  // (bounded again after the accumulating repeats)
+    REP(sobfu::device::update_psi(psi_d, nUS_d, r.updates, p.alpha))
+    REP(r.max_update_norm())
+    REP(r.data_energy(pg.ptr<float2>(), vol.ptr<float2>()))
+    REP(r.reg_energy_sobolev(J1.ptr<Mat4f>()))
+    REP(sobfu::device::init_identity(inv_d); sobfu::device::estimate_inverse(psi_d, inv_d))
+    REP(kfusion::device::integrate(fuse_d, warped_d))
+    // per-frame side: clear, an analytic volume, the depth pre-steps and integrate(depth)
+    const int rows = p.rows, cols = p.cols;
+    std::vector<unsigned short> raw = read_bin<unsigned short>("depth", (size_t) rows * cols);
+    kfusion::cuda::Depth depth, filtered;
+    depth.upload(raw.data(), cols * sizeof(unsigned short), rows, cols);
+    kfusion::cuda::Dists dists;
+    kfusion::cuda::TsdfVolume v(p);
+    REP(v.clear())
+    REP(v.initSphere(make_float3((float) arg("sphere_cx"), (float) arg("sphere_cy"), (float) arg("sphere_cz")), (float) arg("sphere_r")))
+    REP(kfusion::cuda::depthBilateralFilter(depth, filtered, p.bilateral_kernel_size, p.bilateral_sigma_spatial, p.bilateral_sigma_depth))
+    REP(kfusion::cuda::depthTruncation(filtered, p.icp_truncate_depth_dist))
+    REP(kfusion::cuda::computeDists(filtered, dists, p.intr))
+    REP(v.integrate(dists, cv::Affine3f::Identity(), p.intr))
+#undef REP
+    cudaDeviceSynchronize();
+}
+
 // wall time of Solver::estimate_psi as the reference runs it (a host sync and a 128 KB read-back per iteration, solver.cu:172):
 // `repeat` solves of max_iter iterations from two initSphere volumes; prints seconds per solve (meaningful on the GPU build only)
 static void scenario_time() {
@@ -289,6 +351,7 @@ int main(int argc, char** argv) {
     else if (scenario == "solver") scenario_solver();
     else if (scenario == "tsdf") scenario_tsdf();
     else if (scenario == "depth") scenario_depth();
+    else if (scenario == "launchers") scenario_launchers();
     else if (scenario == "time") scenario_time();
 #ifndef REF_HIP_BUILD
     else if (scenario == "frames") scenario_frames();
