@@ -114,6 +114,51 @@ def test_reference_config3_on_gpu_equals_the_emulation_and_this_repo():
     assert r["log"] == f["log"]
 
 
+def _ellipsoid_solve_digests(dim, iters, P5):
+    """this repo's estimate_psi on two init_ellipsoid volumes at dim^3 -> word digests of the four arrays the reference's Solver leaves + the inputs"""
+    import torch
+
+    from sobfu_amd import ops
+
+    dims = (dim, dim, dim)
+    size = np.float32(P5["size"])
+    vs = np.array([size / np.float32(dim)] * 3, F32)
+    trunc = np.float32(P5["trunc_vox"]) * vs[0]
+    pg, pn = ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_ellipsoid(pg, vs, trunc, P5["r1"])
+    ops.init_ellipsoid(pn, vs, trunc, P5["r2"])
+    psi, psi_inv, pnp, pgi = ops.new_field(dims), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_identity(psi)
+    sv = ops.Solver(dims, max_iter=iters, alpha=P5["alpha"], w_reg=P5["w_reg"], max_update_norm=P5["max_update_norm"])
+    sv.estimate_psi(pg, pgi, pn, pnp, psi, psi_inv)
+    sv.close()
+    torch.cuda.synchronize()
+    out = {}
+    for k, t in (("phi_global", pg), ("phi_n", pn), ("psi", psi), ("phi_n_psi", pnp), ("psi_inv", psi_inv), ("phi_global_psi_inv", pgi)):
+        out[k] = R.word_digest(t.cpu().numpy())
+    moved = float((psi.cpu().numpy()[..., 0] - np.arange(dim, dtype=F32)[None, None, :]).__abs__().max())
+    return out, moved
+
+
+@pytest.mark.parametrize("dim,iters", [(96, 12), (512, 6)])
+def test_reference_on_gpu_equals_this_repo_at_config5_size(dim, iters):
+    """BASELINE config 5's grid (512^3, params_umbrella.ini solver values) -- a size the host emulation cannot run: the reference's own kernels on the MI355X
+    and this repo's solver, both from two initEllipsoid volumes built on the device (no device libm on the way) and the identity, through the whole
+    Solver::estimate_psi (iterations + 48 inverse sweeps + both warps).  The gigabyte arrays are compared by a 64-bit word digest (96^3: the same
+    comparison at a size that takes a second)."""
+    P5 = dict(size=1.0, trunc_vox=8.0, alpha=0.001, w_reg=0.2, max_update_norm=1e-10, r1=(0.20, 0.16, 0.14), r2=(0.205, 0.158, 0.142))
+    kw = dict(X=dim, Y=dim, Z=dim, size_x=1.0, size_y=1.0, size_z=1.0, trunc_vox=8.0, eta_vox=3.0, max_weight=128.0, s=7, alpha=P5["alpha"], w_reg=P5["w_reg"],
+              max_update_norm=P5["max_update_norm"], verbosity=0, max_iter=iters, ell_rx=P5["r1"][0], ell_ry=P5["r1"][1], ell_rz=P5["r1"][2], ell2_rx=P5["r2"][0],
+              ell2_ry=P5["r2"][1], ell2_rz=P5["r2"][2], digest=1)
+    kw["lambda"] = 0.1
+    names = ("phi_global", "phi_n", "psi", "phi_n_psi", "psi_inv", "phi_global_psi_inv")
+    r = R.run("ieee", "solver", {}, {k: (np.uint64, None) for k in names}, **kw)
+    ours, moved = _ellipsoid_solve_digests(dim, iters, P5)
+    assert moved > 1e-4  # the solve did something
+    for k in names:
+        assert r[k] == ours[k], (dim, k, hex(r[k]), hex(ours[k]))
+
+
 def test_fast_math_build_of_the_reference_distance():
     """the reference compiled with hipcc's analogues of its nvcc flags against its IEEE build, BASELINE config 3 from initSphere on the GPU:
     the warp fields differ by less than 1e-5 in total L2 (the north star's bar), the per-iteration max norms agree to 1e-6 relative"""

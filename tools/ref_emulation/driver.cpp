@@ -17,6 +17,7 @@
 //   frames   SobFusion::operator() frame by frame (sob_fusion.cpp:71-145); its private volumes are read for the dumps
 //   mc       kfusion::cuda::MarchingCubes::run                                                 (marching_cubes.cpp:24-79)
 #include <cassert>
+#include <cstdint>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -58,10 +59,17 @@ static void write_bin(const std::string& name, const void* p, size_t bytes) {
     std::ofstream f(g_dir + "/out_" + name + ".bin", std::ios::binary);
     f.write((const char*) p, bytes);
 }
+// digest=1: an array leaves as 8 bytes -- sum over its 32-bit words w_i of w_i * (2 i + 1) mod 2^64 (tests/ref_hip_runner.py computes the same) -- for sizes whose
+// arrays are gigabytes (BASELINE config 5's 512^3 on the GPU build)
+static bool g_digest = false;
 static void dump(const std::string& name, const kfusion::cuda::CudaData& d) {
     std::vector<char> h(d.sizeBytes());
     d.download(h.data());
-    write_bin(name, h.data(), h.size());
+    if (!g_digest) return write_bin(name, h.data(), h.size());
+    const uint32_t* w = (const uint32_t*) h.data();
+    uint64_t sum = 0;
+    for (size_t i = 0, n = h.size() / 4; i < n; ++i) sum += (uint64_t) w[i] * (2 * (uint64_t) i + 1);
+    write_bin(name, &sum, sizeof sum);
 }
 
 static Params make_params() {
@@ -155,6 +163,10 @@ static void scenario_solver() {
     if (g_args.count("sphere_r")) {  // the set-up of the reference's own test/solver_test.cpp:109-132: two initSphere volumes, identity start
         pg->initSphere(make_float3((float) arg("sphere_cx"), (float) arg("sphere_cy"), (float) arg("sphere_cz")), (float) arg("sphere_r"));
         pn->initSphere(make_float3((float) arg("sphere2_cx"), (float) arg("sphere2_cy"), (float) arg("sphere2_cz")), (float) arg("sphere_r"));
+        dump("phi_global", pg->data()), dump("phi_n", pn->data());
+    } else if (g_args.count("ell_rx")) {  // two initEllipsoid volumes (no device libm on the way: every build gives the same bits), identity start
+        pg->initEllipsoid(make_float3((float) arg("ell_rx"), (float) arg("ell_ry"), (float) arg("ell_rz")));
+        pn->initEllipsoid(make_float3((float) arg("ell2_rx"), (float) arg("ell2_ry"), (float) arg("ell2_rz")));
         dump("phi_global", pg->data()), dump("phi_n", pn->data());
     } else {
         pg->data().upload(read_bin<float>("phi_global", N * 2).data(), N * 8);
@@ -339,6 +351,7 @@ int main(int argc, char** argv) {
         if (!eq) return fprintf(stderr, "ref_emu: bad argument %s\n", argv[i]), 2;
         g_args[std::string(argv[i], (size_t) (eq - argv[i]))] = atof(eq + 1);
     }
+    g_digest = arg("digest", 0.0) != 0.0;
     // identity poses must stay bit-exact identities through the stand-in Affine3 (shim/opencv2/core/affine.hpp)
     {
         cv::Affine3f pose = cv::Affine3f().translate(cv::Vec3f(-0.25f, -0.125f, 0.5f)), v2c = cv::Affine3f::Identity().inv() * pose;
