@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import fixture_inputs as FI  # noqa: E402
 import ref_hip_runner as R  # noqa: E402
-from test_reference_fixtures import KERNEL_DIMS, SOLVER_NAMES, _sphere_pair, _tsdf_params, check, kernel_fixture, load, same  # noqa: E402
+from test_reference_fixtures import KERNEL_DIMS, SOLVER_NAMES, _sphere_pair, _tsdf_params, check, hip_launchers_against, kernel_fixture, load, same  # noqa: E402
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref/reference_hip_* were not built (needs /root/reference: build container)")]
 F32 = np.float32
@@ -46,6 +46,21 @@ def test_reference_kernels_on_gpu_equal_the_emulation(dims):
             check(f, k, r[k])
     # energies: the reference's tree on 64-wide wavefronts pairs the same elements (shared-memory branch: __CUDA_ARCH__ is undefined under hipcc)
     assert same(r["scalars"], f["scalars"]), (r["scalars"], f["scalars"])
+
+
+@pytest.mark.parametrize("dims", [(200, 131, 77), (320, 160, 136)])
+def test_this_repo_launchers_against_the_reference_on_gpu_at_sizes_without_fixtures(dims):
+    """every launcher (and the two fused passes) against the reference's own kernels run here, at sizes the emulation's fixtures do not reach: rows of three
+    full waves + a partial one, ragged y / z (200 x 131 x 77); 7 M cells (320 x 160 x 136) -- the streaming instantiations, the XCD band map (40 tile rows), a
+    convolution_depth march of two 68-plane chunks"""
+    X, Y, Z = dims
+    ins = FI.kernel_inputs(dims, 23, 0.45)
+    w_reg, alpha, max_weight = 0.2, 0.1, 64.0
+    J = (F32, (Z, Y, X, 4, 4))
+    outs = dict(grad=fld(dims), laplacian=fld(dims), jacobian0=J, jacobian1=J, nabla_U=fld(dims), conv_rows=fld(dims), conv_cols=fld(dims), conv_depth=fld(dims),
+                psi_new=fld(dims), updates=fld(dims), warped=vol(dims), psi_inv=fld(dims), fused=vol(dims), scalars=(F32, (6,)))
+    r = R.run("ieee", "kernels", ins, outs, X=X, Y=Y, Z=Z, w_reg=w_reg, alpha=alpha, max_weight=max_weight)
+    hip_launchers_against(r, ins, dims, w_reg, alpha, max_weight)
 
 
 @pytest.mark.parametrize("name", SOLVER_NAMES)

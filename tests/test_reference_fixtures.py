@@ -350,9 +350,15 @@ def _dev(a):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims", KERNEL_DIMS)
 def test_hip_launchers(dims):
+    f, ins, w_reg, alpha, max_weight = kernel_fixture(dims)
+    hip_launchers_against(f, ins, dims, w_reg, alpha, max_weight)
+
+
+def hip_launchers_against(f, ins, dims, w_reg, alpha, max_weight):
+    """every launcher of the C ABI (and the two fused passes) on `ins` against the reference's arrays in `f` (a fixture, or the outputs of the
+    reference's GPU build: tests/test_gpu_reference_hipbuild.py)"""
     from sobfu_amd import ops
 
-    f, ins, w_reg, alpha, max_weight = kernel_fixture(dims)
     g, L, nU, nUS, upd, inv = (ops.new_field(dims) for _ in range(6))
     vol, pg, psi0 = _dev(ins["phi_n_psi"]), _dev(ins["phi_global"]), _dev(ins["psi"])
     ops.tsdf_gradient(vol, g)
