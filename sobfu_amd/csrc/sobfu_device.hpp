@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace sobfu_hip {
 
@@ -130,7 +131,11 @@ SOBFU_DEV float2 ld2(const float2* p) {
     return make_float2(t.x, t.y);
 }
 // grids of more cells than this stream (a float4 field of 3.3 M cells is 53 MB: a launcher chain's few arrays still fit the Infinity Cache)
-inline bool launcher_streams(int X, int Y, int Z) { return (long) X * Y * Z > 3300000L; }
+// SOBFU_LAUNCHER_NT=0 / 1 overrides (measurement: tools/ref_hipbuild/launcher_table.py).
+inline bool launcher_streams(int X, int Y, int Z) {
+    if (const char* e = getenv("SOBFU_LAUNCHER_NT")) return e[0] == '1';
+    return (long) X * Y * Z > 3300000L;
+}
 
 // ---- launch geometry ---------------------------------------------------------------------------------
 // Per-voxel kernels: one wave spans 64 consecutive x (1 KiB float4 / 512 B float2 coalesced segments),

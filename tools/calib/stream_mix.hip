@@ -83,6 +83,60 @@ __global__ void __launch_bounds__(256) write_x3(Arrays a, size_t n) {
     if (i < n) st3<false>(a.v2, i, v3f{1.f, 2.f, 3.f});
 }
 
+// ---- the same with hints that REACH the hardware (round 6).  hipcc drops the nontemporal flag of __builtin_nontemporal_load/_store on the
+// 4-byte-aligned 12-byte vector type (found in the ISA in round 5), so the `_nt` patterns above stream their 12-byte accesses plainly.  Below they
+// go through buffer instructions, whose cache-policy operand carries the hint -- as the solver's pass B does (NTBUF) -- and a 16-byte copy shows
+// what the launcher-shaped kernels' float4 streams reach.
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) bytes, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ v3f bld3(__amdgpu_buffer_rsrc_t r, size_t i) {
+    const v3u t = __builtin_amdgcn_raw_buffer_load_b96(r, (int) (12 * i), 0, NT ? 2 : 0);
+    return v3f{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z)};
+}
+template <bool NT>
+__device__ __forceinline__ void bst3(__amdgpu_buffer_rsrc_t r, size_t i, v3f v) {
+    const v3u t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+    __builtin_amdgcn_raw_buffer_store_b96(t, r, (int) (12 * i), 0, NT ? 2 : 0);
+}
+// LOADS: which of pass B's two 12-byte loads stream (bit 0: nabla_U, bit 1: psi); STORES: psi and F stores stream
+template <int LOADS, bool STORES>
+__global__ void __launch_bounds__(256) mix_b_buf(Arrays a, size_t n) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const __amdgpu_buffer_rsrc_t r0 = rsrc(a.v0, 12 * n), r1 = rsrc(a.v1, 12 * n), r2 = rsrc(a.v2, 12 * n);
+    const v3f u = bld3<(LOADS & 1) != 0>(r1, i), psi = bld3<(LOADS & 2) != 0>(r0, i);
+    const v3f p = psi - u;
+    bst3<STORES>(r2, i, p);
+    st1<STORES>(a.f2, i, p.x + p.y + p.z);
+}
+template <bool NT_LOADS, bool NT_STORE>
+__global__ void __launch_bounds__(256) mix_a_buf(Arrays a, size_t n) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const __amdgpu_buffer_rsrc_t r0 = rsrc(a.v0, 12 * n), r1 = rsrc(a.v1, 12 * n);
+    const v3f psi = bld3<NT_LOADS>(r0, i);
+    const float f = ld1<NT_LOADS>(a.f0, i), g = ld1<true>(a.f1, i);
+    bst3<NT_STORE>(r1, i, psi * (f - g));
+}
+template <bool NT_LOAD, bool NT_STORE>
+__global__ void __launch_bounds__(256) copy_x3_buf(Arrays a, size_t n) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) bst3<NT_STORE>(rsrc(a.v2, 12 * n), i, bld3<NT_LOAD>(rsrc(a.v0, 12 * n), i));
+}
+// 16-byte elements over the first 3/4 of the same arrays (n * 12 bytes hold 3 n / 4 float4s)
+template <bool NT_LOAD, bool NT_STORE>
+__global__ void __launch_bounds__(256) copy_x4(Arrays a, size_t n) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n / 4 * 3) return;
+    const v4f v = NT_LOAD ? __builtin_nontemporal_load((const v4f*) a.v0 + i) : ((const v4f*) a.v0)[i];
+    if (NT_STORE) __builtin_nontemporal_store(v, (v4f*) a.v2 + i);
+    else ((v4f*) a.v2)[i] = v;
+}
+
 template <class K>
 static void run(const char* name, K kernel, const Arrays& a, size_t n, int reps, double bytes_per_voxel) {
     const dim3 grid((unsigned) ((n + 255) / 256)), block(256);
@@ -102,7 +156,7 @@ static void run(const char* name, K kernel, const Arrays& a, size_t n, int reps,
     }
     std::sort(us.begin(), us.end());
     const double t = us[us.size() / 2];
-    std::printf("%-10s %6.1f B/voxel  %7.1f us/launch  %7.1f GB/s  (min %.1f, max %.1f us)\n", name, bytes_per_voxel, t,
+    std::printf("%-22s %6.1f B/voxel  %7.1f us/launch  %7.1f GB/s  (min %.1f, max %.1f us)\n", name, bytes_per_voxel, t,
                 bytes_per_voxel * n / t * 1e-3, us.front(), us.back());
 }
 
@@ -159,6 +213,19 @@ int main(int argc, char** argv) {
     run("mix_b", mix_b<false>, a, n, reps, 40);
     run("mix_b_nt", mix_b<true>, a, n, reps, 40);
     run("mix_b_nt_rev", mix_b<true, true>, a, n, reps, 40);
+    std::printf("-- hints that reach the hardware: 12-byte accesses through buffer instructions, 16-byte through the builtin\n");
+    run("copy_x3 buf plain", copy_x3_buf<false, false>, a, n, reps, 24);
+    run("copy_x3 buf nt st", copy_x3_buf<false, true>, a, n, reps, 24);
+    run("copy_x3 buf nt ld+st", copy_x3_buf<true, true>, a, n, reps, 24);
+    run("copy_x4 plain", copy_x4<false, false>, a, n, reps, 24);  // (3/4 n float4s = the same 24 B per voxel of n)
+    run("copy_x4 nt st", copy_x4<false, true>, a, n, reps, 24);
+    run("copy_x4 nt ld+st", copy_x4<true, true>, a, n, reps, 24);
+    run("mix_a buf plain", mix_a_buf<false, false>, a, n, reps, 32);
+    run("mix_a buf nt st", mix_a_buf<false, true>, a, n, reps, 32);
+    run("mix_a buf nt all", mix_a_buf<true, true>, a, n, reps, 32);
+    run("mix_b buf plain", mix_b_buf<0, false>, a, n, reps, 40);
+    run("mix_b buf as pass B", mix_b_buf<2, true>, a, n, reps, 40);  // psi load + both stores stream, nabla_U load plain
+    run("mix_b buf nt all", mix_b_buf<3, true>, a, n, reps, 40);
     run_pair("mix_a_nt + mix_b_nt", mix_a<true>, mix_b<true>, a, n, reps, 72);
     run_pair("mix_a_nt + mix_b_rev", mix_a<true>, mix_b<true, true>, a, n, reps, 72);
     return 0;

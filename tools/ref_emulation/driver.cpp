@@ -249,7 +249,11 @@ static void scenario_launchers() {
     sobfu::device::Reductor r(dims, vsz.x, trunc);
     sobfu::device::set_convolution_kernel(taps.ptr<float>());
     sobfu::device::Differentiator diff(psi_d);
-#define REP(...) for (int i_ = 0; i_ < rep; ++i_) { __VA_ARGS__; }
+    // flush=1: 512 MB are overwritten before every call, so that no call finds its inputs in the 256 MB Infinity Cache because the call before it left them there
+    kfusion::cuda::CudaData flush_buf;
+    const size_t flush_bytes = (size_t) 512 << 20;
+    if (arg("flush", 0.0) != 0.0) flush_buf.create(flush_bytes);
+#define REP(...) for (int i_ = 0; i_ < rep; ++i_) { if (!flush_buf.empty()) cudaMemset(flush_buf.ptr<char>(), i_, flush_bytes); __VA_ARGS__; }
     REP(sobfu::device::apply(vol_d, warped_d, psi_d))
     REP(sobfu::device::TsdfDifferentiator(vol_d).calculate(grad_d))
     REP(sobfu::device::SecondOrderDifferentiator(psi_d).calculate(L_d))

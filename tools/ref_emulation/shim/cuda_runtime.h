@@ -207,6 +207,7 @@ static inline cudaError_t cudaMallocPitch(void** p, size_t* pitch, size_t width_
     return cudaSuccess;
 }
 static inline cudaError_t cudaMemcpy(void* d, const void* s, size_t n, cudaMemcpyKind) { return memcpy(d, s, n), cudaSuccess; }
+static inline cudaError_t cudaMemset(void* d, int v, size_t n) { return memset(d, v, n), cudaSuccess; }
 static inline cudaError_t cudaMemcpy2D(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, cudaMemcpyKind) {
     for (size_t r = 0; r < h; ++r) memcpy((char*) d + r * dp, (const char*) s + r * sp, w);
     return cudaSuccess;

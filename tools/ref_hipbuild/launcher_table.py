@@ -71,7 +71,7 @@ def pick(table, kernels, used):
 def reference_times(exe, d, kw, repeat):
     out = os.path.join(d, "prof")
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "-o", "r", "--", exe, "launchers", d, "repeat=%d" % repeat] +
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "-o", "r", "--", exe, "launchers", d, "repeat=%d" % repeat, "flush=1"] +
                        ["%s=%r" % (k, float(v)) for k, v in kw.items()], capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
     db = os.path.join(out, "r_results.db")
     assert os.path.exists(db), (r.stdout + r.stderr)[-3000:]
@@ -90,8 +90,9 @@ def workload(dim):
     return P, ins, intr, FI.bench_sequence_frame(intr, 0.75, P["t_z"], 0.75 / dim, 1)
 
 
-def ours(dim, repeat):
-    """every launcher through sobfu_amd.ops `repeat` times back to back -> microseconds per call from HIP events (in the order of ROWS)"""
+def ours(dim, repeat, flush=False):
+    """every launcher through sobfu_amd.ops `repeat` times -> microseconds per call from HIP events, back to back (in the order of ROWS); flush: 512 MB are
+    overwritten before every call instead (cold Infinity Cache; the kernel times are then read from rocprofv3 by the parent)"""
     import torch
 
     from sobfu_amd import ops
@@ -110,7 +111,15 @@ def ours(dim, repeat):
     filt = ops.bilateral_filter(draw, 7, 4.5, 0.04)
     dists = ops.compute_dists(filt, intr)
 
+    scratch = torch.empty(512 << 20, dtype=torch.uint8, device="cuda") if flush else None
+
     def timed(fn):
+        if flush:
+            for i in range(repeat):
+                scratch.fill_(i)
+                fn()
+            torch.cuda.synchronize()
+            return 0.0
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -144,11 +153,116 @@ def ours(dim, repeat):
     return out
 
 
+CHAIN = [("estimate_gradient", "tsdf_gradient_kernel", "estimate_gradient_kernel"), ("deformation Jacobian", "jacobian_kernel", "estimate_deformation_jacobian_kernel"),
+         ("laplacian", "laplacian_kernel", "estimate_laplacian_kernel"), ("calculate_potential_gradient", "potential_gradient_kernel", "calculate_potential_gradient_kernel"),
+         ("convolution_rows", "conv1d_kernel<0", "convolution_rows_kernel"), ("convolution_columns", "conv1d_kernel<1", "convolution_columns_kernel"),
+         ("convolution_depth", "conv_depth_march_kernel", "convolution_depth_kernel"), ("update_psi", "update_psi_kernel", "update_psi_kernel"),
+         ("apply", "apply_kernel", "apply_kernel"), ("max_update_norm (device part)", "tree_max_kernel", "reduce_max_kernel")]
+
+
+def chain(dim, iters):
+    """this repo's launchers in the order of the reference's iteration (solver.cu:114-193: gradient, Jacobian, Laplacian, potential gradient, three convolutions,
+    update, warp, max-norm with its read-back) on bench.py's workload, one stream -> microseconds per iteration (HIP events)"""
+    import torch
+
+    import bench
+    from sobfu_amd import ops
+
+    P = bench.boxing_params(dim)
+    dims = P["dims"]
+    c0, c1, r = bench.sphere_pair(P)
+    pg, pn, pnp = ops.new_volume(dims), ops.new_volume(dims), ops.new_volume(dims)
+    ops.init_sphere(pg, P["vs"], P["trunc"], P["eta"], c0, r)
+    ops.init_sphere(pn, P["vs"], P["trunc"], P["eta"], c1, r)
+    psi, grad, L, nU, nUS, upd = (ops.new_field(dims) for _ in range(6))
+    J = ops.new_jacobian(dims)
+    ops.init_identity(psi)
+    S = ops.sobolev_filter(P["s"], P["lam"])
+    ops.apply(pn, pnp, psi)
+
+    def one():
+        ops.tsdf_gradient(pnp, grad)
+        ops.jacobian(psi, J, 1)
+        ops.laplacian(psi, L)
+        ops.potential_gradient(pnp, pg, grad, L, nU, P["w_reg"])
+        ops.convolution_rows(nUS, nU, S)
+        ops.convolution_columns(nUS, nU, S)
+        ops.convolution_depth(nUS, nU, S)
+        ops.update_psi(psi, nUS, upd, P["alpha"])
+        ops.apply(pn, pnp, psi)
+        return ops.max_update_norm(upd)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        one()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / iters
+
+
+def chain_table(dim, exe):
+    """the reference's iteration as the reference decomposes it: its own kernels in its own loop (three streams, a host synchronisation and a read-back per
+    iteration) and this repo's launcher-shaped kernels chained in the same order, kernel by kernel IN the chain (no call finds the previous call's arrays cached:
+    2.3 GB cycle through per iteration at 256^3) -- with the streaming hints and without -- beside the two fused passes the solver really runs"""
+    import json
+
+    import bench
+
+    P = bench.boxing_params(dim)
+    c0, c1, r = bench.sphere_pair(P)
+    kw = dict(X=dim, Y=dim, Z=dim, size_x=0.75, size_y=0.75, size_z=0.75, trunc_vox=48.0, eta_vox=3.0, max_weight=128.0, s=P["s"], alpha=P["alpha"], w_reg=P["w_reg"],
+              max_update_norm=P["max_update_norm"], verbosity=0, sphere_cx=c0[0], sphere_cy=c0[1], sphere_cz=c0[2], sphere2_cx=c1[0], sphere2_cy=c1[1], sphere2_cz=c1[2],
+              sphere_r=r, repeat=2, max_iter=50)
+    kw["lambda"] = P["lam"]
+    d = tempfile.mkdtemp(prefix="chain_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {}
+    try:
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(d, "ref"), "-o", "r", "--", exe, "time", d] + ["%s=%r" % (k, float(v)) for k, v in kw.items()],
+                       capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
+        res["ref"] = top_kernels(os.path.join(d, "ref", "r_results.db"))
+        subprocess.run([exe, "time", d] + ["%s=%r" % (k, float(v)) for k, v in kw.items()], capture_output=True, text=True, timeout=900)  # (wall time: not under the profiler)
+        ref_wall = min(float(x) for x in open(os.path.join(d, "out_time.txt")).read().split()) / 50 * 1e6
+        for tag, nt in (("nt", "1"), ("plain", "0")):
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(d, tag), "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--chain", str(dim), "30"],
+                               capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(env, SOBFU_LAUNCHER_NT=nt))
+            assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+            res[tag] = top_kernels(os.path.join(d, tag, "r_results.db"))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--chain", str(dim), "30"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SOBFU_LAUNCHER_NT=nt))
+            res[tag + "_wall"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])[0]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    print("\n### The reference's iteration, kernel by kernel IN its loop, %d^3 (bench.py's workload)\n" % dim)
+    print("Kernel time from `rocprofv3 --kernel-trace --stats` inside the running loop: the reference's own kernels in its own `estimate_psi` (gradient, Jacobian and Laplacian on "
+          "three concurrent streams, a host synchronisation and a 128 KB read-back per iteration), this repo's launcher-shaped kernels chained in the same order on one stream "
+          "with the streaming hints (the default beyond 3.3 M cells) and without (`SOBFU_LAUNCHER_NT=0`). Nothing is warm here: the chain cycles 2.3 GB per iteration at 256^3.\n")
+    print("| launcher | reference kernel in its loop, µs | this repo, streaming hints, µs | this repo, plain, µs |\n|---|---|---|---|")
+    tot = {"ref": 0.0, "nt": 0.0, "plain": 0.0}
+    for name, mine, theirs in CHAIN:
+        row = []
+        for tag, sub in (("ref", theirs), ("nt", mine), ("plain", mine)):
+            v = [avg for k, (calls, avg) in res[tag].items() if sub in k and (tag != "ref" or "rocclr" not in k)]
+            row.append(v[0] if v else float("nan"))
+            tot[tag] += row[-1]
+        print("| %s | %.1f | %.1f | %.1f |" % (name, *row))
+    print("| **sum of kernel times** | %.0f (overlapping streams) | %.0f | %.0f |" % (tot["ref"], tot["nt"], tot["plain"]))
+    print("| **wall time per iteration** (not under the profiler) | %.0f (a 50-iteration `estimate_psi` / 50: its inverse and warps included) | %.0f | %.0f |" % (ref_wall, res["nt_wall"], res["plain_wall"]))
+    print("\n(The solver's two fused passes do the same iteration in ≈ 235 – 245 µs: `bench.py`.)")
+
+
 def main():
     import json
 
-    if sys.argv[1:2] == ["--ours"]:  # the child under rocprofv3: this repo's launchers, event times on the last line
-        print(json.dumps(ours(int(sys.argv[2]), int(sys.argv[3]))))
+    if sys.argv[1:2] == ["--chain"]:
+        print(json.dumps([chain(int(sys.argv[2]), int(sys.argv[3]))]))
+        return
+
+    if sys.argv[1:2] == ["--ours"]:  # the child: this repo's launchers; event times on the last line (back to back), or flushed launches under rocprofv3
+        print(json.dumps(ours(int(sys.argv[2]), int(sys.argv[3]), flush=len(sys.argv) > 4 and sys.argv[4] == "flush")))
         return
     dim = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     repeat = 10
@@ -164,20 +278,24 @@ def main():
         depth.tofile(os.path.join(d, "depth.bin"))
         ref = reference_times(exe, d, P, repeat)
         out = os.path.join(d, "ours")
-        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--ours", str(dim), str(repeat)],
-                           capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--ours", str(dim), str(repeat), "flush"],
+                           capture_output=True, text=True, timeout=1800, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        mine = top_kernels(os.path.join(out, "r_results.db"))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ours", str(dim), str(repeat)], capture_output=True, text=True, timeout=1800)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
         t_events = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
-        mine = top_kernels(os.path.join(out, "r_results.db"))
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
-    print("Launcher by launcher at %d^3 on one MI355X, kernel time (`rocprofv3 --kernel-trace --stats`, average of %d calls, both sides): the reference's own kernels (hipcc "
-          "build through a name-map header, `tools/ref_hipbuild`) and this repo's C-ABI launchers on the same arrays. `call` = what a caller of this repo's launcher sees "
-          "(HIP events around %d back-to-back calls: launch gaps and, for the reductions, the read-back and the host finish included). Bytes per voxel: SURVEY 8(a)'s column for "
-          "the launcher as the reference decomposes the work; fraction = kernel bytes/s over 8 TB/s. The solver does not run these kernels in its loop (it runs the two fused "
-          "passes `bench.py` measures); they are the drop-in surface.\n" % (dim, repeat + 2, repeat))
-    print("| launcher (SURVEY row) | reference kernels, µs | this repo's kernels, µs | × | call, µs | B/voxel | GB/s | fraction of 8 TB/s |\n|---|---|---|---|---|---|---|---|")
+    print("Launcher by launcher at %d^3 on one MI355X, kernel time (`rocprofv3 --kernel-trace --stats`, average of %d calls, both sides, **512 MB overwritten before every call** so "
+          "that no call finds its inputs in the 256 MB Infinity Cache because the call before it left them there): the reference's own kernels (hipcc build through a name-map "
+          "header, `tools/ref_hipbuild`) and this repo's C-ABI launchers on the same arrays%s. `warm call` = HIP events around %d back-to-back calls of this repo's launcher on the "
+          "same arrays (launch gaps and, for the reductions, the read-back and the host finish included; inputs up to 256 MB come from the Infinity Cache there). Bytes per voxel: "
+          "SURVEY 8(a)'s column for the launcher as the reference decomposes the work; fraction = kernel bytes/s over 8 TB/s. The solver does not run these kernels in its loop "
+          "(it runs the two fused passes `bench.py` measures); they are the drop-in surface.\n"
+          % (dim, repeat, " (SOBFU_LAUNCHER_NT=%s)" % os.environ["SOBFU_LAUNCHER_NT"] if "SOBFU_LAUNCHER_NT" in os.environ else "", repeat))
+    print("| launcher (SURVEY row) | reference kernels, µs | this repo's kernels, µs | × | warm call, µs | B/voxel | GB/s | fraction of 8 TB/s |\n|---|---|---|---|---|---|---|---|")
     used_r, used_m = set(), set()
     for (name, rk, mk, bpv), ev in zip(ROWS, t_events):
         tr, dr = pick(ref, rk, used_r)
@@ -188,6 +306,7 @@ def main():
     rest = [k for k in ref if k not in used_r and "rocclr" not in k]
     if rest:
         print("\nreference kernels not in a row: " + "; ".join("%s (%d calls, %.1f µs)" % (k.split("(")[0], ref[k][0], ref[k][1]) for k in rest))
+    chain_table(dim, exe)
 
 
 if __name__ == "__main__":

@@ -101,6 +101,7 @@ typedef hipMemcpyKind cudaMemcpyKind;
 #define cudaGetDeviceProperties hipGetDeviceProperties
 #define cudaFree hipFree
 #define cudaMemcpy hipMemcpy
+#define cudaMemset hipMemset
 #define cudaMemcpy2D hipMemcpy2D
 #define cudaMallocPitch hipMallocPitch
 template <class T>
