@@ -45,14 +45,25 @@ __global__ void __launch_bounds__(256) apply_kernel(const float2* __restrict__ p
 // The float iteration soon repeats itself: once a sweep returns its input bit for bit every later sweep does too, and once
 // it returns the value before that (period 2) the tail just alternates -- in both cases the value after n_sweeps is known
 // and the lane stops (same bits as running all sweeps; typically < 10 of the 48 are needed).
+// From one sweep to the next p moves by a fraction of a cell, so the eight corners it interpolates between are almost always the eight of the
+// sweep before: they stay in registers (as displacements, psi - id of the corner cell: what interpolate_field_inv reads) and are re-loaded only
+// when p enters another cell -- a sweep then costs arithmetic instead of eight dependent gathers.  Same values, same lerp chain, same bits.
 SOBFU_DEV float4 inverse_fixed_point(const float4* __restrict__ psi, const Dims& pd, float4 v, const float4& id, int n_sweeps) {
     float4 w = v;  // p_it = v, p_(it-1) = w
     auto same = [](const float4& a, const float4& b) {
         return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
                __float_as_uint(a.z) == __float_as_uint(b.z);
     };
+    int cx = -1, cy = -1, cz = -1, hx = -1, hy = -1, hz = -1;  // the cell whose corners are held
+    float4 hhh, hhg, hgh, hgg, ghh, ghg, ggh, ggg;             // (x, y, z) corner: h = upper index, g = lower (interp_disp's order)
     for (int it = 0; it < n_sweeps; ++it) {
-        const float4 u  = interp_disp(psi, pd, v.x, v.y, v.z);
+        const Tri a = tri_setup(v.x, pd.x), b = tri_setup(v.y, pd.y), c = tri_setup(v.z, pd.z);
+        if (a.g != cx || b.g != cy || c.g != cz || a.h != hx || b.h != hy || c.h != hz) {
+            cx = a.g, cy = b.g, cz = c.g, hx = a.h, hy = b.h, hz = c.h;
+            hhh = disp_at(psi, pd, a.h, b.h, c.h), hhg = disp_at(psi, pd, a.h, b.h, c.g), hgh = disp_at(psi, pd, a.h, b.g, c.h), hgg = disp_at(psi, pd, a.h, b.g, c.g);
+            ghh = disp_at(psi, pd, a.g, b.h, c.h), ghg = disp_at(psi, pd, a.g, b.h, c.g), ggh = disp_at(psi, pd, a.g, b.g, c.h), ggg = disp_at(psi, pd, a.g, b.g, c.g);
+        }
+        const float4 u = lerp4(lerp4(lerp4(hhh, hhg, c.t), lerp4(hgh, hgg, c.t), b.t), lerp4(lerp4(ghh, ghg, c.t), lerp4(ggh, ggg, c.t), b.t), a.t);  // interp_disp
         const float4 nv = sub4(id, mul4(u, 1.f));  // p_(it+1)
         const int left  = n_sweeps - (it + 1);     // sweeps still to run after this one
         if (same(nv, v)) {                         // fixed point
