@@ -48,7 +48,9 @@ __global__ void __launch_bounds__(256) apply_kernel(const float2* __restrict__ p
 // From one sweep to the next p moves by a fraction of a cell, so the eight corners it interpolates between are almost always the eight of the
 // sweep before: they stay in registers (as displacements, psi - id of the corner cell: what interpolate_field_inv reads) and are re-loaded only
 // when p enters another cell -- a sweep then costs arithmetic instead of eight dependent gathers.  Same values, same lerp chain, same bits.
-SOBFU_DEV float4 inverse_fixed_point(const float4* __restrict__ psi, const Dims& pd, float4 v, const float4& id, int n_sweeps) {
+// disp(x, y, z): the displacement psi - id of a cell (whole volume: disp_at; a tile's window: disp_at_win)
+template <class Disp>
+SOBFU_DEV float4 inverse_fixed_point(Disp disp, const Dims& pd, float4 v, const float4& id, int n_sweeps) {
     float4 w = v;  // p_it = v, p_(it-1) = w
     auto same = [](const float4& a, const float4& b) {
         return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
@@ -60,8 +62,8 @@ SOBFU_DEV float4 inverse_fixed_point(const float4* __restrict__ psi, const Dims&
         const Tri a = tri_setup(v.x, pd.x), b = tri_setup(v.y, pd.y), c = tri_setup(v.z, pd.z);
         if (a.g != cx || b.g != cy || c.g != cz || a.h != hx || b.h != hy || c.h != hz) {
             cx = a.g, cy = b.g, cz = c.g, hx = a.h, hy = b.h, hz = c.h;
-            hhh = disp_at(psi, pd, a.h, b.h, c.h), hhg = disp_at(psi, pd, a.h, b.h, c.g), hgh = disp_at(psi, pd, a.h, b.g, c.h), hgg = disp_at(psi, pd, a.h, b.g, c.g);
-            ghh = disp_at(psi, pd, a.g, b.h, c.h), ghg = disp_at(psi, pd, a.g, b.h, c.g), ggh = disp_at(psi, pd, a.g, b.g, c.h), ggg = disp_at(psi, pd, a.g, b.g, c.g);
+            hhh = disp(a.h, b.h, c.h), hhg = disp(a.h, b.h, c.g), hgh = disp(a.h, b.g, c.h), hgg = disp(a.h, b.g, c.g);
+            ghh = disp(a.g, b.h, c.h), ghg = disp(a.g, b.h, c.g), ggh = disp(a.g, b.g, c.h), ggg = disp(a.g, b.g, c.g);
         }
         const float4 u = lerp4(lerp4(lerp4(hhh, hhg, c.t), lerp4(hgh, hgg, c.t), b.t), lerp4(lerp4(ghh, ghg, c.t), lerp4(ggh, ggg, c.t), b.t), a.t);  // interp_disp
         const float4 nv = sub4(id, mul4(u, 1.f));  // p_(it+1)
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(256) inverse_fixed_point_kernel(const float4* 
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
     const float4 id = f4((float) (x + base.x), (float) (y + base.y), (float) (z + base.z));
-    st4<NT>(&psi_inv[i], inverse_fixed_point(psi, pd, ld4<NT>(&psi_inv[i]), id, n_sweeps));
+    st4<NT>(&psi_inv[i], inverse_fixed_point([&](int a, int b, int c) { return disp_at(psi, pd, a, b, c); }, pd, ld4<NT>(&psi_inv[i]), id, n_sweeps));
 }
 
 // The tail of Solver::estimate_psi in one pass (solver.cu:196-199): psi^-1 <- identity, 48 sweeps, phi_global o psi^-1.
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256) inverse_from_identity_and_warp_kernel(con
     VOXEL_XYZ(d);
     size_t i = vidx(d, x, y, z);
     const float4 id = f4((float) x, (float) y, (float) z);
-    const float4 v  = inverse_fixed_point(psi, d, id, id, n_sweeps);
+    const float4 v  = inverse_fixed_point([&](int a, int b, int c) { return disp_at(psi, d, a, b, c); }, d, id, id, n_sweeps);
     st4<NT>(&psi_inv[i], v);
     st2<NT>(&phi_warped[i], interp_tsdf(phi, d, v.x, v.y, v.z));
 }
@@ -127,15 +129,6 @@ SOBFU_DEV size_t win_idx(const Window& w, int x, int y, int z) {
 SOBFU_DEV float4 disp_at_win(const float4* __restrict__ psi, const Window& w, int x, int y, int z) {
     return sub4(psi[win_idx(w, x, y, z)], f4((float) x, (float) y, (float) z));
 }
-// interpolate_field_inv (utils.hpp:124-164) on a window
-SOBFU_DEV float4 interp_disp_win(const float4* __restrict__ psi, const Window& w, float px, float py, float pz) {
-    const Tri a = tri_setup(px, w.pd.x), b = tri_setup(py, w.pd.y), c = tri_setup(pz, w.pd.z);
-    return lerp4(lerp4(lerp4(disp_at_win(psi, w, a.h, b.h, c.h), disp_at_win(psi, w, a.h, b.h, c.g), c.t),
-                       lerp4(disp_at_win(psi, w, a.h, b.g, c.h), disp_at_win(psi, w, a.h, b.g, c.g), c.t), b.t),
-                 lerp4(lerp4(disp_at_win(psi, w, a.g, b.h, c.h), disp_at_win(psi, w, a.g, b.h, c.g), c.t),
-                       lerp4(disp_at_win(psi, w, a.g, b.g, c.h), disp_at_win(psi, w, a.g, b.g, c.g), c.t), b.t),
-                 a.t);
-}
 // interpolate_tsdf (utils.hpp:50-86) on a window
 SOBFU_DEV float2 interp_tsdf_win(const float2* __restrict__ v, const Window& w, float px, float py, float pz) {
     const Tri a = tri_setup(px, w.pd.x), b = tri_setup(py, w.pd.y), c = tri_setup(pz, w.pd.z);
@@ -153,19 +146,8 @@ __global__ void __launch_bounds__(256) tile_inverse_window_kernel(const float4* 
     const int x = x0 + blockIdx.x * kBX + threadIdx.x, y = y0 + blockIdx.y * kBY + threadIdx.y, z = z0 + blockIdx.z;
     if (x >= x1 || y >= y1 || z >= z1) return;
     const float4 id = f4((float) (x + base.x), (float) (y + base.y), (float) (z + base.z));
-    float4 v = id, w = id;
-    auto same = [](const float4& a, const float4& b) {
-        return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) && __float_as_uint(a.z) == __float_as_uint(b.z);
-    };
-    for (int it = 0; it < n_sweeps; ++it) {  // inverse_fixed_point() with the windowed sampler: the same early exits, the same bits
-        const float4 u  = interp_disp_win(psi_win, wpsi, v.x, v.y, v.z);
-        const float4 nv = sub4(id, mul4(u, 1.f));
-        const int left  = n_sweeps - (it + 1);
-        if (same(nv, v)) { v = nv; break; }
-        if (it > 0 && same(nv, w)) { v = (left & 1) ? v : nv; break; }
-        w = v;
-        v = nv;
-    }
+    // inverse_fixed_point() with the windowed sampler (interpolate_field_inv, utils.hpp:124-164, on a window): the same early exits, the same bits
+    const float4 v = inverse_fixed_point([&](int a, int b, int c) { return disp_at_win(psi_win, wpsi, a, b, c); }, wpsi.pd, id, id, n_sweeps);
     psi_inv[vidx(d, x, y, z)] = v;
 }
 __global__ void __launch_bounds__(256) tile_apply_window_kernel(const float2* __restrict__ phi_win, Window wphi, float2* __restrict__ out,
