@@ -31,6 +31,19 @@ def word_digest(a, chunk=1 << 26):
     return int(total)
 
 
+def word_digest_device(t, chunk=1 << 27):
+    """word_digest of a CUDA tensor, computed on the device (int64 arithmetic wraps like uint64: the low 64 bits are the same)"""
+    import torch
+
+    w = t.contiguous().view(-1).view(torch.int32)
+    total = 0
+    for i in range(0, w.numel(), chunk):
+        part = w[i:i + chunk].to(torch.int64) & 0xFFFFFFFF
+        idx = torch.arange(i, i + part.numel(), dtype=torch.int64, device=w.device) * 2 + 1
+        total = (total + int((part * idx).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    return total
+
+
 def run(flavour, scenario, inputs, outputs, **kw):
     """inputs: name -> array; outputs: name -> (dtype, shape or None).  -> dict of arrays + 'log' (the reference's stdout) [+ 'time': seconds].
     With digest=1 every output is the 64-bit word_digest of the array instead (an int)."""

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import fixture_inputs as FI  # noqa: E402
 import ref_hip_runner as R  # noqa: E402
-from test_reference_fixtures import KERNEL_DIMS, SOLVER_NAMES, _sphere_pair, _tsdf_params, check, hip_launchers_against, kernel_fixture, load, same  # noqa: E402
+from test_reference_fixtures import KERNEL_DIMS, SOLVER_NAMES, HipFusion, _frame_inputs, _sphere_pair, _tsdf_params, check, hip_launchers_against, kernel_fixture, load, same  # noqa: E402
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref/reference_hip_* were not built (needs /root/reference: build container)")]
 F32 = np.float32
@@ -150,7 +150,7 @@ def _ellipsoid_solve_digests(dim, iters, P5):
     torch.cuda.synchronize()
     out = {}
     for k, t in (("phi_global", pg), ("phi_n", pn), ("psi", psi), ("phi_n_psi", pnp), ("psi_inv", psi_inv), ("phi_global_psi_inv", pgi)):
-        out[k] = R.word_digest(t.cpu().numpy())
+        out[k] = R.word_digest_device(t)
     moved = float((psi.cpu().numpy()[..., 0] - np.arange(dim, dtype=F32)[None, None, :]).__abs__().max())
     return out, moved
 
@@ -172,6 +172,79 @@ def test_reference_on_gpu_equals_this_repo_at_config5_size(dim, iters):
     assert moved > 1e-4  # the solve did something
     for k in names:
         assert r[k] == ours[k], (dim, k, hex(r[k]), hex(ours[k]))
+
+
+@pytest.mark.parametrize("dim,frames,iters", [(64, 3, 8), (512, 3, 6)])
+def test_reference_frame_pipeline_on_gpu_equals_this_repo_at_config5_size(dim, frames, iters):
+    """SobFusion::operator() of the reference (depth pre-steps, integrate(depth), Solver::estimate_psi warm-started from frame to frame, fusion) frame by frame on
+    the MI355X at BASELINE config 5's grid (512^3, params_umbrella.ini values, bench.py's depth sequence), against this repo's frame driver: every volume and field
+    of every frame by 64-bit word digests.  The bilateral filter's exp is the one device-libm call on the path (HIP's __expf in the reference's build, a correctly
+    rounded expf in this repo's): on this depth sequence both give the same filtered image -- phi_global of frame 0 being equal says so."""
+    vx = float(F32(1.0) / F32(dim))
+    P = dict(rows=480, cols=640, fx=570.342, fy=570.342, cx=320.0, cy=240.0, trunc_depth=1.5, bilateral_ksz=7, bilateral_ss=4.5, bilateral_sd=0.04, X=dim, Y=dim, Z=dim,
+             size_x=1.0, size_y=1.0, size_z=1.0, trunc_vox=8.0, eta_vox=3.0, t_z=0.3, max_weight=128.0, start_frame=1, s=7, alpha=0.001, w_reg=0.2, max_iter=iters,
+             max_update_norm=1e-10, verbosity=0, frames=frames)
+    P["lambda"] = 0.1
+    intr = (P["fx"], P["fy"], P["cx"], P["cy"])
+    depths = [FI.bench_sequence_frame(intr, 1.0, P["t_z"], vx, n) for n in range(frames)]
+    names = ["phi_global_f0"]
+    for i in range(1, frames):
+        names += ["%s_f%d" % (k, i) for k in ("phi_global", "phi_n", "psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv")]
+    r = R.run("ieee", "frames", {"depth_%d" % i: d for i, d in enumerate(depths)}, {k: (np.uint64, None) for k in names}, digest=1, **P)
+    fu = HipFusion(P)
+    seen = 0
+    for i, depth in enumerate(depths):
+        fu(depth)
+        for k in ("phi_global", "phi_n", "psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv"):
+            key = "%s_f%d" % (k, i)
+            if key in r:
+                assert R.word_digest_device(getattr(fu, k)) == r[key], (dim, key)
+                if dim <= 64:
+                    assert R.word_digest(getattr(fu, k).cpu().numpy()) == r[key]  # (the host and the device form of the digest agree)
+                seen += 1
+    assert seen == len(names)
+    observed = int((fu.phi_global.cpu().numpy()[..., 1] > 0).sum())
+    fu.close()
+    assert observed > dim ** 3 // 100  # the camera saw the sphere: the volumes are not empty
+
+
+def _frames(flavour, f, frames_out):
+    P = dict(f["P"])
+    n = int(P["frames"])
+    dims = (int(P["X"]), int(P["Y"]), int(P["Z"]))
+    outs = {"phi_global_f0": vol(dims)}
+    for i in range(1, n):
+        outs["phi_global_f%d" % i] = vol(dims)
+        outs["phi_n_f%d" % i] = vol(dims)
+        if i >= max(1, int(P["start_frame"])):
+            outs.update({"%s_f%d" % (k, i): (fld(dims) if k in ("psi", "psi_inv") else vol(dims)) for k in ("psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv")})
+    return R.run(flavour, "frames", {"depth_%d" % i: d for i, d in enumerate(_frame_inputs(f, n))}, outs, **P)
+
+
+@pytest.mark.parametrize("name", ["ref_config1_64", "ref_config2_128"])
+def test_baseline_depth_configs_through_the_reference_on_gpu(name):
+    """BASELINE configs 1 (64^3, two frames, 10 iterations) and 2 (128^3, seven frames at the ini's own length: 612 / 143 / 53 iterations) through
+    SobFusion::operator() of the reference's GPU build.  IEEE flavour: every array of every frame and every printed line equal the host emulation's
+    (tests/golden) -- when the one device-libm call on the path, __expf in the bilateral filter, rounds the filtered image as the emulation's did
+    (phi_global of frame 0 says so; otherwise the comparison is skipped with the count of differing voxels).  Fast flavour against IEEE: what a real GPU
+    compiler's fast-math does to a depth-driven configuration (DESIGN section 2's table: discrete pixel / millimetre flips in the TSDF builders)."""
+    f = load(name)
+    n = int(f["P"]["frames"])
+    a = _frames("ieee", f, n)
+    first = FI.digest(a["phi_global_f0"])
+    if not np.array_equal(first, f["sha256_phi_global_f0"]):
+        pytest.skip("the device's __expf rounds the filtered depth image differently from the emulation's on this GPU: phi_global of frame 0 differs")
+    for k, v in a.items():
+        if k not in ("log", "time"):
+            check(f, k, v)
+    assert a["log"] == f["log"]
+    b = _frames("fast", f, n)
+    last = max(int(k.split("_f")[1]) for k in a if k.startswith("psi_f"))
+    d = a["psi_f%d" % last][..., :3].astype(np.float64) - b["psi_f%d" % last][..., :3].astype(np.float64)
+    dv = np.abs(a["phi_global_f0"][..., 0].astype(np.float64) - b["phi_global_f0"][..., 0])
+    print("%s, fast-math reference vs IEEE reference: psi of the last frame L2 %.3g max %.3g rms %.3g; phi_global of frame 0: %d voxels differ, max %.3g; logs %s"
+          % (name, np.sqrt((d ** 2).sum()), np.abs(d).max(), np.sqrt((d ** 2).mean()), int((dv != 0).sum()), dv.max(), "equal" if a["log"] == b["log"] else "differ"))
+    assert np.abs(d).max() < 5e-2 and np.sqrt((d ** 2).mean()) < 1e-4  # the stated tolerance of DESIGN section 2 for depth-driven inputs
 
 
 def test_fast_math_build_of_the_reference_distance():

@@ -29,12 +29,10 @@
 #include <chrono>
 
 #include <cuda_runtime.h>
-#ifndef REF_HIP_BUILD  // (tools/ref_hipbuild compiles this driver too, without SobFusion / marching cubes: their kernels use 32-wide warp intrinsics and PTX)
 #define private public  // SobFusion keeps phi_global & co. private; the dumps need to read them
 #include <sobfu/sob_fusion.hpp>
 #undef private
-#include <kfusion/cuda/marching_cubes.hpp>
-#endif
+#include <kfusion/cuda/marching_cubes.hpp>  // (tools/ref_hipbuild compiles this driver too, without the marching cubes KERNELS -- 32-wide warp code -- and so without the mc scenario)
 #include <kfusion/precomp.hpp>
 #include <sobfu/solver.hpp>
 
@@ -306,7 +304,6 @@ static void scenario_time() {
     }
 }
 
-#ifndef REF_HIP_BUILD
 static void scenario_frames() {
     Params p = make_params();
     const int n = (int) arg("frames");
@@ -326,6 +323,7 @@ static void scenario_frames() {
     }
 }
 
+#ifndef REF_HIP_BUILD
 static void scenario_mc() {
     Params p = make_params();
     const size_t N = (size_t) p.volume_dims[0] * p.volume_dims[1] * p.volume_dims[2];
@@ -370,8 +368,8 @@ int main(int argc, char** argv) {
     else if (scenario == "depth") scenario_depth();
     else if (scenario == "launchers") scenario_launchers();
     else if (scenario == "time") scenario_time();
-#ifndef REF_HIP_BUILD
     else if (scenario == "frames") scenario_frames();
+#ifndef REF_HIP_BUILD
     else if (scenario == "mc") scenario_mc();
 #endif
     else return fprintf(stderr, "ref_emu: unknown scenario %s\n", scenario.c_str()), 2;

@@ -1,7 +1,7 @@
 """Builds the reference's hot-path sources for gfx950 with hipcc -- the .cu and .cpp files compiled WHERE THEY LIE under
 /root/reference (no copies, no rewriting: hipcc understands `kernel<<<...>>>(...)` and `extern __shared__`), through the CUDA -> HIP
 name map of shim/cuda_runtime.h and the OpenCV / PCL / Boost stand-ins of tools/ref_emulation/shim, with the driver of
-tools/ref_emulation/driver.cpp (scenarios kernels / solver / tsdf / depth / time) -> oracle/_ref/reference_hip_ieee and
+tools/ref_emulation/driver.cpp (scenarios kernels / solver / tsdf / depth / frames / launchers / time) -> oracle/_ref/reference_hip_ieee and
 oracle/_ref/reference_hip_fast (git-ignored; they travel to the GPU box, the reference does not).
 
   ieee   -ffp-contract=off, correctly rounded divide / sqrt, denormals kept: the arithmetic of the host emulation, the oracle and this
@@ -10,8 +10,8 @@ oracle/_ref/reference_hip_fast (git-ignored; they travel to the GPU box, the ref
          reference's nvcc flags (CMakeLists.txt:40-46: --fmad=true by default, --prec-div=false --prec-sqrt=false --ftz=true)
 
 `fast` with -DOCML_BASIC_ROUNDED_OPERATIONS (the *_rn intrinsics become correctly rounded library calls, never contracted -- nvcc's
-guarantee); both with -fgpu-rdc (the reference launches kernels of one .cu file from another).  Not compiled: marching_cubes.{cu,cpp} and sob_fusion.cpp (32-wide
-warp intrinsics, PTX).  SHIM EVIDENCE -- see shim/cuda_runtime.h.  Test / measurement infrastructure; nothing under sobfu_amd/ uses it.
+guarantee); both with -fgpu-rdc (the reference launches kernels of one .cu file from another).  Not compiled: marching_cubes.cu (32-wide warp
+intrinsics, PTX, texture fetches) -- mc_unavailable.cpp holds its five launchers as refusing stubs so that SobFusion links.  SHIM EVIDENCE -- see shim/cuda_runtime.h.  Test / measurement infrastructure; nothing under sobfu_amd/ uses it.
 """
 import os
 import subprocess
@@ -23,7 +23,7 @@ REF = os.environ.get("SOBFU_REFERENCE", "/root/reference")
 OUT_DIR = os.path.join(ROOT, "oracle", "_ref")
 CU = ["src/sobfu/cuda/solver.cu", "src/sobfu/cuda/vector_fields.cu", "src/sobfu/cuda/reductor.cu", "src/kfusion/cuda/tsdf_volume.cu", "src/kfusion/cuda/imgproc.cu"]
 CPP = ["src/sobfu/solver.cpp", "src/sobfu/vector_fields.cpp", "src/sobfu/reductor.cpp", "src/sobfu/precomp.cpp", "src/kfusion/device_memory.cpp",
-       "src/kfusion/precomp.cpp", "src/kfusion/tsdf_volume.cpp", "src/kfusion/imgproc.cpp"]
+       "src/kfusion/precomp.cpp", "src/kfusion/tsdf_volume.cpp", "src/kfusion/imgproc.cpp", "src/sobfu/sob_fusion.cpp", "src/kfusion/marching_cubes.cpp"]
 # ieee: the *_rn intrinsics are HIP's plain operators, which -ffp-contract=off keeps un-contracted and IEEE-rounded (the same values as
 #       rounded library calls, at full speed: this is also the build whose SPEED is quoted).
 # fast: contraction is on, so the intrinsics must be opaque: -DOCML_BASIC_ROUNDED_OPERATIONS turns them into correctly rounded OCML calls
@@ -45,7 +45,8 @@ def build(force=False, verbose=False):
         raise FileNotFoundError("%s is not mounted: the reference is only present in the build container" % REF)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
-    srcs = [os.path.join(REF, r) for r in CU + CPP] + [os.path.join(HERE, "texture_state.cpp"), os.path.join(ROOT, "tools", "ref_emulation", "driver.cpp")]
+    srcs = [os.path.join(REF, r) for r in CU + CPP] + [os.path.join(HERE, "texture_state.cpp"), os.path.join(HERE, "mc_unavailable.cpp"),
+            os.path.join(ROOT, "tools", "ref_emulation", "driver.cpp")]
     deps = srcs + [os.path.join(HERE, "shim", "cuda_runtime.h"), __file__]
     for flavour, fl in FLAVOURS.items():
         exe = binary(flavour)
