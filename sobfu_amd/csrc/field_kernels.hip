@@ -73,7 +73,10 @@ SOBFU_DEV float4 inverse_fixed_point(Disp disp, const Dims& pd, float4 v, const 
             break;
         }
         if (it > 0 && same(nv, w)) {               // period 2: ..., w, v, w (= nv), v, w, ...
-            v = (left & 1) ? v : nv;
+            // (component by component: a select between two float4 OBJECTS is compiled to a load through a selected stack address -- 48 B of scratch
+            //  per lane and a scratch store per sweep, found in the ISA in round 6)
+            const bool keep = (left & 1) != 0;
+            v = f4(keep ? v.x : nv.x, keep ? v.y : nv.y, keep ? v.z : nv.z);
             break;
         }
         w = v;
