@@ -354,6 +354,15 @@ def test_hip_launchers(dims):
     hip_launchers_against(f, ins, dims, w_reg, alpha, max_weight)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", KERNEL_DIMS)
+def test_hip_launchers_streaming_instantiations(dims, monkeypatch):
+    """the same with SOBFU_LAUNCHER_NT=1: the instantiations grids beyond 3.3 M cells get (nontemporal loads / stores), forced onto the fixtures' small ragged grids"""
+    monkeypatch.setenv("SOBFU_LAUNCHER_NT", "1")
+    f, ins, w_reg, alpha, max_weight = kernel_fixture(dims)
+    hip_launchers_against(f, ins, dims, w_reg, alpha, max_weight)
+
+
 def hip_launchers_against(f, ins, dims, w_reg, alpha, max_weight):
     """every launcher of the C ABI (and the two fused passes) on `ins` against the reference's arrays in `f` (a fixture, or the outputs of the
     reference's GPU build: tests/test_gpu_reference_hipbuild.py)"""
