@@ -63,6 +63,61 @@ def test_this_repo_launchers_against_the_reference_on_gpu_at_sizes_without_fixtu
     hip_launchers_against(r, ins, dims, w_reg, alpha, max_weight)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SOBFU_FUZZ_LAUNCHER_SEEDS", "8"))))
+def test_random_launcher_cases_against_the_reference_on_gpu(seed, monkeypatch):
+    """seeded random grids (5 - 140 cells per axis, ragged), warp amplitudes and scalars; every launcher and the two fused passes against the reference's own kernels;
+    the launchers' streaming instantiations forced on for every other seed"""
+    rng = np.random.default_rng(9000 + seed)
+    dims = tuple(int(v) for v in rng.integers(5, [140, 90, 60][seed % 3] + 1, size=3))
+    X, Y, Z = dims
+    if seed % 2:
+        monkeypatch.setenv("SOBFU_LAUNCHER_NT", "1")
+    ins = FI.kernel_inputs(dims, 300 + seed, float(rng.choice([0.05, 0.45, 1.7])))
+    w_reg, alpha, max_weight = float(rng.choice([0.2, 0.6])), float(rng.choice([0.1, 0.01])), float(rng.choice([3.0, 64.0]))
+    J = (F32, (Z, Y, X, 4, 4))
+    outs = dict(grad=fld(dims), laplacian=fld(dims), jacobian0=J, jacobian1=J, nabla_U=fld(dims), conv_rows=fld(dims), conv_cols=fld(dims), conv_depth=fld(dims),
+                psi_new=fld(dims), updates=fld(dims), warped=vol(dims), psi_inv=fld(dims), fused=vol(dims), scalars=(F32, (6,)))
+    r = R.run("ieee", "kernels", ins, outs, X=X, Y=Y, Z=Z, w_reg=w_reg, alpha=alpha, max_weight=max_weight)
+    hip_launchers_against(r, ins, dims, w_reg, alpha, max_weight)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SOBFU_FUZZ_SEEDS", "10"))))  # (SOBFU_FUZZ_SEEDS=300: the stress run of profiles/r06/fuzz_solver_300.log)
+def test_random_solves_against_the_reference_on_gpu(seed):
+    """seeded random cases of the whole Solver::estimate_psi -- ragged extents from 9 to 150 cells, every verbosity, 1 - 130 iterations, thresholds that fire early,
+    late or never, both storage formats of this repo's loop -- the reference's own kernels on the GPU against this repo: every array bit for bit and every line it printed"""
+    import torch
+
+    from sobfu_amd import ops
+
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(9, [150, 100, 70][seed % 3] + 1, size=3))
+    X, Y, Z = dims
+    verbosity = int(rng.integers(0, 3))
+    iters = int(rng.integers(1, 131 if verbosity != 2 else 40))
+    alpha, w_reg = float(rng.choice([0.1, 0.05, 0.01, 0.001])), float(rng.choice([0.2, 0.4, 0.6]))
+    mun = float(rng.choice([-1.0, 1e-10, 1e-4, 2e-3]))
+    c = 0.45 + 0.1 * rng.random(3)
+    r = 0.22 + 0.1 * rng.random()
+    pg = FI.sphere_volume(dims, tuple(c * np.array(dims)), r * min(dims), 5.0)
+    pn = FI.sphere_volume(dims, tuple((c + rng.normal(0, 0.02, 3)) * np.array(dims)), (r + rng.normal(0, 0.01)) * min(dims), 5.0)
+    psi0 = FI.warped_identity(dims, 77 + seed, float(rng.choice([0.0, 0.2, 0.6])))
+    P = dict(X=X, Y=Y, Z=Z, size_x=X * 0.004, size_y=Y * 0.004, size_z=Z * 0.004, trunc_vox=5.0, eta_vox=2.0, max_weight=64.0, s=7, max_update_norm=mun, verbosity=verbosity,
+             max_iter=iters, alpha=alpha, w_reg=w_reg)
+    P["lambda"] = 0.1
+    ref = R.run("ieee", "solver", dict(phi_global=pg, phi_n=pn, psi0=psi0), dict(psi=fld(dims), phi_n_psi=vol(dims), psi_inv=fld(dims), phi_global_psi_inv=vol(dims)), **P)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for compact in (True, False):
+        sv = ops.Solver(dims, max_iter=iters, alpha=alpha, w_reg=w_reg, s=7, lam=0.1, max_update_norm=mun, verbosity=verbosity)
+        sv.set_compact(compact)
+        psi, psi_inv, pnp, pgi = dev(psi0), ops.new_field(dims), ops.new_volume(dims), ops.new_volume(dims)
+        sv.estimate_psi(dev(pg), pgi, dev(pn), pnp, psi, psi_inv)
+        what = (seed, dims, verbosity, iters, alpha, w_reg, mun, compact)
+        for k, t in (("psi", psi), ("phi_n_psi", pnp), ("psi_inv", psi_inv), ("phi_global_psi_inv", pgi)):
+            assert same(t.cpu().numpy(), ref[k]), (k,) + what
+        assert "\n".join(sv.log_lines) + "\n" == ref["log"], what
+        sv.close()
+
+
 @pytest.mark.parametrize("name", SOLVER_NAMES)
 def test_reference_solver_on_gpu_equals_the_emulation(name):
     f = load(name)
@@ -219,6 +274,55 @@ def _frames(flavour, f, frames_out):
         if i >= max(1, int(P["start_frame"])):
             outs.update({"%s_f%d" % (k, i): (fld(dims) if k in ("psi", "psi_inv") else vol(dims)) for k in ("psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv")})
     return R.run(flavour, "frames", {"depth_%d" % i: d for i, d in enumerate(_frame_inputs(f, n))}, outs, **P)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SOBFU_FUZZ_FRAME_SEEDS", "6"))))
+def test_random_frame_sequences_against_the_reference_on_gpu(seed):
+    """seeded random SobFusion::operator() sequences -- image size, intrinsics, volume extents / pose, truncation, START_FRAME gating, 2 - 4 frames of a sphere moving in
+    front of the camera, solver values -- the reference's own kernels on the GPU against this repo's frame driver, every volume and field of every frame bit for bit.
+    (When the device's __expf rounds a filtered depth pixel differently from this repo's correctly rounded expf the sequences part at frame 0: skipped, counted in the message.)"""
+    from sobfu_amd.synthetic import render_sphere_depth
+
+    rng = np.random.default_rng(5000 + seed)
+    dims = tuple(int(v) for v in rng.integers(24, 81, size=3))
+    rows, cols = [(480, 640), (240, 320), (200, 264)][seed % 3]
+    fx = float(rng.uniform(0.7, 1.0) * cols)
+    intr = (fx, fx * float(rng.uniform(0.97, 1.03)), cols / 2.0 + float(rng.uniform(-8, 8)), rows / 2.0 + float(rng.uniform(-8, 8)))
+    size = float(rng.uniform(0.4, 0.9))
+    t_z = float(rng.uniform(0.25, 0.6))
+    frames, start = int(rng.integers(2, 5)), int(rng.integers(1, 3))
+    P = dict(rows=rows, cols=cols, fx=intr[0], fy=intr[1], cx=intr[2], cy=intr[3], trunc_depth=float(rng.choice([1.2, 2.5])), bilateral_ksz=int(rng.choice([5, 7])),
+             bilateral_ss=4.5, bilateral_sd=float(rng.choice([0.005, 0.04])), X=dims[0], Y=dims[1], Z=dims[2], size_x=size, size_y=size * dims[1] / dims[0], size_z=size * dims[2] / dims[0],
+             trunc_vox=float(rng.choice([4.0, 6.0, 8.0])), eta_vox=float(rng.choice([2.0, 3.0])), t_z=t_z, max_weight=float(rng.choice([2.0, 64.0])), start_frame=start, s=7,
+             alpha=float(rng.choice([0.1, 0.01])), w_reg=float(rng.choice([0.2, 0.6])), max_iter=int(rng.integers(3, 21)), max_update_norm=float(rng.choice([-1.0, 1e-10, 1e-3])),
+             verbosity=0, frames=frames)
+    P["lambda"] = 0.1
+    depth_z = t_z + 0.5 * P["size_z"]
+    v = rng.normal(0, 0.004, 3)
+    depths = [render_sphere_depth(tuple(n * v + np.array([0.0, 0.0, depth_z])), 0.2 * size, intr, rows=rows, cols=cols) for n in range(frames)]
+    dims3 = dims
+    outs = {"phi_global_f0": vol(dims3)}
+    for i in range(1, frames):
+        outs["phi_global_f%d" % i] = vol(dims3)
+        outs["phi_n_f%d" % i] = vol(dims3)
+        if i >= max(1, start):
+            outs.update({"%s_f%d" % (k, i): (fld(dims3) if k in ("psi", "psi_inv") else vol(dims3)) for k in ("psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv")})
+    r = R.run("ieee", "frames", {"depth_%d" % i: d for i, d in enumerate(depths)}, outs, **P)
+    fu = HipFusion(P)
+    checked = 0
+    for i, depth in enumerate(depths):
+        fu(depth)
+        for k in ("phi_global", "phi_n", "psi", "psi_inv", "phi_n_psi", "phi_global_psi_inv"):
+            key = "%s_f%d" % (k, i)
+            if key in r:
+                mine = getattr(fu, k).cpu().numpy()
+                if i == 0 and not same(mine, r[key]):
+                    fu.close()
+                    pytest.skip("the filtered depth images differ (__expf): %d voxels of phi_global of frame 0" % int((mine.view(np.uint32) != r[key].view(np.uint32)).sum()))
+                assert same(mine, r[key]), (seed, key, dims, P)
+                checked += 1
+    fu.close()
+    assert checked == len(outs) and (r["phi_global_f0"][..., 1] > 0).sum() > 100, (seed, checked)
 
 
 @pytest.mark.parametrize("name", ["ref_config1_64", "ref_config2_128"])
