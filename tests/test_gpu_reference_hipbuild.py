@@ -154,6 +154,33 @@ def test_reference_builders_on_gpu():
         assert np.array_equal(r["truncated"], f["truncated"]) and same(r["dists"], f["dists"]) and same(r["volume"], f["volume"])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SOBFU_FUZZ_BUILDER_SEEDS", "6"))))
+def test_random_sdf_primitives_against_the_reference_on_gpu(seed):
+    """seeded random grids, voxel sizes, truncations and shape parameters: the five analytic initialisers of this repo against the reference's own kernels on the GPU --
+    box, ellipsoid, plane and torus bit for bit; the sphere (powf(d, 2) there, d * d here) to 4e-6 with equal weights outside a few voxels on the eta shell"""
+    from sobfu_amd import ops
+
+    rng = np.random.default_rng(7000 + seed)
+    dims = tuple(int(v) for v in rng.integers(7, 97, size=3))
+    size = rng.uniform(0.2, 1.5, 3)
+    P = dict(X=dims[0], Y=dims[1], Z=dims[2], size_x=float(size[0]), size_y=float(size[1]), size_z=float(size[2]), trunc_vox=float(rng.choice([3.0, 5.0, 12.0])), eta_vox=float(rng.choice([1.0, 2.0, 4.0])),
+             max_weight=64.0, sphere_cx=float(size[0] * rng.uniform(0.3, 0.7)), sphere_cy=float(size[1] * rng.uniform(0.3, 0.7)), sphere_cz=float(size[2] * rng.uniform(0.3, 0.7)),
+             sphere_r=float(size.min() * rng.uniform(0.1, 0.4)), box_x=float(size[0] * rng.uniform(0.1, 0.4)), box_y=float(size[1] * rng.uniform(0.1, 0.4)), box_z=float(size[2] * rng.uniform(0.1, 0.4)),
+             ell_x=float(size[0] * rng.uniform(0.1, 0.4)), ell_y=float(size[1] * rng.uniform(0.1, 0.4)), ell_z=float(size[2] * rng.uniform(0.1, 0.4)), plane_z=float(size[2] * rng.uniform(0.2, 0.8)),
+             torus_R=float(size.min() * rng.uniform(0.2, 0.35)), torus_r=float(size.min() * rng.uniform(0.03, 0.1)))
+    r = R.run("ieee", "tsdf", {}, {k: vol(dims) for k in ("sphere", "box", "ellipsoid", "plane", "torus")}, **P)
+    _, vs, trunc, eta = _tsdf_params(P, dims)
+    v = ops.new_volume(dims)
+    ops.init_sphere(v, vs, trunc, eta, (P["sphere_cx"], P["sphere_cy"], P["sphere_cz"]), P["sphere_r"])
+    h = v.cpu().numpy()
+    assert np.abs(h[..., 0] - r["sphere"][..., 0]).max() <= 4e-6 and (h[..., 1] != r["sphere"][..., 1]).sum() <= 4, (seed, dims)
+    for fn, key, arg in ((ops.init_box, "box", (P["box_x"], P["box_y"], P["box_z"])), (ops.init_ellipsoid, "ellipsoid", (P["ell_x"], P["ell_y"], P["ell_z"])),
+                         (ops.init_plane, "plane", P["plane_z"]), (ops.init_torus, "torus", (P["torus_R"], P["torus_r"]))):
+        v = ops.new_volume(dims)
+        fn(v, vs, trunc, arg)
+        assert same(v.cpu().numpy(), r[key]), (seed, key, dims, P)
+
+
 def _config3(flavour, pg=None, pn=None, iters=50, scenario="solver", **extra):
     f = load("ref_config3_256")
     P = {k: v for k, v in f["P"].items()}
