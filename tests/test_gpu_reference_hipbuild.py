@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import fixture_inputs as FI  # noqa: E402
 import ref_hip_runner as R  # noqa: E402
-from test_reference_fixtures import KERNEL_DIMS, SOLVER_NAMES, HipFusion, _frame_inputs, _sphere_pair, _tsdf_params, check, hip_launchers_against, kernel_fixture, load, same  # noqa: E402
+from test_reference_fixtures import KERNEL_DIMS, SOLVER_NAMES, HipFusion, _frame_inputs, expected_log, _sphere_pair, _tsdf_params, check, hip_launchers_against, kernel_fixture, load, same  # noqa: E402
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref/reference_hip_* were not built (needs /root/reference: build container)")]
 F32 = np.float32
@@ -116,6 +116,35 @@ def test_random_solves_against_the_reference_on_gpu(seed):
             assert same(t.cpu().numpy(), ref[k]), (k,) + what
         assert "\n".join(sv.log_lines) + "\n" == ref["log"], what
         sv.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SOBFU_FUZZ_ORACLE_SEEDS", "6"))))
+def test_random_solves_oracle_against_the_reference_on_gpu(seed):
+    """the CPU ORACLE (oracle/sobfu_oracle.c, the checker of the CPU suite) against the reference's own kernels on the GPU on seeded random cases: arrays bit for bit
+    and, from the oracle's per-iteration trace, every line the reference printed"""
+    import oracle as O
+
+    rng = np.random.default_rng(3000 + seed)
+    dims = tuple(int(v) for v in rng.integers(7, 49, size=3))
+    X, Y, Z = dims
+    verbosity = int(rng.integers(0, 3))
+    iters = int(rng.integers(1, 60))
+    alpha, w_reg, mun = float(rng.choice([0.1, 0.05, 0.01])), float(rng.choice([0.2, 0.4, 0.6])), float(rng.choice([-1.0, 1e-10, 1e-4, 2e-3]))
+    c = 0.45 + 0.1 * rng.random(3)
+    r0 = 0.22 + 0.1 * rng.random()
+    pg = FI.sphere_volume(dims, tuple(c * np.array(dims)), r0 * min(dims), 5.0)
+    pn = FI.sphere_volume(dims, tuple((c + rng.normal(0, 0.02, 3)) * np.array(dims)), (r0 + rng.normal(0, 0.01)) * min(dims), 5.0)
+    psi0 = FI.warped_identity(dims, 177 + seed, float(rng.choice([0.0, 0.2, 0.6])))
+    P = dict(X=X, Y=Y, Z=Z, size_x=X * 0.004, size_y=Y * 0.004, size_z=Z * 0.004, trunc_vox=5.0, eta_vox=2.0, max_weight=64.0, s=7, max_update_norm=mun, verbosity=verbosity,
+             max_iter=iters, alpha=alpha, w_reg=w_reg)
+    P["lambda"] = 0.1
+    ref = R.run("ieee", "solver", dict(phi_global=pg, phi_n=pn, psi0=psi0), dict(psi=fld(dims), phi_n_psi=vol(dims), psi_inv=fld(dims), phi_global_psi_inv=vol(dims)), **P)
+    psi = psi0.copy()
+    o = O.estimate_psi(pg, pn, psi, max_iter=iters, alpha=alpha, w_reg=w_reg, s=7, lam=0.1, max_update_norm=mun, verbosity=2)
+    what = (seed, dims, verbosity, iters, alpha, w_reg, mun)
+    for k, v in (("psi", psi), ("phi_n_psi", o["phi_n_psi"]), ("psi_inv", o["psi_inv"]), ("phi_global_psi_inv", o["phi_global_psi_inv"])):
+        assert same(v, ref[k]), (k,) + what
+    assert expected_log(o["trace"], dims, iters, w_reg, mun, verbosity) == ref["log"], what
 
 
 @pytest.mark.parametrize("name", SOLVER_NAMES)
