@@ -251,14 +251,21 @@ def frames_fixture(emu, P, depths, full_last=True):
     return c
 
 
-def mc_fixture(emu, dims):
+def mc_fixture(emu, dims, buffer=3 * 4096, as_digest=False):
     X, Y, Z = dims
     size = (0.28, 0.22, 0.18)
     vol = mc_volume(dims)
-    P = dict(X=X, Y=Y, Z=Z, size_x=size[0], size_y=size[1], size_z=size[2], trunc_vox=4.0, eta_vox=2.0, t_z=0.4, buffer=3 * 4096)
+    P = dict(X=X, Y=Y, Z=Z, size_x=size[0], size_y=size[1], size_z=size[2], trunc_vox=4.0, eta_vox=2.0, t_z=0.4, buffer=buffer)
     r = emu.run("mc", dict(volume=vol), dict(vertices=(np.float32, None), normals=(np.float32, None)), **P)
     r["vertices"], r["normals"] = r["vertices"].reshape(-1, 4), r["normals"].reshape(-1, 4)
-    r["in_volume"] = vol
+    if as_digest:  # the SET of triangles (the reference's order is run-dependent): rows of 3 x (vertex, normal), sorted by their bit patterns
+        a = np.concatenate([r.pop("vertices").reshape(-1, 3, 4), r.pop("normals").reshape(-1, 3, 4)], axis=2).reshape(-1, 24)
+        b = a.view(np.uint32)
+        r["n_triangles"] = np.array([len(a)], np.int64)
+        r["sha256_triangle_set"] = digest(b[np.lexsort(b.T[::-1])])
+        r["sha256_in_volume"] = digest(vol)
+    else:
+        r["in_volume"] = vol
     r["params"] = np.array([P[k] for k in sorted(P)], np.float64)
     r["param_names"] = ",".join(sorted(P))
     return r
@@ -310,6 +317,8 @@ def make_some(emu, emu_smem, names):
             fx[n] = solver_fixture(emu, d, rand_volume(d, 901), rand_volume(d, 902), warped_identity(d, 903, 0.7), 4, alpha=0.05, w_reg=0.4)
         elif n == "ref_mc_14x11x9":
             fx[n] = mc_fixture(emu, (14, 11, 9))
+        elif n == "ref_mc_40x33x29":
+            fx[n] = mc_fixture(emu, (40, 33, 29), buffer=3 * 16384, as_digest=True)
         elif n == "ref_depth_32x32x32":
             fx[n] = depth_fixture(emu, (32, 32, 32))
         elif n == "ref_config5_values_96":
@@ -403,6 +412,7 @@ def make_all(emu, emu_smem, only_config5=False):
                                                             sphere_cy=0.375, sphere_cz=0.375, sphere2_cx=0.375 + 1.3 * vs3, sphere2_cy=0.375, sphere2_cz=0.375,
                                                             sphere_r=0.2))
     fx["ref_mc_14x11x9"] = mc_fixture(emu, (14, 11, 9))
+    fx["ref_mc_40x33x29"] = mc_fixture(emu, (40, 33, 29), buffer=3 * 16384, as_digest=True)
     check_appendix_b(fx)
     return fx
 def main():

@@ -98,7 +98,7 @@ def test_fixture_inventory():
     names = sorted(n[:-4] for n in os.listdir(G) if n.startswith("ref_") and n.endswith(".npz"))
     assert names == sorted(["ref_kernels_%dx%dx%d" % d for d in KERNEL_DIMS] + SOLVER_NAMES +
                            ["ref_solver_test_64", "ref_tsdf_30x24x18", "ref_depth_32x32x32", "ref_frames_32x32x32", "ref_frames_gated_32x32x32",
-                            "ref_config1_64", "ref_config2_128", "ref_config3_256", "ref_config5_values_96", "ref_mc_14x11x9"])
+                            "ref_config1_64", "ref_config2_128", "ref_config3_256", "ref_config5_values_96", "ref_mc_14x11x9", "ref_mc_40x33x29"])
     assert sum(os.path.getsize(os.path.join(G, n + ".npz")) for n in names) < 4 << 20  # small fixtures
 
 
@@ -338,6 +338,15 @@ def test_oracle_marching_cubes(oracle):
     v, n = oracle.marching_cubes(vol, tuple(size), R, t)
     assert f["log"] == "no. of active voxels: %d\n" % oracle.mc_occupied_voxels(vol, 4096)[1]
     assert len(v) == len(f["vertices"]) == 1164 and np.array_equal(triangle_set(v, n), triangle_set(f["vertices"], f["normals"]))
+    # a larger surface in digest form: 40 x 33 x 29
+    f = load("ref_mc_40x33x29")
+    P = f["P"]
+    vol = FI.mc_volume((40, 33, 29))
+    check(f, "in_volume", vol)
+    size = np.array([P["size_x"], P["size_y"], P["size_z"]], np.float32)
+    R, t = _pose(P, size)
+    v, n = oracle.marching_cubes(vol, tuple(size), R, t)
+    assert len(v) == 3 * int(f["n_triangles"][0]) and np.array_equal(FI.digest(triangle_set(v, n)), f["sha256_triangle_set"])
 
 
 # ------------------------------------------------------------------------------------------------- HIP (GPU box, through the C ABI)
@@ -572,3 +581,9 @@ def test_hip_marching_cubes():
     R, t = _pose(P, size)
     v, n = ops.marching_cubes(_dev(f["in_volume"]), tuple(size), R, t, max_voxels=4096)
     assert np.array_equal(triangle_set(v.cpu().numpy(), n.cpu().numpy()), triangle_set(f["vertices"], f["normals"]))
+    f = load("ref_mc_40x33x29")
+    P = f["P"]
+    size = np.array([P["size_x"], P["size_y"], P["size_z"]], np.float32)
+    R, t = _pose(P, size)
+    v, n = ops.marching_cubes(_dev(FI.mc_volume((40, 33, 29))), tuple(size), R, t, max_voxels=16384)
+    assert len(v) == 3 * int(f["n_triangles"][0]) and np.array_equal(FI.digest(triangle_set(v.cpu().numpy(), n.cpu().numpy())), f["sha256_triangle_set"])
