@@ -122,7 +122,7 @@ def cpu_baseline(P, budget_s=12.0):
 
 def reference_build_on_this_gpu(P, repeat=2):
     """Part of the baseline leg: oracle/_ref/reference_hip_ieee -- the reference's own .cu / .cpp files compiled for gfx950 by hipcc through a
-    CUDA -> HIP name-map header in the build container (tools/ref_hipbuild; shim evidence, arrays bit-identical to this repo's) -- runs its
+    CUDA -> HIP name-map header in the build container (oracle/ref_hipbuild; shim evidence, arrays bit-identical to this repo's) -- runs its
     Solver::estimate_psi on this workload.  The iteration rate is the difference of a 100- and a 50-iteration solve.  None when the binary
     is not there (it cannot be built on the GPU box: the reference does not travel)."""
     import shutil
@@ -150,7 +150,7 @@ def reference_build_on_this_gpu(P, repeat=2):
             shutil.rmtree(d, ignore_errors=True)
     return {"value": 50.0 / (t[100] - t[50]), "unit": "iterations/s", "s_per_solve_50": t[50], "s_not_iterations": t[50] - (t[100] - t[50]),
             "kind": "the reference's own kernels and host loop (ten kernels, a host synchronisation and a 128 KB read-back per iteration, solver.cu:114-193), "
-                    "compiled by hipcc for gfx950 through a CUDA -> HIP name-map header (tools/ref_hipbuild; shim evidence, not a supported build of the reference)",
+                    "compiled by hipcc for gfx950 through a CUDA -> HIP name-map header (oracle/ref_hipbuild; shim evidence, not a supported build of the reference)",
             "sample": "Solver::estimate_psi of 50 and of 100 iterations on the same %d^3 workload, best of %d each; rate = 50 / (t100 - t50)" % (dim, repeat)}
 
 

@@ -1,5 +1,5 @@
 // The reference's marching cubes kernels (src/kfusion/cuda/marching_cubes.cu) are written for 32-wide warps (ballot masks, warp scans, a PTX lane query) and 1-D texture
-// fetches; they are NOT part of the hipcc build of the reference (tools/ref_hipbuild).  SobFusion (src/sobfu/sob_fusion.cpp) and the host class MarchingCubes
+// fetches; they are NOT part of the hipcc build of the reference (oracle/ref_hipbuild).  SobFusion (src/sobfu/sob_fusion.cpp) and the host class MarchingCubes
 // (src/kfusion/marching_cubes.cpp) link against their five launchers, so the frames scenario of the driver needs the symbols: here they are, refusing to run.
 // (Marching cubes is compared with the host emulation of those kernels instead: tests/golden/ref_mc_14x11x9.npz.)
 #include <cstdio>

@@ -1,5 +1,5 @@
 // CUDA -> HIP name map, written for this repo: lets hipcc compile the reference's own .cu / .cpp files WHERE THEY LIE, for gfx950
-// (tools/ref_hipbuild/build.py -> oracle/_ref/reference_hip_{ieee,fast}).  TEST / MEASUREMENT INFRASTRUCTURE ONLY -- the product
+// (oracle/ref_hipbuild/build.py -> oracle/_ref/reference_hip_{ieee,fast}).  TEST / MEASUREMENT INFRASTRUCTURE ONLY -- the product
 // (sobfu_amd/) is written for CDNA4 from scratch and never sees this header.  What the binaries are for:
 //   ieee  (-ffp-contract=off, correctly rounded divide / sqrt): the reference's kernels running as real GPU kernels must give the
 //         SAME ARRAYS as the host emulation of tools/ref_emulation/ (tests/golden/ref_*.npz) -- a cross-check of that emulation --
@@ -7,7 +7,7 @@
 //   fast  (-ffp-contract=fast, approximate divide / sqrt, flush-to-zero: hipcc's analogues of the reference's nvcc flags
 //         --fmad=true --prec-div=false --prec-sqrt=false --ftz=true, CMakeLists.txt:40-46): the distance to the reference AS BUILT,
 //         with a real GPU compiler's contraction choices;
-//   both: how fast the reference's own 10-kernel decomposition runs on an MI355X (tools/ref_hipbuild/time_reference.py).
+//   both: how fast the reference's own 10-kernel decomposition runs on an MI355X (tests/reference_time.py).
 // SHIM EVIDENCE: a stand-in header for a toolkit the image lacks, so by the task's rules it pins nothing.
 //
 // Intrinsics (__fadd_rn / __fsub_rn / __fmul_rn / __fmaf_rn): HIP's plain operators in the `ieee` flavour, where -ffp-contract=off
@@ -131,7 +131,7 @@ struct CuemuTex2D {
     const void* ptr;
     unsigned long long width, height, pitch;
 };
-extern __device__ CuemuTex2D cuemu_tex2d_float;  // defined in tools/ref_hipbuild/texture_state.cpp
+extern __device__ CuemuTex2D cuemu_tex2d_float;  // defined in oracle/ref_hipbuild/texture_state.cpp
 template <class T, int dim, enum hipTextureReadMode mode>
 static inline cudaError_t cudaBindTexture2D(size_t* off, const texture<T, dim, mode>&, const void* p, const hipChannelFormatDesc&, size_t w, size_t h, size_t pitch) {
     static_assert(sizeof(T) == 4, "");

@@ -131,7 +131,7 @@ SOBFU_DEV float2 ld2(const float2* p) {
     return make_float2(t.x, t.y);
 }
 // grids of more cells than this stream (a float4 field of 3.3 M cells is 53 MB: a launcher chain's few arrays still fit the Infinity Cache)
-// SOBFU_LAUNCHER_NT=0 / 1 overrides (measurement: tools/ref_hipbuild/launcher_table.py).
+// SOBFU_LAUNCHER_NT=0 / 1 overrides (measurement: tests/reference_launcher_table.py).
 inline bool launcher_streams(int X, int Y, int Z) {
     if (const char* e = getenv("SOBFU_LAUNCHER_NT")) return e[0] == '1';
     return (long) X * Y * Z > 3300000L;

@@ -1,6 +1,6 @@
-"""Runs oracle/_ref/reference_hip_{ieee,fast} (the reference's own kernels compiled for gfx950 by tools/ref_hipbuild/build.py in the build
+"""Runs oracle/_ref/reference_hip_{ieee,fast} (the reference's own kernels compiled for gfx950 by oracle/ref_hipbuild/build.py in the build
 container; the binaries travel to the GPU box, the reference does not): writes the inputs as raw files, runs one scenario of the driver,
-reads the outputs back.  Test infrastructure (shim evidence, see tools/ref_hipbuild/shim/cuda_runtime.h)."""
+reads the outputs back.  Test infrastructure (shim evidence, see oracle/ref_hipbuild/shim/cuda_runtime.h)."""
 import os
 import shutil
 import subprocess

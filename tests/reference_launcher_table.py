@@ -1,7 +1,7 @@
-"""Launcher by launcher on the GPU at hand: the reference's own kernels (oracle/_ref/reference_hip_ieee, tools/ref_hipbuild) and this repo's C-ABI
+"""Launcher by launcher on the GPU at hand: the reference's own kernels (oracle/_ref/reference_hip_ieee, oracle/ref_hipbuild) and this repo's C-ABI
 launchers on the same arrays -- every row of SURVEY 8(a) that launches a kernel.
 
-    python tools/ref_hipbuild/launcher_table.py [dim] > profiles/r06/launcher_table_256.md        # on the GPU box
+    python tests/reference_launcher_table.py [dim] > profiles/r06/launcher_table_256.md        # on the GPU box
 
 reference side: the driver's `launchers` scenario (each launcher `repeat` times back to back) under `rocprofv3 --kernel-trace --stats`; the
                 kernels of one launcher call are summed (estimate_inverse = 48 sweeps, the reductions' device part only);
@@ -20,7 +20,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 F32 = np.float32
@@ -269,7 +269,7 @@ def main():
     N = dim ** 3
     exe = os.path.join(ROOT, "oracle", "_ref", "reference_hip_ieee")
     if not os.path.exists(exe):
-        raise SystemExit("oracle/_ref/reference_hip_ieee is missing: build it in the build container (python tools/ref_hipbuild/build.py)")
+        raise SystemExit("oracle/_ref/reference_hip_ieee is missing: build it in the build container (python oracle/ref_hipbuild/build.py)")
     P, ins, intr, depth = workload(dim)
     d = tempfile.mkdtemp(prefix="launchers_")
     try:
@@ -290,7 +290,7 @@ def main():
 
     print("Launcher by launcher at %d^3 on one MI355X, kernel time (`rocprofv3 --kernel-trace --stats`, average of %d calls, both sides, **512 MB overwritten before every call** so "
           "that no call finds its inputs in the 256 MB Infinity Cache because the call before it left them there): the reference's own kernels (hipcc build through a name-map "
-          "header, `tools/ref_hipbuild`) and this repo's C-ABI launchers on the same arrays%s. `warm call` = HIP events around %d back-to-back calls of this repo's launcher on the "
+          "header, `oracle/ref_hipbuild`) and this repo's C-ABI launchers on the same arrays%s. `warm call` = HIP events around %d back-to-back calls of this repo's launcher on the "
           "same arrays (launch gaps and, for the reductions, the read-back and the host finish included; inputs up to 256 MB come from the Infinity Cache there). Bytes per voxel: "
           "SURVEY 8(a)'s column for the launcher as the reference decomposes the work; fraction = kernel bytes/s over 8 TB/s. The solver does not run these kernels in its loop "
           "(it runs the two fused passes `bench.py` measures); they are the drop-in surface.\n"

@@ -1,10 +1,10 @@
 """How fast does the reference's OWN decomposition run on this GPU?  oracle/_ref/reference_hip_ieee (the reference's kernels compiled for
-gfx950 by tools/ref_hipbuild/build.py; arrays bit-identical to the host emulation and to this repo's kernels) runs Solver::estimate_psi on
+gfx950 by oracle/ref_hipbuild/build.py; arrays bit-identical to the host emulation and to this repo's kernels) runs Solver::estimate_psi on
 bench.py's workload (256^3, params_boxing.ini solver values, two initSphere volumes) as the reference drives it: ten kernels, a host
 synchronisation and a 128 KB read-back per iteration (solver.cu:114-193), then 48 inverse launches and a warp.  The iteration rate is the
 difference of a 100-iteration and a 50-iteration solve; this repo's solver runs the same workload beside it.
 
-    python tools/ref_hipbuild/time_reference.py [dim]      # on the GPU box; prints one JSON line
+    python tests/reference_time.py [dim]      # on the GPU box; prints one JSON line
 
 Shim evidence / a measured baseline, not the product: the binary exists only where the build container made it."""
 import json
@@ -12,7 +12,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -36,7 +36,7 @@ def main():
 
     dim = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     if not R.available():
-        raise SystemExit("oracle/_ref/reference_hip_ieee is missing: build it in the build container (python tools/ref_hipbuild/build.py)")
+        raise SystemExit("oracle/_ref/reference_hip_ieee is missing: build it in the build container (python oracle/ref_hipbuild/build.py)")
     ref = reference_rate(dim)
     P = bench.boxing_params(dim)
     c0, c1, r = bench.sphere_pair(P)
@@ -60,7 +60,7 @@ def main():
     ours = 50.0 / (t[100] - t[50])
     print(json.dumps({"workload": "%d^3, params_boxing.ini solver values, two initSphere volumes 1.3 voxels apart (bench.py's)" % dim,
                       "reference_build": dict(ref, what="the reference's .cu / .cpp files compiled for gfx950 by hipcc through a CUDA -> HIP name map "
-                                                      "(tools/ref_hipbuild), IEEE flavour, driven by its own Solver::estimate_psi"),
+                                                      "(oracle/ref_hipbuild), IEEE flavour, driven by its own Solver::estimate_psi"),
                       "this_repo": {"iterations_per_s": ours, "s_per_solve_50": t[50]}, "speedup_iterations": ours / ref["iterations_per_s"],
                       "speedup_whole_solve_50": ref["s_per_solve_50"] / t[50]}))
 

@@ -1,5 +1,5 @@
 """The reference's OWN kernels running as real GPU kernels on the MI355X: oracle/_ref/reference_hip_{ieee,fast}, built in the build
-container by tools/ref_hipbuild/build.py from the reference's .cu / .cpp files where they lie (hipcc through a CUDA -> HIP name map).
+container by oracle/ref_hipbuild/build.py from the reference's .cu / .cpp files where they lie (hipcc through a CUDA -> HIP name map).
 
   ieee  must give the arrays of the host emulation (tests/golden/ref_*.npz) BIT FOR BIT -- two independent executions of the same
         source lines (coroutines on a CPU, wavefronts on a GPU) agreeing is a cross-check of the emulation, and with
@@ -422,7 +422,7 @@ def test_fast_math_build_of_the_reference_distance():
 
 def test_reference_speed_on_this_gpu_beside_this_repo():
     """iterations/s of the reference's own decomposition (10 kernels, a host sync and a read-back per iteration) on this GPU, and of this
-    repo's solver on the same workload (tools/ref_hipbuild/time_reference.py records the rates, profiles/r06/reference_on_mi355x.json); asserted here
+    repo's solver on the same workload (tests/reference_time.py records the rates, profiles/r06/reference_on_mi355x.json); asserted here
     with a wide margin"""
     import torch
 

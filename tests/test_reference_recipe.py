@@ -32,8 +32,8 @@ def test_recipe_is_imported_by_the_fixture_script_only():
                 # imports or executions of the recipe (mentions in docstrings do not count)
                 if re.search(r"^\s*(import|from)\s+make_reference_fixtures|import build as emu_build|\"ref_emulation\"|make_reference_fixtures\.py\"\)", text, re.M):
                     users.append(os.path.relpath(os.path.join(base, f), ROOT))
-    # tools/ref_hipbuild/build.py shares the scenario driver and the OpenCV / PCL / Boost stand-ins (the hipcc build of the reference, GPU tests only)
-    assert sorted(users) == ["tests/golden/make_reference_fixtures.py", "tests/test_reference_recipe.py", "tools/ref_hipbuild/build.py"], users
+    # oracle/ref_hipbuild/build.py shares the scenario driver and the OpenCV / PCL / Boost stand-ins (the hipcc build of the reference, GPU tests only)
+    assert sorted(users) == ["oracle/ref_hipbuild/build.py", "tests/golden/make_reference_fixtures.py", "tests/test_reference_recipe.py"], users
 
 
 def test_launch_rewrite_is_one_regular_expression():

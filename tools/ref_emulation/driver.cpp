@@ -32,7 +32,7 @@
 #define private public  // SobFusion keeps phi_global & co. private; the dumps need to read them
 #include <sobfu/sob_fusion.hpp>
 #undef private
-#include <kfusion/cuda/marching_cubes.hpp>  // (tools/ref_hipbuild compiles this driver too, without the marching cubes KERNELS -- 32-wide warp code -- and so without the mc scenario)
+#include <kfusion/cuda/marching_cubes.hpp>  // (oracle/ref_hipbuild compiles this driver too, without the marching cubes KERNELS -- 32-wide warp code -- and so without the mc scenario)
 #include <kfusion/precomp.hpp>
 #include <sobfu/solver.hpp>
 
@@ -219,7 +219,7 @@ static void scenario_depth() {
     dump("volume", v.data());
 }
 
-// timing aid for the GPU build (tools/ref_hipbuild/launcher_table.py reads the per-kernel times from rocprofv3): every L1 launcher of the kernels and
+// timing aid for the GPU build (tests/reference_launcher_table.py reads the per-kernel times from rocprofv3): every L1 launcher of the kernels and
 // depth scenarios `repeat` times back to back on the same uploaded arrays, nothing dumped
 static void scenario_launchers() {
     Params p = make_params();
